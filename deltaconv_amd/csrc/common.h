@@ -1,0 +1,52 @@
+// Shared helpers for the DeltaConv HIP kernels (gfx950 / CDNA4 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define DC_EXPORT extern "C" __attribute__((visibility("default")))
+
+enum {
+    DC_OK = 0,
+    DC_ERR_ARG = -1,      // bad argument (null pointer, unsupported size, misaligned leading dimension)
+    DC_ERR_LAUNCH = -2,   // HIP reported a launch error (see dc_last_error)
+    DC_ERR_WORKSPACE = -3 // workspace too small
+};
+
+void dc_set_error(const char* fmt, ...);
+
+#define DC_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            dc_set_error(__VA_ARGS__);        \
+            return DC_ERR_ARG;                \
+        }                                     \
+    } while (0)
+
+#define DC_CHECK_LAUNCH(name)                                                   \
+    do {                                                                        \
+        hipError_t e_ = hipGetLastError();                                      \
+        if (e_ != hipSuccess) {                                                 \
+            dc_set_error("%s: %s", name, hipGetErrorString(e_));                \
+            return DC_ERR_LAUNCH;                                               \
+        }                                                                       \
+    } while (0)
+
+static inline int dc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Wave-level helpers -------------------------------------------------------------------------
+__device__ __forceinline__ double dc_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float dc_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float dc_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,88 @@
+// Transposed adjacency ("who lists me as a neighbour") of the kNN graph, built once per batch and
+// shared by every transposed apply / max-aggregation backward of the step.  The reference gets the
+// same effect from torch_sparse's autograd (spmm with A^T) and torch_scatter's arg-indexed backward.
+//   tptr[Nt+1], tedge[Nt*k]: in-edges of point j are tedge[tptr[j] .. tptr[j+1]), edge id e = i*k + s,
+//   sorted ascending so every transposed sum has a fixed order (bit-reproducible, no fp atomics).
+// Neighbours never leave their cloud, so the in-edges of cloud b total exactly N_b*k and the scan
+// base of cloud b is cloud_ptr[b]*k: the scan is local to a cloud (one block per cloud).
+#include "common.h"
+#include "ell_math.h"
+
+namespace {
+constexpr int TPB = 256;
+
+__global__ void csc_count_kernel(const int* __restrict__ nbr, long ne, int* __restrict__ cnt) {
+    const long e = (long)blockIdx.x * TPB + threadIdx.x;
+    if (e < ne) atomicAdd(cnt + nbr[e], 1);
+}
+
+// exclusive scan of cnt over one cloud; writes tptr and the fill cursors (cursor aliases cnt)
+__global__ __launch_bounds__(TPB) void csc_scan_kernel(const int* __restrict__ cloud_ptr, int k, int num_clouds,
+                                                       int* __restrict__ cnt, int* __restrict__ tptr) {
+    __shared__ int part[TPB];
+    const int cloud = blockIdx.x;
+    const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
+    const int per = (n + TPB - 1) / TPB;
+    const int lo = min(threadIdx.x * per, n), hi = min(lo + per, n);
+    int s = 0;
+    for (int q = lo; q < hi; ++q) s += cnt[begin + q];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = begin * k;  // in-edges of earlier clouds
+        for (int w = 0; w < TPB; ++w) {
+            const int c = part[w];
+            part[w] = run;
+            run += c;
+        }
+        if (cloud == num_clouds - 1) tptr[begin + n] = run;  // = Nt*k
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int q = lo; q < hi; ++q) {
+        const int c = cnt[begin + q];
+        tptr[begin + q] = run;
+        cnt[begin + q] = run;  // becomes the fill cursor
+        run += c;
+    }
+}
+
+__global__ void csc_fill_kernel(const int* __restrict__ nbr, long ne, int* __restrict__ cursor,
+                                int* __restrict__ tedge) {
+    const long e = (long)blockIdx.x * TPB + threadIdx.x;
+    if (e < ne) tedge[atomicAdd(cursor + nbr[e], 1)] = (int)e;
+}
+
+__global__ void csc_sort_kernel(const int* __restrict__ tptr, int n, int* __restrict__ tedge) {
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    if (j < n) dcell::sort_column(tedge, tptr[j], tptr[j + 1]);
+}
+}  // namespace
+
+DC_EXPORT size_t dc_csc_workspace_bytes(int32_t num_points) { return (size_t)num_points * 4; }
+
+DC_EXPORT int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
+                           int32_t k, int32_t* tptr, int32_t* tedge, void* workspace, size_t workspace_bytes,
+                           void* stream) {
+    DC_REQUIRE(nbr && cloud_ptr && tptr && tedge, "dc_csc_build: null pointer");
+    DC_REQUIRE(num_clouds >= 0 && num_points >= 0 && k >= 1, "dc_csc_build: bad size");
+    DC_REQUIRE((long long)num_points * k < 2147483647LL, "dc_csc_build: edge ids overflow int32");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (num_points == 0 || num_clouds == 0) return DC_OK;
+    if (!workspace || workspace_bytes < dc_csc_workspace_bytes(num_points)) {
+        dc_set_error("dc_csc_build: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    int* cnt = static_cast<int*>(workspace);
+    const long ne = (long)num_points * k;
+    if (hipMemsetAsync(cnt, 0, (size_t)num_points * 4, s) != hipSuccess) {
+        dc_set_error("dc_csc_build: memset failed");
+        return DC_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(csc_count_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, cnt);
+    hipLaunchKernelGGL(csc_scan_kernel, dim3(num_clouds), dim3(TPB), 0, s, cloud_ptr, k, num_clouds, cnt, tptr);
+    hipLaunchKernelGGL(csc_fill_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, cnt, tedge);
+    hipLaunchKernelGGL(csc_sort_kernel, dim3(dc_cdiv(num_points, TPB)), dim3(TPB), 0, s, tptr, num_points, tedge);
+    DC_CHECK_LAUNCH("dc_csc_build");
+    return DC_OK;
+}
