@@ -1,0 +1,163 @@
+"""Headline benchmark: point-clouds/sec, forward+backward(+optimizer step), ModelNet40-shaped input
+(1024 points, k=20, batch 32 per GPU), synthetic data, random-init weights, fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One JSON line on rank 0 (contract in the task statement) carrying `roofline` (the sparse operator
+apply, measured live with HIP events) and `cpu_baseline` (the oracle = CPU port of the reference
+path, timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (weak scaling)")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def apply_roofline(model_graph, grad, div, C, iters=200):
+    """Live measurement of the dominant kernel family (ELL operator apply) with HIP events on the
+    stream the kernels are launched on.  Algorithmic bytes per apply:
+    12*C*Nt + 12*E (input once, output once, ids + coefficients once)."""
+    n, k = model_graph.n, model_graph.k
+    dev = grad.coef.device
+    x = torch.randn(n, C, device=dev)
+    v = torch.randn(2 * n, C, device=dev)
+    res = {}
+    for name, fn in (("grad", lambda: grad @ x), ("div", lambda: div @ v)):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters * 1e-3      # seconds per launch
+    nbytes = 12 * C * n + 12 * n * k
+    t = 0.5 * (res["grad"] + res["div"])
+    return dict(bound="hbm", achieved=nbytes / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=nbytes / t / 1e9 / HBM_PEAK_GBS, traffic=None,
+                kernel="dc_apply_grad/dc_apply_div (ELL SpMM)", channels=C,
+                bytes_per_launch=nbytes, us_per_launch=dict(grad=res["grad"] * 1e6, div=res["div"] * 1e6))
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
+    import oracle
+    from deltaconv_amd.data import synthetic_batch
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    b = synthetic_batch(args.cpu_clouds, args.points, seed=2)
+    torch.manual_seed(1)
+    model = oracle.models.DeltaNetClassification(3, 40, num_neighbors=args.k).train()
+    times = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        model.zero_grad()
+        loss = oracle.loss.calc_loss(model(b), b.y)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+    t = min(times[1:])
+    return dict(value=args.cpu_clouds / t, unit="clouds/s", cores=threads, kind="port",
+                sample=f"oracle/ (torch-CPU restatement), {args.cpu_clouds} clouds x {args.points} pts, k={args.k}, "
+                       f"fwd+bwd train mode, best of 2 after 1 warm-up, {threads} threads")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+
+    import deltaconv_amd as dc
+    import oracle  # loss definition only (experiments/utils.py:7-24 restated); the model is the HIP product
+    from deltaconv_amd.data import synthetic_batch
+    from deltaconv_amd.dp import FlatGradDataParallel
+
+    torch.manual_seed(1)
+    model = dc.models.DeltaNetClassification(3, 40, num_neighbors=args.k).to(dev).train()
+    ddp = FlatGradDataParallel(model)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)  # train_modelnet.py:67
+    data = synthetic_batch(args.batch, args.points, seed=100 + rank).to(dev)
+
+    def step():
+        ddp.zero_grad()
+        loss = oracle.loss.calc_loss(ddp(data), data.y)
+        loss.backward()
+        ddp.reduce_gradients()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    assert torch.isfinite(loss).item(), "loss is not finite"
+
+    if rank == 0:
+        graph, grad, div = model.deltanet_base.build_operators(data)
+        roof = apply_roofline(graph, grad, div, 64)
+        out = {
+            "metric": "point-clouds/sec fwd+bwd, ModelNet40 1024pt k=20, 1/2/4/8 MI355X",
+            "value": args.batch * world * args.steps / dt, "unit": "clouds/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded smooth closed surfaces with analytic normals, random-init weights)",
+            "config": {"workload": f"ModelNet40 classification, {args.points} points, k={args.k}, "
+                                   f"batch={args.batch} per GPU, fwd+bwd+SGD step, train-mode BN/Dropout",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""ctypes binding of libdeltaconv_hip.so -- the C ABI declared in include/deltaconv_hip.h.
+
+The argtypes are parsed from that header at import, so the Python side cannot drift from the
+declared ABI.  There is NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import re
+
+import torch  # must be imported first: the HIP runtime already loaded by torch is reused
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libdeltaconv_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "deltaconv_hip.h")
+
+_CTYPES = {
+    "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
+    "float": ctypes.c_float,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes], [argnames])} for every dc_* prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(dc_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        restype = ctypes.c_char_p if "char" in ret else _CTYPES[ret.replace("const", "").strip()]
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                    argnames.append(a.split("*")[-1].strip())
+                else:
+                    ty, nm = a.replace("const ", "").rsplit(" ", 1)
+                    argtypes.append(_CTYPES[ty.strip()])
+                    argnames.append(nm)
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+class _Lib:
+    def __init__(self):
+        self._cdll = None
+        self.protos = parse_header()
+
+    def load(self):
+        if self._cdll is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is not built. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C deltaconv_amd/csrc`). deltaconv_amd has no CPU / eager fallback.")
+            cdll = ctypes.CDLL(LIB_PATH)
+            for name, (restype, argtypes, _) in self.protos.items():
+                fn = getattr(cdll, name)  # AttributeError = header/library mismatch: fail loudly
+                fn.restype, fn.argtypes = restype, argtypes
+            self._cdll = cdll
+        return self._cdll
+
+    def last_error(self):
+        return (self.load().dc_last_error() or b"").decode()
+
+    def raw(self, name):
+        return getattr(self.load(), name)
+
+    def call(self, name, *args):
+        """Call an int-returning entry point on the current torch stream (appended as last arg)."""
+        fn = self.raw(name)
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                if not a.is_cuda:
+                    raise RuntimeError(f"{name}: tensor argument is not on a HIP device (no CPU path exists)")
+                conv.append(a.data_ptr())
+            else:
+                conv.append(a)
+        conv.append(torch.cuda.current_stream().cuda_stream)
+        rc = fn(*conv)
+        if rc != 0:
+            raise RuntimeError(f"{name} failed (rc={rc}): {self.last_error()}")
+
+
+lib = _Lib()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("deltaconv_amd needs a HIP device (MI355X); there is no CPU fallback. "
+                           "The CPU restatement lives in oracle/ and is test infrastructure only.")

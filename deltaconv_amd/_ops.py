@@ -1,0 +1,138 @@
+"""torch.autograd wrappers around the C-ABI kernels (forward + hand-written backward each).
+
+Operators (G, D) depend on geometry only and never require grad (reference: backward never
+differentiates through build_grad_div), so every backward is a transposed
+apply over the graph's CSC.
+"""
+import torch
+
+from ._lib import lib
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+class _Apply(torch.autograd.Function):
+    """kind in {'grad','div'}: y = A @ x with A in ELL form."""
+
+    @staticmethod
+    def forward(ctx, x, coef, graph, kind):
+        x = _f32c(x)
+        n, k, c = graph.n, graph.k, x.shape[1]
+        ctx.graph, ctx.kind, ctx.coef = graph, kind, coef
+        if kind == 'grad':
+            assert x.shape[0] == n, f"grad @ x: x has {x.shape[0]} rows, graph has {n} points"
+            out = torch.empty(2 * n, c, dtype=torch.float32, device=x.device)
+            lib.call("dc_apply_grad", coef, graph.nbr, n, k, x, c, c, out, c)
+        else:
+            assert x.shape[0] == 2 * n, f"div @ v: v has {x.shape[0]} rows, graph has {n} points"
+            out = torch.empty(n, c, dtype=torch.float32, device=x.device)
+            lib.call("dc_apply_div", coef, graph.nbr, n, k, x, c, c, out, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32c(dy)
+        g, c = ctx.graph, dy.shape[1]
+        tptr, tedge = g.csc()
+        if ctx.kind == 'grad':
+            dx = torch.empty(g.n, c, dtype=torch.float32, device=dy.device)
+            lib.call("dc_apply_grad_T", ctx.coef, tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
+        else:
+            dx = torch.empty(2 * g.n, c, dtype=torch.float32, device=dy.device)
+            lib.call("dc_apply_div_T", ctx.coef, tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
+        return dx, None, None, None
+
+
+class _DivCurlNorm(torch.autograd.Function):
+    """v[2Nt,C] -> [div v | curl v | norm v] [Nt,3C] in one gather pass."""
+
+    @staticmethod
+    def forward(ctx, v, coef, graph):
+        v = _f32c(v)
+        n, k, c = graph.n, graph.k, v.shape[1]
+        assert v.shape[0] == 2 * n
+        out = torch.empty(n, 3 * c, dtype=torch.float32, device=v.device)
+        lib.call("dc_apply_div_curl_norm", coef, graph.nbr, n, k, v, c, c, out, 3 * c)
+        ctx.graph, ctx.coef = graph, coef
+        ctx.save_for_backward(v)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        (v,) = ctx.saved_tensors
+        g, c = ctx.graph, v.shape[1]
+        tptr, tedge = g.csc()
+        dv = torch.empty_like(v)
+        lib.call("dc_apply_div_curl_norm_T", ctx.coef, tptr, tedge, g.n, g.k, dout, c, 3 * c, v, c, dv, c, 0)
+        return dv, None, None
+
+
+class _Hodge(torch.autograd.Function):
+    """dcn[Nt, >=2C] holding [div v | curl v | ...] -> hodge_laplacian(v) [2Nt,C]."""
+
+    @staticmethod
+    def forward(ctx, dcn, coef, graph, c):
+        dcn = _f32c(dcn)
+        n, k = graph.n, graph.k
+        ld = dcn.shape[1]
+        assert dcn.shape[0] == n and ld >= 2 * c
+        out = torch.empty(2 * n, c, dtype=torch.float32, device=dcn.device)
+        lib.call("dc_apply_hodge", coef, graph.nbr, n, k, dcn, c, ld, out, c)
+        ctx.graph, ctx.coef, ctx.c, ctx.ld = graph, coef, c, ld
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        dh = _f32c(dh)
+        g, c, ld = ctx.graph, ctx.c, ctx.ld
+        tptr, tedge = g.csc()
+        ddcn = torch.zeros(g.n, ld, dtype=torch.float32, device=dh.device) if ld > 2 * c else \
+            torch.empty(g.n, ld, dtype=torch.float32, device=dh.device)
+        lib.call("dc_apply_hodge_T", ctx.coef, tptr, tedge, g.n, g.k, dh, c, c, ddcn, ld, 0)
+        return ddcn, None, None, None
+
+
+class _KnnMax(torch.autograd.Function):
+    """out[i,c] = max over the k neighbours of h[.,c]; first maximal slot takes the gradient."""
+
+    @staticmethod
+    def forward(ctx, h, graph):
+        h = _f32c(h)
+        n, k, c = graph.n, graph.k, h.shape[1]
+        assert h.shape[0] == n
+        out = torch.empty(n, c, dtype=torch.float32, device=h.device)
+        arg = torch.empty(n, c, dtype=torch.uint8, device=h.device)
+        lib.call("dc_knn_max", graph.nbr, n, k, h, c, c, out, c, arg)
+        ctx.graph = graph
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, dout, _darg):
+        dout = _f32c(dout)
+        (arg,) = ctx.saved_tensors
+        g, c = ctx.graph, dout.shape[1]
+        tptr, tedge = g.csc()
+        dh = torch.empty(g.n, c, dtype=torch.float32, device=dout.device)
+        lib.call("dc_knn_max_backward", tptr, tedge, g.n, g.k, arg, dout, c, c, dh, c, 0)
+        return dh, None
+
+
+def apply_op(x, coef, graph, kind):
+    return _Apply.apply(x, coef, graph, kind)
+
+
+def div_curl_norm(v, div):
+    return _DivCurlNorm.apply(v, div.coef, div.graph)
+
+
+def hodge_from_dcn(dcn, grad, c):
+    return _Hodge.apply(dcn, grad.coef, grad.graph, c)
+
+
+def knn_max(h, graph):
+    return _KnnMax.apply(h, graph)[0]

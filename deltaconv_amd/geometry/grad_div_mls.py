@@ -1,0 +1,96 @@
+"""Tangent bases and moving-least-squares gradient / divergence operators on the GPU.
+
+API mirror of the reference's deltaconv/geometry/grad_div_mls.py (same names, argument order,
+defaults); the work is done by dc_tangent_basis / dc_estimate_basis / dc_mls_assemble
+(deltaconv_amd/csrc/{basis,mls}.hip).  ``edge_index`` may be the reference's [2,E] tensor or a
+``Graph``; operators come back as ``SparseOp`` (ELL coefficients, supports ``.size(i)`` and ``@``).
+"""
+import torch
+
+from .._lib import lib, require_gpu
+from .. import _ops
+from .graph import Graph, as_graph, _ptr_from_batch
+
+EPS = 1e-5
+
+
+class SparseOp:
+    """grad (2Nt x Nt) or div (Nt x 2Nt) as coef[Nt,k,2] over graph.nbr.  Stands where the
+    reference holds a torch_sparse.SparseTensor (grad_div_mls.py:263,275)."""
+
+    def __init__(self, kind, graph, coef):
+        assert kind in ("grad", "div")
+        self.kind, self.graph, self.coef = kind, graph, coef
+
+    def size(self, i):
+        n = self.graph.n
+        return ((2 * n, n) if self.kind == "grad" else (n, 2 * n))[i]
+
+    def sizes(self):
+        return [self.size(0), self.size(1)]
+
+    def __matmul__(self, x):
+        return _ops.apply_op(x, self.coef, self.graph, self.kind)
+
+    def coo(self):
+        """(row, col, value) triplets in the reference's order (grad_div_mls.py:253-255,271-274)."""
+        n, k = self.graph.n, self.graph.k
+        i = torch.arange(n, device=self.coef.device).repeat_interleave(k)
+        j = self.graph.nbr.reshape(-1).long()
+        if self.kind == "grad":
+            return (torch.stack([2 * i, 2 * i + 1], 1).reshape(-1), torch.stack([j, j], 1).reshape(-1),
+                    self.coef.reshape(-1))
+        return (torch.stack([i, i], 1).reshape(-1), torch.stack([2 * j, 2 * j + 1], 1).reshape(-1),
+                self.coef.reshape(-1))
+
+
+def _graph_from(edge_index, n, k=None, batch=None):
+    if isinstance(edge_index, Graph):
+        return edge_index
+    from .graph import _GRAPH_OF
+    g = _GRAPH_OF.get(id(edge_index))
+    if g is not None and g._edge_index is edge_index:
+        return g
+    return Graph.from_edge_index(edge_index, n, k=k, batch=batch)
+
+
+def build_tangent_basis(normal):
+    """grad_div_mls.py:50-69 -> (x_basis, y_basis)."""
+    require_gpu()
+    normal = normal.contiguous().float()
+    xb, yb = torch.empty_like(normal), torch.empty_like(normal)
+    lib.call("dc_tangent_basis", normal, normal.shape[0], xb, yb)
+    return xb, yb
+
+
+def estimate_basis(pos, edge_index, k=None, orientation=None):
+    """grad_div_mls.py:10-47 -> (normal, x_basis, y_basis).  x_basis sign: largest-|component|
+    positive (the reference inherits LAPACK's arbitrary sign)."""
+    require_gpu()
+    pos = pos.contiguous().float()
+    g = _graph_from(edge_index, pos.shape[0], k)
+    normal, xb, yb = torch.empty_like(pos), torch.empty_like(pos), torch.empty_like(pos)
+    orient = None if orientation is None else orientation.contiguous().float()
+    lib.call("dc_estimate_basis", pos, g.nbr, g.n, g.k, orient, normal, xb, yb)
+    return normal, xb, yb
+
+
+def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel_width=1, regularizer=0.001,
+                   normalized=True, shape_regularizer=None):
+    """grad_div_mls.py:197-277 -> (grad, div) as SparseOp."""
+    require_gpu()
+    if shape_regularizer is not None:
+        raise NotImplementedError("shape_regularizer is unused by every reference model/experiment")
+    pos = pos.contiguous().float()
+    n = pos.shape[0]
+    g = _graph_from(edge_index, n, batch=batch)
+    if batch is not None and g.num_clouds == 1 and not isinstance(edge_index, Graph):
+        g.ptr, g.num_clouds, g.max_cloud = _ptr_from_batch(batch, n, pos.device)
+    G = torch.empty(n, g.k, 2, dtype=torch.float32, device=pos.device)
+    D = torch.empty(n, g.k, 2, dtype=torch.float32, device=pos.device)
+    nbytes = lib.raw("dc_mls_workspace_bytes")(g.num_clouds, n)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=pos.device)
+    lib.call("dc_mls_assemble", pos, normal.contiguous().float(), x_basis.contiguous().float(),
+             y_basis.contiguous().float(), g.nbr, g.ptr, g.num_clouds, n, g.max_cloud, g.k, float(kernel_width),
+             float(regularizer), int(bool(normalized)), G, D, ws, ws.numel() * 8)
+    return SparseOp("grad", g, G), SparseOp("div", g, D)

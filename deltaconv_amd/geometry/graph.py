@@ -1,0 +1,101 @@
+"""Fixed-degree kNN graph of a batch of clouds, held the way the HIP kernels want it.
+
+Replaces the ``edge_index`` produced by ``knn_graph(pos, k, batch, loop=True,
+flow='target_to_source')`` (reference: deltaconv/models/deltanet_base.py:52,63).  ``Graph``
+keeps ``nbr[Nt,k] int32`` (centre-major, so ``edge_index = (repeat_interleave(arange(Nt), k),
+nbr.flatten())`` is the reference's tensor) and lazily builds the transposed adjacency used by
+every backward op of the step.
+"""
+import weakref
+
+import torch
+
+from .._lib import lib, require_gpu
+
+
+def _ptr_from_batch(batch, n, device):
+    """(ptr int32 [B+1] on device, num_clouds, max_cloud_size).  One host sync when batch is given."""
+    if batch is None:
+        return torch.tensor([0, n], dtype=torch.int32, device=device), 1, n
+    counts = torch.bincount(batch)
+    ptr = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=device)
+    ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return ptr, int(counts.numel()), int(counts.max())
+
+
+class Graph:
+    def __init__(self, nbr, ptr, num_clouds, max_cloud):
+        self.nbr = nbr                                    # [Nt,k] int32, global ids
+        self.n, self.k = int(nbr.shape[0]), int(nbr.shape[1])
+        self.ptr, self.num_clouds, self.max_cloud = ptr, num_clouds, max_cloud
+        self._csc = None
+        self._edge_index = None
+
+    @staticmethod
+    def knn(pos, k, batch=None, ptr_info=None, lanes_per_query=0):
+        """k nearest neighbours per cloud incl. self (bit-exact order: fp32 ((dx*dx+dy*dy)+dz*dz)
+        ascending, ties by lower index)."""
+        require_gpu()
+        pos = pos.contiguous().float()
+        n = pos.shape[0]
+        ptr, nc, mx = ptr_info if ptr_info is not None else _ptr_from_batch(batch, n, pos.device)
+        nbr = torch.empty(n, k, dtype=torch.int32, device=pos.device)
+        lib.call("dc_knn", pos, ptr, nc, mx, k, lanes_per_query, nbr)
+        return Graph(nbr, ptr, nc, mx)
+
+    @staticmethod
+    def from_edge_index(edge_index, num_points, k=None, batch=None, ptr_info=None):
+        """Adopt a reference-style ``edge_index[2,E]`` (centre-major, fixed k: the layout the
+        reference itself relies on, grad_div_mls.py:24-25,85,224)."""
+        e = edge_index.shape[1]
+        k = e // num_points if k is None else int(k)
+        assert k * num_points == e, "edge_index is not a fixed-degree centre-major kNN graph"
+        nbr = edge_index[1].reshape(num_points, k).to(torch.int32).contiguous()
+        ptr, nc, mx = ptr_info if ptr_info is not None else _ptr_from_batch(batch, num_points, edge_index.device)
+        g = Graph(nbr, ptr, nc, mx)
+        g._edge_index = edge_index
+        return g
+
+    @property
+    def edge_index(self):
+        if self._edge_index is None:
+            row = torch.arange(self.n, device=self.nbr.device).repeat_interleave(self.k)
+            self._edge_index = torch.stack([row, self.nbr.reshape(-1).long()], 0)
+            _GRAPH_OF[id(self._edge_index)] = self
+        return self._edge_index
+
+    def csc(self):
+        """(tptr[Nt+1], tedge[Nt*k]) int32: in-edges per point, ascending edge id; built once."""
+        if self._csc is None:
+            dev = self.nbr.device
+            tptr = torch.empty(self.n + 1, dtype=torch.int32, device=dev)
+            tedge = torch.empty(self.n * self.k, dtype=torch.int32, device=dev)
+            ws = torch.empty(self.n, dtype=torch.int32, device=dev)
+            lib.call("dc_csc_build", self.nbr, self.ptr, self.num_clouds, self.n, self.k, tptr, tedge, ws,
+                     ws.numel() * 4)
+            self._csc = (tptr, tedge)
+        return self._csc
+
+
+# id(edge_index tensor handed out by Graph.edge_index) -> Graph (cheap round trip; weak: no leak)
+_GRAPH_OF = weakref.WeakValueDictionary()
+
+
+def as_graph(edge_index, like=None):
+    """edge_index argument of the reference API -> Graph.  Accepts a Graph, an edge_index tensor
+    previously handed out by a Graph (no rebuild), or any centre-major fixed-k edge_index."""
+    if isinstance(edge_index, Graph):
+        return edge_index
+    g = _GRAPH_OF.get(id(edge_index))
+    if g is not None and g._edge_index is edge_index:
+        return g
+    if like is not None and like._edge_index is edge_index:
+        return like
+    assert like is not None, "need the operator's graph to infer the number of points"
+    return Graph.from_edge_index(edge_index, like.n, ptr_info=(like.ptr, like.num_clouds, like.max_cloud))
+
+
+def knn_graph(x, k, batch=None, loop=True, flow='target_to_source'):
+    """Drop-in for the one call form the reference uses (deltanet_base.py:52,63) -> edge_index."""
+    assert loop and flow == 'target_to_source', "only the reference's call form is implemented"
+    return Graph.knn(x, k, batch).edge_index

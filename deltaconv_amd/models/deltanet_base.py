@@ -1,0 +1,66 @@
+"""DeltaNet backbone (reference: deltaconv/models/deltanet_base.py:9-87)."""
+import torch
+
+from ..nn import DeltaConv
+from ..geometry.graph import Graph
+from ..geometry.grad_div_mls import build_grad_div, build_tangent_basis, estimate_basis
+
+
+def _ptr_info(data):
+    """(ptr, num_clouds, max_cloud) without a device sync when the batch carries it (data.Batch)."""
+    from ..geometry.graph import _ptr_from_batch
+    info = getattr(data, "_ptr_info", None)
+    if info is not None and info[0].device == data.pos.device:
+        return info
+    if hasattr(data, "ptr") and getattr(data, "num_graphs", None) is not None and not callable(data.ptr):
+        ptr = data.ptr.to(device=data.pos.device, dtype=torch.int32)
+        sizes = (ptr[1:] - ptr[:-1])
+        info = (ptr, int(data.num_graphs), int(sizes.max()))
+    else:
+        info = _ptr_from_batch(data.batch, data.pos.shape[0], data.pos.device)
+    try:
+        data._ptr_info = info
+    except Exception:
+        pass
+    return info
+
+
+class DeltaNetBase(torch.nn.Module):
+    def __init__(self, in_channels, conv_channels, mlp_depth, num_neighbors, grad_regularizer, grad_kernel_width,
+                 centralize_first=True):
+        super().__init__()
+        self.k = num_neighbors
+        self.grad_regularizer = grad_regularizer
+        self.grad_kernel_width = grad_kernel_width
+        conv_channels = [in_channels] + list(conv_channels)
+        self.convs = torch.nn.ModuleList()
+        for i in range(len(conv_channels) - 1):
+            last_layer = i == (len(conv_channels) - 2)
+            self.convs.append(DeltaConv(conv_channels[i], conv_channels[i + 1], depth=mlp_depth,
+                                        centralized=(centralize_first and i == 0), vector=not last_layer))
+
+    @torch.no_grad()
+    def build_operators(self, data):
+        """kNN graph, tangent frames, grad/div (deltanet_base.py:52-69).  Geometry only: no autograd."""
+        pos = data.pos
+        info = _ptr_info(data)
+        graph = Graph.knn(pos, self.k, ptr_info=info)
+        if hasattr(data, 'norm') and data.norm is not None:
+            normal = data.norm
+            x_basis, y_basis = build_tangent_basis(normal)
+        else:
+            graph_normal = Graph.knn(pos, 10, ptr_info=info)
+            normal, x_basis, y_basis = estimate_basis(pos, graph_normal, orientation=pos)
+        grad, div = build_grad_div(pos, normal, x_basis, y_basis, graph, data.batch,
+                                   kernel_width=self.grad_kernel_width, regularizer=self.grad_regularizer)
+        return graph, grad, div
+
+    def forward(self, data):
+        graph, grad, div = self.build_operators(data)
+        x = data.x if hasattr(data, 'x') and data.x is not None else data.pos   # deltanet_base.py:76
+        v = grad @ x                                                             # deltanet_base.py:78
+        out = []
+        for conv in self.convs:
+            x, v = conv(x, v, grad, div, graph)
+            out.append(x)
+        return out

@@ -1,0 +1,26 @@
+"""Classification head (reference: deltaconv/models/deltanet_classification.py:9-51)."""
+import torch
+from torch.nn import Sequential as Seq, Dropout, Linear
+
+from .deltanet_base import DeltaNetBase, _ptr_info
+from .pool import global_max_pool, global_mean_pool
+from ..nn import MLP
+
+
+class DeltaNetClassification(torch.nn.Module):
+    def __init__(self, in_channels, num_classes, conv_channels=[64, 64, 128, 256], num_neighbors=20,
+                 grad_regularizer=1e-3, grad_kernel_width=1):
+        super().__init__()
+        self.deltanet_base = DeltaNetBase(in_channels, conv_channels, 1, num_neighbors, grad_regularizer,
+                                          grad_kernel_width)
+        self.lin_embedding = MLP([sum(conv_channels), 1024])
+        self.classification_head = Seq(
+            MLP([1024 * 2, 512]), Dropout(0.5), MLP([512, 256]), Dropout(0.5),
+            Linear(256, num_classes))
+
+    def forward(self, data):
+        conv_out = self.deltanet_base(data)
+        x = self.lin_embedding(torch.cat(conv_out, dim=1))
+        info = _ptr_info(data)
+        x = torch.cat([global_max_pool(x, info), global_mean_pool(x, info)], dim=1)
+        return self.classification_head(x)

@@ -1,0 +1,51 @@
+"""The DeltaConv layer (reference: deltaconv/nn/deltaconv.py:29-72), same constructor, same
+``forward(x, v, grad, div, edge_index) -> (x, v)``, same parameter names.
+
+What differs underneath: the kNN max-aggregation never materialises the [E,C] gathered tensor,
+``div v``, ``curl v`` and ``|v|`` come out of one gather pass, and the Hodge-Laplacian reuses them
+instead of recomputing two applies (operators.py:40,43 vs deltaconv.py:57)."""
+import torch
+
+from .mlp import MLP, VectorMLP
+from .. import _ops
+from ..geometry.graph import as_graph
+from ..geometry.operators import I_J
+
+
+class DeltaConv(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, depth=1, centralized=False, vector=True, aggr='max'):
+        super().__init__()
+        if aggr != 'max':
+            raise NotImplementedError("only aggr='max' (the reference default, used by every model)")
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.centralized = centralized
+        self.aggr = aggr
+        self.s_mlp_max = MLP([in_channels] + [out_channels] * depth)
+        self.s_mlp = MLP([in_channels * 4] + [out_channels] * depth)
+        self.v_mlp = VectorMLP([in_channels * 4 + out_channels * 2] + [out_channels] * depth) if vector else None
+
+    def forward(self, x, v, grad, div, edge_index):
+        graph = as_graph(edge_index, grad.graph)
+        n, k, ci = graph.n, graph.k, self.in_channels
+
+        # scalar stream: max aggregation over the k neighbours (deltaconv.py:50-54)
+        if self.centralized:
+            nbr = graph.nbr.long()
+            x_edge = (x[nbr] - x.unsqueeze(1)).reshape(n * k, ci)
+            x_max = self.s_mlp_max(x_edge).view(n, k, -1).max(dim=1).values
+        else:
+            x_max = _ops.knn_max(self.s_mlp_max(x), graph)
+
+        # [x, div v, curl v, |v|] -> MLP (deltaconv.py:57-59)
+        dcn = _ops.div_curl_norm(v, div)
+        x = x_max + self.s_mlp(torch.cat([x, dcn], dim=1))
+
+        # vector stream (deltaconv.py:64-68)
+        if self.v_mlp is not None:
+            v_cat = torch.cat([v, _ops.hodge_from_dcn(dcn, grad, ci), grad @ x], dim=1)
+            v = self.v_mlp(I_J(v_cat))
+        return x, v
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels})'

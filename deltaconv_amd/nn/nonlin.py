@@ -1,0 +1,54 @@
+"""BatchNorm over rows and the vector non-linearity.  Module tree / parameter names mirror the
+reference (deltaconv/nn/nonlin.py:11-86) so its state_dicts load unchanged."""
+import torch
+from torch import Tensor
+import torch.nn.functional as F
+
+EPS = 1e-8  # nonlin.py:8
+
+
+class BatchNorm1d(torch.nn.Module):
+    """nonlin.py:11-35: batch norm over the rows of an [N,C] tensor (statistics over all N rows).
+    The reference reshapes to [1,C,N]; an [N,C] input has identical statistics."""
+
+    def __init__(self, in_channels, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = torch.nn.BatchNorm1d(in_channels, eps, momentum, affine, track_running_stats)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.bn.reset_parameters()
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.bn(x)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.bn.num_features})'
+
+
+class VectorNonLin(torch.nn.Module):
+    """nonlin.py:38-86: scale each tangent vector by nonlin(bn(|v|)) / max(|v|, 1e-8)."""
+
+    def __init__(self, in_channels, nonlin=torch.nn.ReLU(), batchnorm=None):
+        super().__init__()
+        self.bias = torch.nn.Parameter(torch.zeros(in_channels))
+        self.nonlin = nonlin
+        self.batchnorm = batchnorm
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            self.bias.zero_()
+        if self.batchnorm is not None:
+            self.batchnorm.reset_parameters()
+
+    def forward(self, x: Tensor) -> Tensor:
+        n, c = x.shape
+        w = x.view(-1, 2, c)
+        mag = w.norm(dim=1)
+        shifted = mag + self.bias.view(1, -1) if self.batchnorm is None else self.batchnorm(mag)
+        scale = self.nonlin(shifted) / mag.clamp(EPS)
+        return (w * scale.unsqueeze(1)).reshape(n, c)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}(batchnorm={self.batchnorm.__repr__()})'

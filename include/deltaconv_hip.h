@@ -1,0 +1,109 @@
+/* deltaconv_hip.h -- C ABI of libdeltaconv_hip.so (MI355X / gfx950).
+ *
+ * The reference (rubenwiersma/deltaconv) has no FFI boundary on its hot path: it is Python over
+ * third-party torch extensions (torch_cluster / torch_sparse / torch_scatter) and ATen.  The entry
+ * points below are what a binding for that path binds INSTEAD of those packages; each one cites
+ * the reference call site(s) it replaces (paths relative to /root/reference).  INTEGRATION.md
+ * shows the ctypes stub and the reference-side edits.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP), fp32 / int32 / uint8 as typed; no torch types.
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued, nothing syncs,
+ *     nothing allocates (callers pass workspaces) -> every entry point is hipGraph-capturable.
+ *   - return 0 on success, <0 on error (DC_ERR_*); dc_last_error() gives the message.
+ *   - layouts: nbr[Nt,k] centre-major (edge e = i*k+s); G,D [Nt,k,2]; scalar fields [Nt, ld];
+ *     vector fields [2Nt, ld] with row 2i = u-, row 2i+1 = v-component
+ *     (deltaconv/geometry/operators.py:4-21); `ld*` = row stride in floats (>= row length), so
+ *     outputs can land directly in a column block of a wider concat buffer.
+ *   - clouds of a batch are contiguous; cloud_ptr[B+1] int32 offsets (sorted `batch` vector of
+ *     deltaconv/models/deltanet_base.py:44).
+ */
+#ifndef DELTACONV_HIP_H
+#define DELTACONV_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DC_OK 0
+#define DC_ERR_ARG (-1)
+#define DC_ERR_LAUNCH (-2)
+#define DC_ERR_WORKSPACE (-3)
+
+int32_t dc_version(void);
+const char* dc_last_error(void);
+
+/* ---- graph ------------------------------------------------------------------------------- */
+/* knn_graph(pos, k, batch, loop=True, flow='target_to_source')  (torch_cluster via
+ * torch_geometric) -- deltaconv/models/deltanet_base.py:52,63.
+ * Order: fp32 ((dx*dx+dy*dy)+dz*dz) ascending, ties by lower index, self included; global ids.
+ * Every cloud needs >= k points; k <= 64.  lanes_per_query: 0 = auto, 1 or 8. */
+int dc_knn(const float* pos, const int32_t* cloud_ptr, int32_t num_clouds, int32_t max_cloud_size, int32_t k,
+           int32_t lanes_per_query, int32_t* nbr, void* stream);
+
+/* Transposed adjacency of nbr (in-edges per point, ascending edge id).  Stands in for the A^T
+ * products torch_sparse autograd performs and torch_scatter's arg-indexed backward. */
+size_t dc_csc_workspace_bytes(int32_t num_points);
+int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points, int32_t k,
+                 int32_t* tptr /*[Nt+1]*/, int32_t* tedge /*[Nt*k]*/, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* ---- tangent frames ------------------------------------------------------------------------ */
+/* build_tangent_basis -- deltaconv/geometry/grad_div_mls.py:50-69 */
+int dc_tangent_basis(const float* normal, int32_t n, float* x_basis, float* y_basis, void* stream);
+/* estimate_basis -- deltaconv/geometry/grad_div_mls.py:10-47 (orientation may be NULL).
+ * x_basis sign convention: largest-|component| positive (LAPACK's sign is arbitrary). */
+int dc_estimate_basis(const float* pos, const int32_t* nbr, int32_t n, int32_t k, const float* orientation,
+                      float* normal, float* x_basis, float* y_basis, void* stream);
+
+/* ---- operator assembly ---------------------------------------------------------------------- */
+/* build_grad_div (+ coords_projected, gaussian_weights, weighted_least_squares,
+ * fit_vector_mapping) -- deltaconv/geometry/grad_div_mls.py:72-277.  Outputs the gradient and
+ * divergence operators as G[Nt,k,2], D[Nt,k,2] over nbr (never COO/CSR). */
+size_t dc_mls_workspace_bytes(int32_t num_clouds, int32_t num_points);
+int dc_mls_assemble(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                    const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
+                    int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer, int32_t normalized,
+                    float* G, float* D, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- operator applies (SparseTensor @ dense: deltanet_base.py:78; deltaconv.py:57,66;
+ *      operators.py:27,33,40,43) ------------------------------------------------------------- */
+/* out[2Nt,C] = grad @ x[Nt,C] */
+int dc_apply_grad(const float* G, const int32_t* nbr, int32_t n, int32_t k, const float* x, int32_t C, int64_t ldx,
+                  float* out, int64_t ldo, void* stream);
+/* out[Nt,C] = div @ v[2Nt,C] */
+int dc_apply_div(const float* D, const int32_t* nbr, int32_t n, int32_t k, const float* v, int32_t C, int64_t ldv,
+                 float* out, int64_t ldo, void* stream);
+/* out[Nt,3C] = [div v | curl v | norm v]  (deltaconv.py:57 + operators.py:4-7,23-27), v read once */
+int dc_apply_div_curl_norm(const float* D, const int32_t* nbr, int32_t n, int32_t k, const float* v, int32_t C,
+                           int64_t ldv, float* out, int64_t ldo, void* stream);
+/* out[2Nt,C] = hodge_laplacian(v) given dc[Nt,2C] = [div v | curl v]  (operators.py:35-46) */
+int dc_apply_hodge(const float* G, const int32_t* nbr, int32_t n, int32_t k, const float* dc, int32_t C, int64_t lddc,
+                   float* out, int64_t ldo, void* stream);
+
+/* Transposed forms = backward of the four applies (operators carry no gradient).  accumulate != 0
+ * adds into the destination (gradient accumulation without a separate add). */
+int dc_apply_grad_T(const float* G, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
+                    int32_t C, int64_t ldy, float* dx, int64_t ldx, int32_t accumulate, void* stream);
+int dc_apply_div_T(const float* D, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
+                   int32_t C, int64_t ldy, float* dv, int64_t ldv, int32_t accumulate, void* stream);
+int dc_apply_hodge_T(const float* G, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dh,
+                     int32_t C, int64_t ldh, float* ddc, int64_t lddc, int32_t accumulate, void* stream);
+int dc_apply_div_curl_norm_T(const float* D, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k,
+                             const float* dout, int32_t C, int64_t ldo, const float* v, int64_t ldv, float* dv,
+                             int64_t lddv, int32_t accumulate, void* stream);
+
+/* ---- max aggregation (torch_scatter.scatter(reduce='max'): deltaconv/nn/deltaconv.py:52,54) -- */
+/* out[i,c] = max_s h[nbr[i,s],c]; arg[Nt,C] = first maximal slot (k <= 255) */
+int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float* out,
+               int64_t ldo, uint8_t* arg, void* stream);
+int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const uint8_t* arg,
+                        const float* dout, int32_t C, int64_t ldo, float* dh, int64_t ldh, int32_t accumulate,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DELTACONV_HIP_H */

@@ -1,0 +1,181 @@
+"""GPU parity of the layer / model level: deltaconv_amd (HIP kernels behind the reference's
+nn / models API) vs the reference's golden vectors and vs the CPU oracle run on the same inputs
+and weights.  Tolerances (scale-relative, tests/helpers.rel_err): layer outputs / grads 2e-3 vs
+the reference's fp32 numbers (bounded by the reference's own fp32 LU in build_grad_div), 1e-3 vs
+the fp64 run; whole-model logits 2e-2 (train-mode BatchNorm over 4-6 layers amplifies fp32
+rounding: the reference's own fp32-vs-fp64 logits differ by ~1e-3..1e-2 on these fixtures)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import geometry as geo
+from tests.helpers import load_golden, rel_err
+from tests.golden.probes import probe_vec, param_summaries, state_checksum
+from deltaconv_amd.data import Batch, synthetic_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CONV_CFGS = {"cent": dict(ci=3, co=8, centralized=True, vector=True),
+             "plain": dict(ci=8, co=16, centralized=False, vector=True),
+             "last": dict(ci=8, co=8, centralized=False, vector=False)}
+
+
+@pytest.mark.parametrize("cname", list(CONV_CFGS))
+def test_deltaconv_layer_golden(cname):
+    import deltaconv_amd as dc
+    g = load_golden("deltaconv_layers")
+    cfg = CONV_CFGS[cname]
+    pos, normal, batch = g["pos"].to(DEV), g["normal"].to(DEV), g["batch"].to(DEV)
+    ei = g["edge_index"].to(DEV)
+    xb, yb = dc.geometry.build_tangent_basis(normal)
+    grad, div = dc.geometry.build_grad_div(pos, normal, xb, yb, ei, batch, regularizer=g["lam"])
+    conv = dc.nn.DeltaConv(cfg["ci"], cfg["co"], 1, cfg["centralized"], cfg["vector"])
+    assert repr(conv) == f'DeltaConv({cfg["ci"]}, {cfg["co"]})'
+    sd = {k[len(cname) + 4:]: v for k, v in g.items() if k.startswith(cname + "_sd_")}
+    res = conv.load_state_dict(sd, strict=False)
+    assert all("num_batches" in m for m in res.missing_keys) and not res.unexpected_keys
+    conv = conv.to(DEV).train()
+    x = g[f"{cname}_x"].to(DEV).requires_grad_(True)
+    v = g[f"{cname}_v"].to(DEV).requires_grad_(True)
+    xo, vo = conv(x, v, grad, div, ei)
+    loss = (xo * probe_vec(tuple(xo.shape), 11).float().to(DEV)).sum()
+    if cfg["vector"]:
+        loss = loss + (vo * probe_vec(tuple(vo.shape), 12).float().to(DEV)).sum()
+    else:
+        assert vo is v
+    loss.backward()
+    for tag, tol in (("f32", 2e-3), ("f64", 1e-3)):
+        assert rel_err(xo, g[f"{cname}_xo_{tag}"]) < tol
+        assert rel_err(vo, g[f"{cname}_vo_{tag}"]) < tol
+        assert rel_err(x.grad, g[f"{cname}_dx_{tag}"]) < tol
+        assert rel_err(v.grad, g[f"{cname}_dv_{tag}"]) < tol
+        for n_, p_ in conv.named_parameters():
+            key = f"{cname}_g_{n_}_{tag}"
+            if key in g:
+                assert rel_err(p_.grad, g[key]) < 5 * tol, n_
+            else:
+                assert p_.grad is None, n_
+        for n_, b_ in conv.named_buffers():
+            if "running" in n_:
+                assert rel_err(b_, g[f"{cname}_buf_{n_}_{tag}"]) < tol, n_
+
+
+MODELS = {
+    "model_cls_B4_N256_k20": ("cls", dict(in_channels=3, num_classes=40), True),
+    "model_seg_B2_N256_k20": ("seg", dict(in_channels=3, num_classes=50, categorical_vector=True), True),
+    "model_cls_nonormals_B2_N256_k20": ("cls", dict(in_channels=3, num_classes=15, conv_channels=[64, 64, 64, 128]), False),
+}
+
+
+def _model(kind, kw, k, lam):
+    import deltaconv_amd as dc
+    torch.manual_seed(1)
+    cls = dc.models.DeltaNetSegmentation if kind == "seg" else dc.models.DeltaNetClassification
+    return cls(num_neighbors=k, grad_regularizer=lam, **kw)
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    return model
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_model_step_golden(name):
+    """Same seed -> same init as the reference (checksum), then one train-mode step."""
+    kind, kw, normals = MODELS[name]
+    g = load_golden(name)
+    model = _model(kind, kw, g["k"], g["lam"])
+    assert np.array_equal(state_checksum(model), g["state_checksum"].numpy())
+    model = _no_dropout(model.to(DEV).train())
+    data = Batch(g["pos"], g["batch"], g["normal"] if normals else None, None, g["y"],
+                 g["category"] if "category" in g else None).to(DEV)
+    logits = model(data)
+    loss = oracle.loss.calc_loss(logits, data.y, smoothing=(kind != "seg"))
+    loss.backward()
+    tol = 2e-2 if normals else 5e-2      # no-normals: SVD-sign gauge + ill-defined x axis
+    assert rel_err(logits, g["logits_f64"]) < tol
+    assert rel_err(logits, g["logits_f32"]) < tol
+    assert abs(float(loss) - float(g["loss_f64"])) < tol * abs(float(g["loss_f64"]))
+    names, norms, dots = param_summaries(model)
+    assert names == [str(s) for s in g["gnames"]]
+    gn = g["gnorm_f64"].numpy()
+    assert np.max(np.abs(np.array(norms) - gn) / (gn + 1e-3 * gn.max())) < 5 * tol
+    key = ("lin_global" if kind == "seg" else "lin_embedding") + ".0.1.bn.running_mean"
+    assert rel_err(dict(model.named_buffers())[key], g["rm_embed_f64"]) < tol
+
+
+@pytest.mark.parametrize("B,N,k", [(2, 512, 20), (8, 1024, 20)])
+def test_model_step_vs_oracle(B, N, k):
+    """Beyond the fixtures: a bigger batch against the CPU oracle on identical inputs and weights,
+    every parameter gradient compared tensor by tensor."""
+    b = synthetic_batch(B, N, seed=40)
+    torch.manual_seed(1)
+    ref = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=k).train())
+    model = _model("cls", dict(in_channels=3, num_classes=40), k, 1e-3)
+    model.load_state_dict(ref.state_dict())
+    model = _no_dropout(model.to(DEV).train())
+    lo = ref(b)
+    oracle.loss.calc_loss(lo, b.y).backward()
+    bd = b.to(DEV)
+    ld = model(bd)
+    oracle.loss.calc_loss(ld, bd.y).backward()
+    assert rel_err(ld, lo) < 2e-2
+    worst = 0.0
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n1 == n2
+        if p2.grad is None:
+            assert p1.grad is None, n1
+            continue
+        err = float((p1.grad.cpu() - p2.grad).abs().max()) / max(float(p2.grad.abs().max()), 1e-3 * gmax)
+        worst = max(worst, err)
+        assert err < 0.1, (n1, err)
+    print("worst per-parameter relative grad error", worst)
+
+
+def test_eval_mode_and_determinism():
+    b = synthetic_batch(2, 512, seed=41).to(DEV)
+    model = _model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).eval()
+    with torch.no_grad():
+        a1 = model(b)
+        a2 = model(b)
+    assert torch.equal(a1, a2) and a1.shape == (2, 40) and not torch.isnan(a1).any()
+    model.train()
+    _no_dropout(model)
+    grads = []
+    for _ in range(2):
+        model.zero_grad()
+        oracle.loss.calc_loss(model(b), b.y).backward()
+        grads.append(torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]).clone())
+    # our kernels are atomics-free and ordered; any residual difference would come from torch's GEMM/BN
+    assert rel_err(grads[0], grads[1]) < 1e-6
+
+
+def test_gauge_invariance_of_parameter_grads():
+    """Reference test_deltaconv (test/nn/test_deltaconv.py:42-74): parameter gradients must not
+    depend on the choice of tangent basis (atol relaxed to 1e-4: fails at 1e-5 on the reference
+    itself in fp32)."""
+    import deltaconv_amd as dc
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    N = 1000
+    x = torch.rand(N, 3, device=DEV)
+    ei = dc.geometry.knn_graph(x, 20)
+    normal, xb, yb = dc.geometry.estimate_basis(x, ei)
+    grad, div = dc.geometry.build_grad_div(x, normal, xb, yb, ei, regularizer=1e-8)
+    xr = geo.rotate_around(xb.cpu(), normal.cpu(), torch.rand(N) * 2 * torch.pi).to(DEV)
+    yr = torch.linalg.cross(normal, xr)
+    grad_r, div_r = dc.geometry.build_grad_div(x, normal, xr, yr, ei, regularizer=1e-8)
+    conv = dc.nn.DeltaConv(3, 1, depth=1, centralized=False).to(DEV)
+    target = torch.rand(N, 1, device=DEV)
+    outs = []
+    for G, D in ((grad, div), (grad_r, div_r)):
+        conv.zero_grad()
+        out, _ = conv(x, G @ x, G, D, ei)
+        F.l1_loss(out, target).backward()
+        outs.append(torch.cat([p.grad.flatten() for p in conv.parameters() if p.grad is not None]).clone())
+    assert torch.allclose(outs[0], outs[1], atol=1e-4)
