@@ -65,25 +65,37 @@ def apply_roofline(model_graph, grad, div, C, iters=200):
 
 
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload."""
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload.
+    torch's intra-op pool is tried at a few sizes (all hardware threads is pathological for the
+    many small ops of this path); the best is reported together with the thread count used."""
     import oracle
     from deltaconv_amd.data import synthetic_batch
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+    hw = os.cpu_count() or 1
     b = synthetic_batch(args.cpu_clouds, args.points, seed=2)
     torch.manual_seed(1)
     model = oracle.models.DeltaNetClassification(3, 40, num_neighbors=args.k).train()
-    times = []
-    for i in range(3):
+
+    def one():
         t0 = time.perf_counter()
         model.zero_grad()
-        loss = oracle.loss.calc_loss(model(b), b.y)
-        loss.backward()
-        times.append(time.perf_counter() - t0)
-    t = min(times[1:])
-    return dict(value=args.cpu_clouds / t, unit="clouds/s", cores=threads, kind="port",
-                sample=f"oracle/ (torch-CPU restatement), {args.cpu_clouds} clouds x {args.points} pts, k={args.k}, "
-                       f"fwd+bwd train mode, best of 2 after 1 warm-up, {threads} threads")
+        oracle.loss.calc_loss(model(b), b.y).backward()
+        return time.perf_counter() - t0
+
+    best, trials, spent = None, {}, 0.0
+    for threads in sorted({min(hw, t) for t in (32, 8, 64)}, reverse=True):
+        torch.set_num_threads(threads)
+        one()                                            # warm-up at this pool size
+        t = min(one(), one())
+        trials[threads] = round(args.cpu_clouds / t, 3)
+        spent += 3 * t
+        if best is None or t < best[1]:
+            best = (threads, t)
+        if spent > 40:
+            break
+    return dict(value=args.cpu_clouds / best[1], unit="clouds/s", cores=best[0], kind="port",
+                sample=f"oracle/ (torch-CPU restatement of the reference path), {args.cpu_clouds} clouds x "
+                       f"{args.points} pts, k={args.k}, fwd+bwd train mode, best of 2 after 1 warm-up per pool size; "
+                       f"clouds/s by torch threads: {trials}; host has {hw} hardware threads")
 
 
 def main():

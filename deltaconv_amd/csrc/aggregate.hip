@@ -11,19 +11,19 @@ using namespace dcell;
 constexpr int TPB = 256;
 
 template <int V>
-__global__ __launch_bounds__(TPB) void knn_max_fwd_kernel(long total, int groups, const int* nbr, int k,
+__global__ __launch_bounds__(TPB) void knn_max_fwd_kernel(long total, int groups, int remap, const int* nbr, int k,
                                                           const float* h, long ldh, float* out, long ldo,
                                                           unsigned char* arg, long lda) {
-    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    const long t = dc_xcd_block(remap) * TPB + threadIdx.x;
     if (t >= total) return;
     knn_max_fwd<V>(t, groups, nbr, k, h, ldh, out, ldo, arg, lda);
 }
 
 template <int V>
-__global__ __launch_bounds__(TPB) void knn_max_bwd_kernel(long total, int groups, const int* tptr, const int* tedge,
+__global__ __launch_bounds__(TPB) void knn_max_bwd_kernel(long total, int groups, int remap, const int* tptr, const int* tedge,
                                                           int k, const unsigned char* arg, long lda,
                                                           const float* dout, long ldo, float* dh, long ldh, int acc) {
-    const long t = (long)blockIdx.x * TPB + threadIdx.x;
+    const long t = dc_xcd_block(remap) * TPB + threadIdx.x;
     if (t >= total) return;
     knn_max_bwd<V>(t, groups, tptr, tedge, k, arg, lda, dout, ldo, dh, ldh, acc);
 }
@@ -43,11 +43,11 @@ DC_EXPORT int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vec_ok(C, ldh, ldo, h, out)) {
         const long total = (long)n * (C / 4);
-        hipLaunchKernelGGL(knn_max_fwd_kernel<4>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C / 4, nbr, k, h,
+        hipLaunchKernelGGL(knn_max_fwd_kernel<4>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C / 4, dc_option(DC_OPT_XCD_REMAP), nbr, k, h,
                            (long)ldh, out, (long)ldo, arg, (long)C);
     } else {
         const long total = (long)n * C;
-        hipLaunchKernelGGL(knn_max_fwd_kernel<1>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C, nbr, k, h,
+        hipLaunchKernelGGL(knn_max_fwd_kernel<1>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C, dc_option(DC_OPT_XCD_REMAP), nbr, k, h,
                            (long)ldh, out, (long)ldo, arg, (long)C);
     }
     DC_CHECK_LAUNCH("dc_knn_max");
@@ -64,11 +64,11 @@ DC_EXPORT int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (vec_ok(C, ldo, ldh, dout, dh)) {
         const long total = (long)n * (C / 4);
-        hipLaunchKernelGGL(knn_max_bwd_kernel<4>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C / 4, tptr,
+        hipLaunchKernelGGL(knn_max_bwd_kernel<4>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C / 4, dc_option(DC_OPT_XCD_REMAP), tptr,
                            tedge, k, arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate);
     } else {
         const long total = (long)n * C;
-        hipLaunchKernelGGL(knn_max_bwd_kernel<1>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C, tptr, tedge, k,
+        hipLaunchKernelGGL(knn_max_bwd_kernel<1>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C, dc_option(DC_OPT_XCD_REMAP), tptr, tedge, k,
                            arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate);
     }
     DC_CHECK_LAUNCH("dc_knn_max_backward");

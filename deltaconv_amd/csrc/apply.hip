@@ -17,8 +17,8 @@ constexpr int TPB = 256;
 
 #define DC_ELL_KERNEL(NAME, BODY, PARAMS, ARGS)                                   \
     template <int V>                                                              \
-    __global__ __launch_bounds__(TPB) void NAME##_kernel(long total, int groups, PARAMS) { \
-        const long t = (long)blockIdx.x * TPB + threadIdx.x;                      \
+    __global__ __launch_bounds__(TPB) void NAME##_kernel(long total, int groups, int remap, PARAMS) { \
+        const long t = dc_xcd_block(remap) * TPB + threadIdx.x;                   \
         if (t >= total) return;                                                   \
         BODY<V>(t, groups, ARGS);                                                 \
     }
@@ -57,7 +57,7 @@ inline int pick_v(int C, std::initializer_list<long> lds, std::initializer_list<
         const int groups_ = (C) / (V);                                                                    \
         const long total_ = (long)(n) * groups_;                                                          \
         hipLaunchKernelGGL((NAME##_kernel<V>), dim3(dc_cdiv(total_, TPB)), dim3(TPB), 0, stream, total_,  \
-                           groups_, __VA_ARGS__);                                                         \
+                           groups_, dc_option(DC_OPT_XCD_REMAP), __VA_ARGS__);                                                         \
     } while (0)
 
 #define DC_DISPATCH_V(NAME, v, n, C, stream, ...)                      \

@@ -32,6 +32,10 @@ void dc_set_error(const char* fmt, ...);
         }                                                                       \
     } while (0)
 
+// Runtime experiment switches (dc_set_option): index -> value.
+enum { DC_OPT_XCD_REMAP = 0, DC_OPT_COUNT = 8 };
+int dc_option(int key);
+
 static inline int dc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Wave-level helpers -------------------------------------------------------------------------
@@ -49,4 +53,15 @@ __device__ __forceinline__ float dc_wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+}
+
+// XCD-aware block remap (MI355X: 8 XCDs, block b is dispatched to XCD b % 8, each XCD has its own
+// 4 MiB L2).  Returns a logical block id such that every XCD owns a CONTIGUOUS range of logical
+// blocks (= contiguous points = whole clouds), so the neighbour gathers of a cloud hit one L2.
+// Pure performance: any placement gives the same result.
+__device__ __forceinline__ long dc_xcd_block(int remap) {
+    const long b = blockIdx.x, nb = gridDim.x;
+    if (!remap) return b;
+    const long q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    return xcd * q + (xcd < r ? xcd : r) + idx;
 }

@@ -34,6 +34,8 @@ extern "C" {
 
 int32_t dc_version(void);
 const char* dc_last_error(void);
+/* Experiment switch for A/B measurements.  key 0: XCD-aware block remap (default 1). */
+int dc_set_option(int32_t key, int32_t value);
 
 /* ---- graph ------------------------------------------------------------------------------- */
 /* knn_graph(pos, k, batch, loop=True, flow='target_to_source')  (torch_cluster via

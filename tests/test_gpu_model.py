@@ -89,7 +89,8 @@ def test_model_step_golden(name):
     kind, kw, normals = MODELS[name]
     g = load_golden(name)
     model = _model(kind, kw, g["k"], g["lam"])
-    assert np.array_equal(state_checksum(model), g["state_checksum"].numpy())
+    # |w| sums in double: identical weights, but the reduction order depends on the host thread count
+    assert np.allclose(state_checksum(model), g["state_checksum"].numpy(), rtol=1e-9, atol=0)
     model = _no_dropout(model.to(DEV).train())
     data = Batch(g["pos"], g["batch"], g["normal"] if normals else None, None, g["y"],
                  g["category"] if "category" in g else None).to(DEV)
@@ -111,30 +112,42 @@ def test_model_step_golden(name):
 @pytest.mark.parametrize("B,N,k", [(2, 512, 20), (8, 1024, 20)])
 def test_model_step_vs_oracle(B, N, k):
     """Beyond the fixtures: a bigger batch against the CPU oracle on identical inputs and weights,
-    every parameter gradient compared tensor by tensor."""
+    every parameter gradient compared tensor by tensor.  The tolerance is self-calibrating: the
+    oracle is run in fp64 ("truth") and in fp32 (= the reference's own numerics); max-aggregation
+    and max-pooling make gradients piecewise (an argmax can flip under fp32 rounding), so the HIP
+    path is required to be no further from truth than 3x the reference's fp32 run (+1e-3)."""
     b = synthetic_batch(B, N, seed=40)
     torch.manual_seed(1)
-    ref = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=k).train())
+    ref32 = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=k).train())
+    ref64 = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=k).double().train())
+    ref64.load_state_dict(ref32.state_dict())
     model = _model("cls", dict(in_channels=3, num_classes=40), k, 1e-3)
-    model.load_state_dict(ref.state_dict())
+    model.load_state_dict(ref32.state_dict())
     model = _no_dropout(model.to(DEV).train())
-    lo = ref(b)
-    oracle.loss.calc_loss(lo, b.y).backward()
+    l32 = ref32(b)
+    oracle.loss.calc_loss(l32, b.y).backward()
+    b64 = Batch(b.pos.double(), b.batch, b.norm.double(), None, b.y)
+    l64 = ref64(b64)
+    oracle.loss.calc_loss(l64, b.y).backward()
     bd = b.to(DEV)
     ld = model(bd)
     oracle.loss.calc_loss(ld, bd.y).backward()
-    assert rel_err(ld, lo) < 2e-2
-    worst = 0.0
-    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
-    for (n1, p1), (n2, p2) in zip(model.named_parameters(), ref.named_parameters()):
-        assert n1 == n2
-        if p2.grad is None:
+    e_hip, e_ref = rel_err(ld, l64), rel_err(l32, l64)
+    print(f"logits: hip-vs-f64 {e_hip:.2e}  oracle32-vs-f64 {e_ref:.2e}")
+    assert e_hip < 3 * e_ref + 1e-3
+    gmax = max(float(p.grad.abs().max()) for p in ref64.parameters() if p.grad is not None)
+    worst_hip = worst_ref = 0.0
+    for (n1, p1), (n2, p2), (n3, p3) in zip(model.named_parameters(), ref32.named_parameters(),
+                                            ref64.named_parameters()):
+        assert n1 == n2 == n3
+        if p3.grad is None:
             assert p1.grad is None, n1
             continue
-        err = float((p1.grad.cpu() - p2.grad).abs().max()) / max(float(p2.grad.abs().max()), 1e-3 * gmax)
-        worst = max(worst, err)
-        assert err < 0.1, (n1, err)
-    print("worst per-parameter relative grad error", worst)
+        scale = max(float(p3.grad.abs().max()), 1e-3 * gmax)
+        worst_hip = max(worst_hip, float((p1.grad.cpu().double() - p3.grad).abs().max()) / scale)
+        worst_ref = max(worst_ref, float((p2.grad.double() - p3.grad).abs().max()) / scale)
+    print(f"worst per-parameter grad error: hip-vs-f64 {worst_hip:.2e}  oracle32-vs-f64 {worst_ref:.2e}")
+    assert worst_hip < 3 * worst_ref + 1e-3
 
 
 def test_eval_mode_and_determinism():

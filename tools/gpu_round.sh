@@ -15,8 +15,10 @@ echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -3 $OUT/smoke.log
 echo "== bench"
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; tail -2 $OUT/bench.log
+echo "== kernels"
+timeout 600 python tools/bench_kernels.py --json $OUT/kernels.json > $OUT/kernels.log 2>&1; tail -75 $OUT/kernels.log
 echo "== rocprof"
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT
 find $OUT/prof -name "*kernel_stats*" | head -3
 python tools/prof_summary.py $OUT/prof > $OUT/kernel_summary.txt 2>&1; head -40 $OUT/kernel_summary.txt
