@@ -1,0 +1,486 @@
+// Fused BatchNorm(+LeakyReLU, +residual) and vector non-linearity kernels for the scalar / vector
+// MLP stream.  Replace the ATen chain the reference runs per block
+//   Linear -> BatchNorm1d -> LeakyReLU(0.2)         (/root/reference/deltaconv/nn/mlp.py:7-11,
+//                                                    nn/nonlin.py:11-35)
+//   Linear -> VectorNonLin(BatchNorm1d)             (nn/mlp.py:13-17, nn/nonlin.py:38-86)
+// around the dense GEMM (which stays a library GEMM for now).  Everything here is HBM-bound
+// streaming over [rows, C] matrices:
+//   stats   : read h once                       -> 4*C*R bytes
+//   apply   : read h (+residual), write y       -> 8..12*C*R bytes
+//   bwd     : reduce (read dy, h) + apply (read dy, h, write dh) -> 20*C*R bytes
+// Column reductions are two-stage and ordered (per-block partials in double, then a fixed-order
+// sum): bit-reproducible, no fp atomics.  Element formulas: nn_math.h.
+#include "common.h"
+#include "nn_math.h"
+#include <algorithm>
+
+namespace {
+
+using namespace dcnn;
+
+constexpr int RT = 16;          // row lanes per block
+constexpr int CT = 16;          // column groups per block
+constexpr int ROWS_PER_CHUNK = 256;
+constexpr int TPB = RT * CT;    // 256
+
+template <int V>
+struct alignas(4 * V) FV {
+    float v[V];
+};
+template <int V>
+__device__ __forceinline__ FV<V> ldv(const float* p) { return *reinterpret_cast<const FV<V>*>(p); }
+template <int V>
+__device__ __forceinline__ void stv(float* p, const FV<V>& a) { *reinterpret_cast<FV<V>*>(p) = a; }
+
+// ---- generic ordered column reduction: NQ quantities per element ------------------------------
+// grid = (row_chunks, col_tiles); partial[(chunk*NQ + q)*C + col] (double)
+template <int V, int NQ, class F>
+__global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, double* __restrict__ partial) {
+    __shared__ float sm[NQ][RT][CT * V];
+    const int cgl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c0 = (blockIdx.y * CT + cgl) * V;
+    const long r0 = (long)blockIdx.x * ROWS_PER_CHUNK;
+    const long r1 = min(r0 + ROWS_PER_CHUNK, R);
+    float acc[NQ][V];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[q][j] = 0.f;
+    if (c0 < C) {
+        for (long r = r0 + rl; r < r1; r += RT) {
+            float t[NQ][V];
+            f(r, c0, t);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[q][j] += t[q][j];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < V; ++j) sm[q][rl][cgl * V + j] = acc[q][j];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NQ * CT * V; idx += TPB) {
+        const int q = idx / (CT * V), cl = idx % (CT * V);
+        const int col = blockIdx.y * CT * V + cl;
+        if (col < C) {
+            double s = 0;
+#pragma unroll
+            for (int rr = 0; rr < RT; ++rr) s += (double)sm[q][rr][cl];
+            partial[((long)blockIdx.x * NQ + q) * C + col] = s;
+        }
+    }
+}
+
+// sums[q*C + col] = sum over chunks (fixed order)
+__global__ void colreduce_final_kernel(const double* __restrict__ partial, int chunks, int nq, int C,
+                                       double* __restrict__ sums) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nq * C) return;
+    const int q = idx / C, col = idx % C;
+    double s = 0;
+    for (int ch = 0; ch < chunks; ++ch) s += partial[((long)ch * nq + q) * C + col];
+    sums[idx] = s;
+}
+
+// ---- functors ---------------------------------------------------------------------------------
+template <int V>
+struct StatsF {  // x, x^2
+    const float* h; long ld;
+    __device__ void operator()(long r, int c0, float (&t)[2][V]) const {
+        const FV<V> x = ldv<V>(h + r * ld + c0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { t[0][j] = x.v[j]; t[1][j] = x.v[j] * x.v[j]; }
+    }
+};
+template <int V>
+struct BnBwdF {  // dz, dz*xhat
+    const float *dy, *h, *scale, *shift, *mean, *invstd; long lddy, ldh; float slope;
+    __device__ void operator()(long r, int c0, float (&t)[2][V]) const {
+        const FV<V> g = ldv<V>(dy + r * lddy + c0), x = ldv<V>(h + r * ldh + c0);
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            bn_bwd_terms(g.v[j], x.v[j], scale[c0 + j], shift[c0 + j], mean[c0 + j], invstd[c0 + j], slope, t[0][j],
+                         t[1][j]);
+    }
+};
+// vector block: "row" = point i; input rows 2i, 2i+1 of pq (combine: [P | Q] with 2*co columns)
+template <int V>
+__device__ __forceinline__ void vn_load_y(const float* in, long ld, long i, int c0, int co, int combine, FV<V>& yu,
+                                          FV<V>& yv) {
+    const FV<V> pu = ldv<V>(in + (2 * i) * ld + c0), pv = ldv<V>(in + (2 * i + 1) * ld + c0);
+    if (combine) {
+        const FV<V> qu = ldv<V>(in + (2 * i) * ld + co + c0), qv = ldv<V>(in + (2 * i + 1) * ld + co + c0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) vn_combine(pu.v[j], qu.v[j], pv.v[j], qv.v[j], yu.v[j], yv.v[j]);
+    } else {
+        yu = pu;
+        yv = pv;
+    }
+}
+template <int V>
+struct VnStatsF {  // n, n^2
+    const float* in; long ld; int co, combine;
+    __device__ void operator()(long i, int c0, float (&t)[2][V]) const {
+        FV<V> yu, yv;
+        vn_load_y<V>(in, ld, i, c0, co, combine, yu, yv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float n = vn_norm(yu.v[j], yv.v[j]); t[0][j] = n; t[1][j] = n * n; }
+    }
+};
+template <int V>
+struct VnBwdF {  // dz, dz*nhat
+    const float *in, *dout, *scale, *shift, *mean, *invstd; long ld, lddo; int co, combine;
+    __device__ void operator()(long i, int c0, float (&t)[2][V]) const {
+        FV<V> yu, yv;
+        vn_load_y<V>(in, ld, i, c0, co, combine, yu, yv);
+        const FV<V> du = ldv<V>(dout + (2 * i) * lddo + c0), dv = ldv<V>(dout + (2 * i + 1) * lddo + c0);
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            vn_bwd_terms(yu.v[j], yv.v[j], du.v[j], dv.v[j], scale[c0 + j], shift[c0 + j], mean[c0 + j],
+                         invstd[c0 + j], t[0][j], t[1][j]);
+    }
+};
+
+// ---- finalize: batch statistics -> scale/shift (+ running statistics) -------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, long R, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / (double)R;
+    double var = sums[C + c] / (double)R - m * m;  // biased (normalisation)
+    if (var < 0) var = 0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    scale[c] = (float)(g * is);
+    shift[c] = (float)(b - m * g * is);
+    if (running_mean) {  // nn.BatchNorm1d: unbiased variance into the running estimate
+        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = rm[c];
+    invstd[c] = is;
+    scale[c] = g * is;
+    shift[c] = b - rm[c] * g * is;
+}
+
+// dgamma = sum dz*xhat, dbeta = sum dz; also the per-column means the apply pass needs
+__global__ void bwd_finalize_kernel(const double* __restrict__ sums, long R, int C, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, float* __restrict__ m1, float* __restrict__ m2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)sums[c];
+    if (dgamma) dgamma[c] = (float)sums[C + c];
+    m1[c] = (float)(sums[c] / (double)R);
+    m2[c] = (float)(sums[C + c] / (double)R);
+}
+
+// ---- streaming applies ---------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ h, long R, int groups, long ldh,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     float slope, const float* __restrict__ res, long ldr,
+                                                     float* __restrict__ y, long ldy) {
+    const long total = R * groups;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        const FV<V> x = ldv<V>(h + r * ldh + c0);
+        FV<V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = act(fmaf(scale[c0 + j], x.v[j], shift[c0 + j]), slope);
+        if (res) {
+            const FV<V> rr = ldv<V>(res + r * ldr + c0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) o.v[j] += rr.v[j];
+        }
+        stv<V>(y + r * ldy + c0, o);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const float* __restrict__ dy, long lddy,
+                                                         const float* __restrict__ h, long ldh, long R, int groups,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, float slope, int training,
+                                                         const float* __restrict__ m1, const float* __restrict__ m2,
+                                                         float* __restrict__ dh, long lddh) {
+    const long total = R * groups;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long r = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        const FV<V> g = ldv<V>(dy + r * lddy + c0), x = ldv<V>(h + r * ldh + c0);
+        FV<V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = c0 + j;
+            const float gi = (gamma ? gamma[c] : 1.f) * invstd[c];
+            o.v[j] = bn_bwd_dh(g.v[j], x.v[j], scale[c], shift[c], mean[c], invstd[c], slope, gi, m1[c], m2[c],
+                               training);
+        }
+        stv<V>(dh + r * lddh + c0, o);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void vn_apply_kernel(const float* __restrict__ in, long n, int groups, long ld,
+                                                       int combine, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ out,
+                                                       long ldo) {
+    const long total = n * groups;
+    const int co = groups * V;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long i = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        FV<V> yu, yv;
+        vn_load_y<V>(in, ld, i, c0, co, combine, yu, yv);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float s = vn_scale(vn_norm(yu.v[j], yv.v[j]), scale[c0 + j], shift[c0 + j]);
+            yu.v[j] *= s;
+            yv.v[j] *= s;
+        }
+        stv<V>(out + (2 * i) * ldo + c0, yu);
+        stv<V>(out + (2 * i + 1) * ldo + c0, yv);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void vn_bwd_kernel(const float* __restrict__ in, long ld, int combine,
+                                                     const float* __restrict__ dout, long lddo, long n, int groups,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, int training,
+                                                     const float* __restrict__ m1, const float* __restrict__ m2,
+                                                     float* __restrict__ din, long lddi) {
+    const long total = n * groups;
+    const int co = groups * V;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long i = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        FV<V> yu, yv, gu, gv;
+        vn_load_y<V>(in, ld, i, c0, co, combine, yu, yv);
+        const FV<V> du = ldv<V>(dout + (2 * i) * lddo + c0), dv = ldv<V>(dout + (2 * i + 1) * lddo + c0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = c0 + j;
+            const float gi = (gamma ? gamma[c] : 1.f) * invstd[c];
+            vn_bwd_dy(yu.v[j], yv.v[j], du.v[j], dv.v[j], scale[c], shift[c], mean[c], invstd[c], gi, m1[c], m2[c],
+                      training, gu.v[j], gv.v[j]);
+        }
+        // d[P|Q]: row u = [dy_u | dy_v], row v = [dy_v | -dy_u]   (transpose of vn_combine)
+        stv<V>(din + (2 * i) * lddi + c0, gu);
+        stv<V>(din + (2 * i + 1) * lddi + c0, gv);
+        if (combine) {
+            FV<V> ngu;
+#pragma unroll
+            for (int j = 0; j < V; ++j) ngu.v[j] = -gu.v[j];
+            stv<V>(din + (2 * i) * lddi + co + c0, gv);
+            stv<V>(din + (2 * i + 1) * lddi + co + c0, ngu);
+        }
+    }
+}
+
+// ---- host helpers --------------------------------------------------------------------------
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int chunks_of(long R) { return (int)((R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK); }
+inline size_t ws_need(long R, int C) { return ((size_t)chunks_of(R) * 2 * C + 2 * (size_t)C) * 8 + 2 * (size_t)C * 4; }
+inline int stream_grid(long total) { return (int)std::min<long>((total + 255) / 256, 256L * 16); }
+
+struct Ws {
+    double* partial; double* sums; float* m1; float* m2;
+};
+inline Ws carve(void* ws, long R, int C) {
+    Ws w;
+    w.partial = static_cast<double*>(ws);
+    w.sums = w.partial + (size_t)chunks_of(R) * 2 * C;
+    w.m1 = reinterpret_cast<float*>(w.sums + 2 * (size_t)C);
+    w.m2 = w.m1 + C;
+    return w;
+}
+
+template <int V, class F>
+void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s) {
+    dim3 grid(chunks_of(R), dc_cdiv(C, CT * V));
+    hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, w.partial);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3(dc_cdiv(2 * C, 256)), dim3(256), 0, s, w.partial, chunks_of(R), 2, C,
+                       w.sums);
+}
+
+}  // namespace
+
+DC_EXPORT size_t dc_bn_workspace_bytes(int64_t rows, int32_t C) { return ws_need(rows, C); }
+
+#define DC_WS_CHECK(name, R, C)                                                   \
+    if (!workspace || workspace_bytes < ws_need(R, C)) {                          \
+        dc_set_error(name ": workspace too small (%zu < %zu)", workspace_bytes, ws_need(R, C)); \
+        return DC_ERR_WORKSPACE;                                                  \
+    }
+
+// Batch statistics of h[R,C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
+// running_mean / running_var (may be NULL) updated with `momentum` (unbiased variance).
+DC_EXPORT int dc_bn_stats(const float* h, int64_t R, int32_t C, int64_t ldh, const float* gamma, const float* beta,
+                          float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                          float* invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    DC_REQUIRE(h && mean && invstd && scale && shift, "dc_bn_stats: null pointer");
+    DC_REQUIRE(R >= 1 && C >= 1 && ldh >= C, "dc_bn_stats: bad size");
+    DC_WS_CHECK("dc_bn_stats", R, C)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, R, C);
+    if (C % 4 == 0 && ldh % 4 == 0 && al16(h))
+        run_colreduce<4>(StatsF<4>{h, (long)ldh}, R, C, w, s);
+    else
+        run_colreduce<1>(StatsF<1>{h, (long)ldh}, R, C, w, s);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)R, C, gamma, beta, eps,
+                       momentum, running_mean, running_var, mean, invstd, scale, shift);
+    DC_CHECK_LAUNCH("dc_bn_stats");
+    return DC_OK;
+}
+
+// Inference coefficients from the running statistics.
+DC_EXPORT int dc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, int32_t C, float* mean, float* invstd,
+                                float* scale, float* shift, void* stream) {
+    DC_REQUIRE(running_mean && running_var && mean && invstd && scale && shift, "dc_bn_eval_coeffs: null pointer");
+    DC_REQUIRE(C >= 1, "dc_bn_eval_coeffs: bad size");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), gamma,
+                       beta, running_mean, running_var, eps, C, mean, invstd, scale, shift);
+    DC_CHECK_LAUNCH("dc_bn_eval_coeffs");
+    return DC_OK;
+}
+
+// y = leaky_slope(scale*h + shift) (+ residual).  slope = 1 -> identity, 0 -> ReLU.
+DC_EXPORT int dc_bn_act(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift,
+                        float slope, const float* residual, int64_t ldr, float* y, int64_t ldy, void* stream) {
+    DC_REQUIRE(h && scale && shift && y, "dc_bn_act: null pointer");
+    DC_REQUIRE(R >= 0 && C >= 1 && ldh >= C && ldy >= C && (!residual || ldr >= C), "dc_bn_act: bad size");
+    if (R == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v4 = C % 4 == 0 && ldh % 4 == 0 && ldy % 4 == 0 && al16(h) && al16(y) &&
+                    (!residual || (ldr % 4 == 0 && al16(residual)));
+    if (v4)
+        hipLaunchKernelGGL(bn_act_kernel<4>, dim3(stream_grid(R * (C / 4))), dim3(256), 0, s, h, (long)R, C / 4, (long)ldh,
+                           scale, shift, slope, residual, (long)ldr, y, (long)ldy);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<1>, dim3(stream_grid(R * C)), dim3(256), 0, s, h, (long)R, C, (long)ldh, scale,
+                           shift, slope, residual, (long)ldr, y, (long)ldy);
+    DC_CHECK_LAUNCH("dc_bn_act");
+    return DC_OK;
+}
+
+// Backward of y = leaky(scale*h + shift): dh (through the batch statistics when training != 0),
+// dgamma[C], dbeta[C] (either may be NULL).
+DC_EXPORT int dc_bn_act_backward(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                                 const float* scale, const float* shift, const float* mean, const float* invstd,
+                                 const float* gamma, float slope, int32_t training, float* dh, int64_t lddh,
+                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(dy && h && scale && shift && mean && invstd && dh, "dc_bn_act_backward: null pointer");
+    DC_REQUIRE(R >= 1 && C >= 1 && lddy >= C && ldh >= C && lddh >= C, "dc_bn_act_backward: bad size");
+    DC_WS_CHECK("dc_bn_act_backward", R, C)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, R, C);
+    const bool v4 = C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && lddh % 4 == 0 && al16(dy) && al16(h) && al16(dh);
+    if (v4)
+        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s);
+    else
+        run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s);
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)R, C, dgamma, dbeta, w.m1,
+                       w.m2);
+    if (v4)
+        hipLaunchKernelGGL(bn_act_bwd_kernel<4>, dim3(stream_grid(R * (C / 4))), dim3(256), 0, s, dy, (long)lddy, h,
+                           (long)ldh, (long)R, C / 4, scale, shift, mean, invstd, gamma, slope, training, w.m1, w.m2, dh,
+                           (long)lddh);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_kernel<1>, dim3(stream_grid(R * C)), dim3(256), 0, s, dy, (long)lddy, h, (long)ldh,
+                           (long)R, C, scale, shift, mean, invstd, gamma, slope, training, w.m1, w.m2, dh, (long)lddh);
+    DC_CHECK_LAUNCH("dc_bn_act_backward");
+    return DC_OK;
+}
+
+// ---- vector block -----------------------------------------------------------------------------
+// in: combine != 0 -> [2n, 2*co] = [P | Q] (Linear applied to v_cat with weights [W1^T | W2^T]);
+//     combine == 0 -> [2n, co] = y.   Statistics of |y| over the n points.
+DC_EXPORT int dc_vn_stats(const float* in, int64_t n, int32_t co, int64_t ld, int32_t combine, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          float* mean, float* invstd, float* scale, float* shift, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(in && mean && invstd && scale && shift, "dc_vn_stats: null pointer");
+    DC_REQUIRE(n >= 1 && co >= 1 && ld >= (combine ? 2 * co : co), "dc_vn_stats: bad size");
+    DC_WS_CHECK("dc_vn_stats", n, co)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, n, co);
+    if (co % 4 == 0 && ld % 4 == 0 && al16(in))
+        run_colreduce<4>(VnStatsF<4>{in, (long)ld, co, combine}, n, co, w, s);
+    else
+        run_colreduce<1>(VnStatsF<1>{in, (long)ld, co, combine}, n, co, w, s);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dc_cdiv(co, 256)), dim3(256), 0, s, w.sums, (long)n, co, gamma, beta, eps,
+                       momentum, running_mean, running_var, mean, invstd, scale, shift);
+    DC_CHECK_LAUNCH("dc_vn_stats");
+    return DC_OK;
+}
+
+// out[2n, co] = y * relu(scale*|y| + shift) / max(|y|, 1e-8)      (nn/nonlin.py:63-82)
+DC_EXPORT int dc_vn_apply(const float* in, int64_t n, int32_t co, int64_t ld, int32_t combine, const float* scale,
+                          const float* shift, float* out, int64_t ldo, void* stream) {
+    DC_REQUIRE(in && scale && shift && out, "dc_vn_apply: null pointer");
+    DC_REQUIRE(n >= 0 && co >= 1 && ld >= (combine ? 2 * co : co) && ldo >= co, "dc_vn_apply: bad size");
+    if (n == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (co % 4 == 0 && ld % 4 == 0 && ldo % 4 == 0 && al16(in) && al16(out))
+        hipLaunchKernelGGL(vn_apply_kernel<4>, dim3(stream_grid(n * (co / 4))), dim3(256), 0, s, in, (long)n, co / 4,
+                           (long)ld, combine, scale, shift, out, (long)ldo);
+    else
+        hipLaunchKernelGGL(vn_apply_kernel<1>, dim3(stream_grid(n * co)), dim3(256), 0, s, in, (long)n, co, (long)ld,
+                           combine, scale, shift, out, (long)ldo);
+    DC_CHECK_LAUNCH("dc_vn_apply");
+    return DC_OK;
+}
+
+// Backward of dc_vn_apply (+ its statistics when training != 0): din has the shape of `in`.
+DC_EXPORT int dc_vn_backward(const float* dout, int64_t lddo, const float* in, int64_t ld, int32_t combine, int64_t n,
+                             int32_t co, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, const float* gamma, int32_t training, float* din, int64_t lddi,
+                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(dout && in && scale && shift && mean && invstd && din, "dc_vn_backward: null pointer");
+    DC_REQUIRE(n >= 1 && co >= 1 && lddo >= co && ld >= (combine ? 2 * co : co) && lddi >= (combine ? 2 * co : co),
+               "dc_vn_backward: bad size");
+    DC_WS_CHECK("dc_vn_backward", n, co)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, n, co);
+    const bool v4 = co % 4 == 0 && ld % 4 == 0 && lddo % 4 == 0 && lddi % 4 == 0 && al16(in) && al16(dout) && al16(din);
+    if (v4)
+        run_colreduce<4>(VnBwdF<4>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s);
+    else
+        run_colreduce<1>(VnBwdF<1>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s);
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(dc_cdiv(co, 256)), dim3(256), 0, s, w.sums, (long)n, co, dgamma, dbeta,
+                       w.m1, w.m2);
+    if (v4)
+        hipLaunchKernelGGL(vn_bwd_kernel<4>, dim3(stream_grid(n * (co / 4))), dim3(256), 0, s, in, (long)ld, combine, dout,
+                           (long)lddo, (long)n, co / 4, scale, shift, mean, invstd, gamma, training, w.m1, w.m2, din,
+                           (long)lddi);
+    else
+        hipLaunchKernelGGL(vn_bwd_kernel<1>, dim3(stream_grid(n * co)), dim3(256), 0, s, in, (long)ld, combine, dout,
+                           (long)lddo, (long)n, co, scale, shift, mean, invstd, gamma, training, w.m1, w.m2, din,
+                           (long)lddi);
+    DC_CHECK_LAUNCH("dc_vn_backward");
+    return DC_OK;
+}

@@ -6,10 +6,9 @@ What differs underneath: the kNN max-aggregation never materialises the [E,C] ga
 instead of recomputing two applies (operators.py:40,43 vs deltaconv.py:57)."""
 import torch
 
-from .mlp import MLP, VectorMLP
+from .mlp import MLP, VectorMLP, run_mlp
 from .. import _ops
 from ..geometry.graph import as_graph
-from ..geometry.operators import I_J
 
 
 class DeltaConv(torch.nn.Module):
@@ -39,12 +38,14 @@ class DeltaConv(torch.nn.Module):
 
         # [x, div v, curl v, |v|] -> MLP (deltaconv.py:57-59)
         dcn = _ops.div_curl_norm(v, div)
-        x = x_max + self.s_mlp(torch.cat([x, dcn], dim=1))
+        x = run_mlp(self.s_mlp, torch.cat([x, dcn], dim=1), residual=x_max)
 
         # vector stream (deltaconv.py:64-68)
         if self.v_mlp is not None:
             v_cat = torch.cat([v, _ops.hodge_from_dcn(dcn, grad, ci), grad @ x], dim=1)
-            v = self.v_mlp(I_J(v_cat))
+            v = self.v_mlp[0].forward_vcat(v_cat)       # = v_mlp(I_J(v_cat)) without materialising I_J
+            for blk in list(self.v_mlp)[1:]:
+                v = blk(v)
         return x, v
 
     def __repr__(self):

@@ -1,0 +1,140 @@
+"""Fused blocks of the scalar / vector MLP stream: library GEMM + hand-written HIP BatchNorm /
+activation / vector non-linearity kernels (deltaconv_amd/csrc/nn.hip), each with its own backward.
+
+Reference semantics: deltaconv/nn/mlp.py:7-17 and nn/nonlin.py:11-86 (Linear(no bias) ->
+BatchNorm1d over rows -> LeakyReLU(0.2);  Linear(no bias) -> VectorNonLin(BatchNorm1d))."""
+import torch
+import torch.nn.functional as F
+
+from .._lib import lib, require_gpu
+
+
+def _c(t):
+    return t if (t is None or (t.dtype == torch.float32 and t.is_contiguous())) else t.contiguous().float()
+
+
+def _ws(rows, c, device):
+    nbytes = lib.raw("dc_bn_workspace_bytes")(rows, c)
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device), nbytes
+
+
+def slope_of(act):
+    """negative slope of a piecewise-linear activation module, or None if it is something else."""
+    if isinstance(act, torch.nn.LeakyReLU):
+        return float(act.negative_slope)
+    if isinstance(act, torch.nn.ReLU):
+        return 0.0
+    if isinstance(act, torch.nn.Identity):
+        return 1.0
+    return None
+
+
+class _BNAct(torch.autograd.Function):
+    """y = leaky_slope(batch_norm(h)) (+ residual) on an [R,C] matrix."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, rm, rv, use_batch_stats, momentum, eps, slope, residual):
+        h = _c(h)
+        r, c = h.shape
+        dev = h.device
+        coef = torch.empty(4, c, dtype=torch.float32, device=dev)     # mean, invstd, scale, shift
+        if use_batch_stats:
+            ws, nb = _ws(r, c, dev)
+            lib.call("dc_bn_stats", h, r, c, c, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1], coef[2],
+                     coef[3], ws, nb)
+        else:
+            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, c, coef[0], coef[1], coef[2], coef[3])
+        y = torch.empty_like(h)
+        res = _c(residual)
+        lib.call("dc_bn_act", h, r, c, c, coef[2], coef[3], slope, res, c, y, c)
+        ctx.save_for_backward(h, coef, gamma)
+        ctx.cfg = (use_batch_stats, slope, gamma is not None, beta is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, coef, gamma = ctx.saved_tensors
+        training, slope, has_g, has_b, has_res = ctx.cfg
+        dy = _c(dy)
+        r, c = h.shape
+        dh = torch.empty_like(h)
+        dgamma = torch.empty(c, dtype=torch.float32, device=h.device) if has_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=h.device) if has_b else None
+        ws, nb = _ws(r, c, h.device)
+        lib.call("dc_bn_act_backward", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
+                 int(training), dh, c, dgamma, dbeta, ws, nb)
+        return dh, dgamma, dbeta, None, None, None, None, None, None, (dy if has_res else None)
+
+
+def bn_act(h, bn, slope, residual=None):
+    """bn: torch.nn.BatchNorm1d holding the parameters / running statistics."""
+    require_gpu()
+    use_batch = bn.training or bn.running_mean is None
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    rm, rv = (bn.running_mean, bn.running_var) if (bn.training and bn.track_running_stats) or not use_batch else (None, None)
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            mom = 1.0 / float(bn.num_batches_tracked)
+    return _BNAct.apply(h, bn.weight, bn.bias, rm, rv, use_batch, mom, float(bn.eps), float(slope), residual)
+
+
+class _VectorNonLin(torch.autograd.Function):
+    """out = y * relu(scale*|y| + shift) / max(|y|, 1e-8); `inp` = y [2n,co] or [P|Q] [2n,2co]."""
+
+    @staticmethod
+    def forward(ctx, inp, combine, gamma, beta, rm, rv, mode, momentum, eps):
+        # mode: 2 = batch statistics, 1 = running statistics, 0 = no batch norm (shift = beta = bias)
+        inp = _c(inp)
+        ld = inp.shape[1]
+        co = ld // 2 if combine else ld
+        n = inp.shape[0] // 2
+        dev = inp.device
+        coef = torch.empty(4, co, dtype=torch.float32, device=dev)
+        if mode == 2:
+            ws, nb = _ws(n, co, dev)
+            lib.call("dc_vn_stats", inp, n, co, ld, int(combine), gamma, beta, eps, momentum, rm, rv, coef[0],
+                     coef[1], coef[2], coef[3], ws, nb)
+        elif mode == 1:
+            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, co, coef[0], coef[1], coef[2], coef[3])
+        else:
+            coef[0].zero_(); coef[1].fill_(1.0); coef[2].fill_(1.0); coef[3].copy_(beta)
+        out = torch.empty(2 * n, co, dtype=torch.float32, device=dev)
+        lib.call("dc_vn_apply", inp, n, co, ld, int(combine), coef[2], coef[3], out, co)
+        ctx.save_for_backward(inp, coef, gamma)
+        ctx.cfg = (int(combine), mode, gamma is not None, beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        inp, coef, gamma = ctx.saved_tensors
+        combine, mode, has_g, has_b = ctx.cfg
+        dout = _c(dout)
+        ld = inp.shape[1]
+        co = ld // 2 if combine else ld
+        n = inp.shape[0] // 2
+        dev = inp.device
+        din = torch.empty_like(inp)
+        dgamma = torch.empty(co, dtype=torch.float32, device=dev) if has_g else None
+        dbeta = torch.empty(co, dtype=torch.float32, device=dev) if has_b else None
+        ws, nb = _ws(n, co, dev)
+        lib.call("dc_vn_backward", dout, co, inp, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1],
+                 gamma if mode else None, int(mode == 2), din, ld, dgamma, dbeta, ws, nb)
+        return din, None, dgamma, dbeta, None, None, None, None, None
+
+
+def vector_nonlin(inp, combine, vn):
+    """vn: VectorNonLin module (bias, optional batchnorm wrapper with .bn)."""
+    require_gpu()
+    if vn.batchnorm is None:
+        return _VectorNonLin.apply(inp, combine, None, vn.bias, None, None, 0, 0.0, 0.0)
+    bn = vn.batchnorm.bn
+    use_batch = bn.training or bn.running_mean is None
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    track = bn.training and bn.track_running_stats
+    if track:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            mom = 1.0 / float(bn.num_batches_tracked)
+    rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
+    return _VectorNonLin.apply(inp, combine, bn.weight, bn.bias, rm, rv, 2 if use_batch else 1, mom, float(bn.eps))

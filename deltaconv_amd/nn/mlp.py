@@ -1,23 +1,72 @@
-"""Scalar / vector MLP builders (reference: deltaconv/nn/mlp.py:7-46)."""
+"""Scalar / vector MLP builders (reference: deltaconv/nn/mlp.py:7-46).  Same Sequential nesting
+(hence the same state_dict keys: ``0.0.weight``, ``0.1.bn.weight`` ...); each inner block runs as
+library GEMM + one fused HIP BatchNorm/activation kernel instead of three ATen ops."""
 import torch
+import torch.nn.functional as F
 from torch.nn import Sequential as Seq, Linear as Lin, LeakyReLU
 
 from .nonlin import BatchNorm1d, VectorNonLin
+from . import fused
+
+
+class MLPBlock(Seq):
+    """[Linear -> BatchNorm1d -> nonlin]; forward(x, residual=None) = nonlin(bn(lin(x))) + residual."""
+
+    def forward(self, x, residual=None):
+        lin, bn, act = self[0], self[1], self[2]
+        slope = fused.slope_of(act)
+        h = F.linear(x, lin.weight, lin.bias)
+        if slope is None:                       # exotic activation: BN fused, activation through torch
+            out = act(fused.bn_act(h, bn.bn, 1.0))
+            return out if residual is None else out + residual
+        return fused.bn_act(h, bn.bn, slope, residual)
+
+
+class VectorBlock(Seq):
+    """[Linear(no bias) -> VectorNonLin]."""
+
+    def forward(self, v):
+        return self[1](F.linear(v, self[0].weight))
+
+    def forward_vcat(self, v_cat):
+        """Same as forward(I_J(v_cat)) without materialising I_J: with W = [W1 | W2],
+        W I_J(a) = (W1 a_u - W2 a_v, W1 a_v + W2 a_u); one GEMM a [W1^T | W2^T] -> [P | Q] and the
+        combination happens inside the fused non-linearity kernel."""
+        w = self[0].weight
+        k = v_cat.shape[1]
+        assert w.shape[1] == 2 * k, "first vector block expects I_J(v_cat) (2x the channels of v_cat)"
+        if not isinstance(self[1].nonlin, torch.nn.ReLU):
+            from ..geometry.operators import I_J
+            return self.forward(I_J(v_cat))
+        pq = F.linear(v_cat, torch.cat([w[:, :k], w[:, k:]], dim=0))     # [2N, 2*co]
+        return self[1](pq, combine=True)
 
 
 def MLP(channels, bias=False, nonlin=LeakyReLU(negative_slope=0.2)):
     """mlp.py:7-11: [Linear(no bias) -> BatchNorm over rows -> LeakyReLU(0.2)]*"""
     return Seq(*[
-        Seq(Lin(channels[i - 1], channels[i], bias=bias), BatchNorm1d(channels[i]), nonlin)
+        MLPBlock(Lin(channels[i - 1], channels[i], bias=bias), BatchNorm1d(channels[i]), nonlin)
         for i in range(1, len(channels))])
 
 
 def VectorMLP(channels, batchnorm=True):
     """mlp.py:13-17: [Linear(no bias) -> VectorNonLin(BN)]*"""
     return Seq(*[
-        Seq(Lin(channels[i - 1], channels[i], bias=False),
-            VectorNonLin(channels[i], batchnorm=BatchNorm1d(channels[i]) if batchnorm else None))
+        VectorBlock(Lin(channels[i - 1], channels[i], bias=False),
+                    VectorNonLin(channels[i], batchnorm=BatchNorm1d(channels[i]) if batchnorm else None))
         for i in range(1, len(channels))])
+
+
+def run_mlp(mlp, x, residual=None):
+    """Apply an MLP Sequential, adding ``residual`` inside the last block's fused kernel."""
+    blocks = list(mlp)
+    for blk in blocks[:-1]:
+        x = blk(x)
+    last = blocks[-1]
+    if isinstance(last, MLPBlock):
+        return last(x, residual)
+    out = last(x)
+    return out if residual is None else out + residual
 
 
 class ScalarVectorMLP(torch.nn.Module):

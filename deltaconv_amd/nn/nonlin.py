@@ -1,8 +1,10 @@
 """BatchNorm over rows and the vector non-linearity.  Module tree / parameter names mirror the
-reference (deltaconv/nn/nonlin.py:11-86) so its state_dicts load unchanged."""
+reference (deltaconv/nn/nonlin.py:11-86) so its state_dicts load unchanged; the arithmetic runs in
+the fused HIP kernels of deltaconv_amd/csrc/nn.hip (see fused.py)."""
 import torch
 from torch import Tensor
-import torch.nn.functional as F
+
+from . import fused
 
 EPS = 1e-8  # nonlin.py:8
 
@@ -20,7 +22,7 @@ class BatchNorm1d(torch.nn.Module):
         self.bn.reset_parameters()
 
     def forward(self, x: Tensor) -> Tensor:
-        return self.bn(x)
+        return fused.bn_act(x, self.bn, 1.0)
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.bn.num_features})'
@@ -42,13 +44,17 @@ class VectorNonLin(torch.nn.Module):
         if self.batchnorm is not None:
             self.batchnorm.reset_parameters()
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, combine: bool = False) -> Tensor:
+        """x: [2N,C]; with combine=True x is [2N,2C] = [P | Q] (see fused.py / mlp.VectorBlock)."""
+        if isinstance(self.nonlin, torch.nn.ReLU):
+            return fused.vector_nonlin(x, combine, self)
+        # any other non-linearity: same formula through torch ops on the GPU
+        assert not combine
         n, c = x.shape
         w = x.view(-1, 2, c)
         mag = w.norm(dim=1)
         shifted = mag + self.bias.view(1, -1) if self.batchnorm is None else self.batchnorm(mag)
-        scale = self.nonlin(shifted) / mag.clamp(EPS)
-        return (w * scale.unsqueeze(1)).reshape(n, c)
+        return (w * (self.nonlin(shifted) / mag.clamp(EPS)).unsqueeze(1)).reshape(n, c)
 
     def __repr__(self):
         return f'{self.__class__.__name__}(batchnorm={self.batchnorm.__repr__()})'

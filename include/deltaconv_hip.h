@@ -105,6 +105,42 @@ int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int32_t n, in
                         const float* dout, int32_t C, int64_t ldo, float* dh, int64_t ldh, int32_t accumulate,
                         void* stream);
 
+/* ---- scalar / vector MLP stream around the dense GEMM -------------------------------------------
+ * Linear -> BatchNorm1d(over rows) -> LeakyReLU(0.2)   deltaconv/nn/mlp.py:7-11, nn/nonlin.py:11-35
+ * Linear -> VectorNonLin(BatchNorm1d)                  deltaconv/nn/mlp.py:13-17, nn/nonlin.py:38-86
+ * (ATen native_batch_norm / leaky_relu / linalg_vector_norm / mul / div in the reference).
+ * Column reductions are ordered two-stage sums (bit-reproducible).  Workspace: dc_bn_workspace_bytes. */
+size_t dc_bn_workspace_bytes(int64_t rows, int32_t C);
+/* batch statistics of h[R,C] -> mean, invstd, scale = gamma*invstd, shift = beta - mean*scale;
+ * running_mean/var (may be NULL) updated with momentum (unbiased variance), as nn.BatchNorm1d */
+int dc_bn_stats(const float* h, int64_t R, int32_t C, int64_t ldh, const float* gamma, const float* beta, float eps,
+                float momentum, float* running_mean, float* running_var, float* mean, float* invstd, float* scale,
+                float* shift, void* workspace, size_t workspace_bytes, void* stream);
+/* inference coefficients from the running statistics */
+int dc_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float eps, int32_t C, float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* y = leaky_slope(scale*h + shift) (+ residual);  slope 1 = identity, 0 = ReLU */
+int dc_bn_act(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift, float slope,
+              const float* residual, int64_t ldr, float* y, int64_t ldy, void* stream);
+/* backward of dc_bn_act (through the batch statistics when training != 0); dgamma/dbeta may be NULL */
+int dc_bn_act_backward(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                       const float* gamma, float slope, int32_t training, float* dh, int64_t lddh, float* dgamma,
+                       float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+/* vector block.  in: combine != 0 -> [2n, 2co] = [P | Q], the Linear applied to v_cat (NOT to
+ * I_J(v_cat)) with the weight halves stacked, y_u = P_u - Q_v, y_v = P_v + Q_u
+ * (deltaconv/geometry/operators.py:9-21 folded into the epilogue); combine == 0 -> [2n, co] = y. */
+int dc_vn_stats(const float* in, int64_t n, int32_t co, int64_t ld, int32_t combine, const float* gamma,
+                const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                float* invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream);
+/* out[2n,co] = y * relu(scale*|y| + shift) / max(|y|, 1e-8) */
+int dc_vn_apply(const float* in, int64_t n, int32_t co, int64_t ld, int32_t combine, const float* scale,
+                const float* shift, float* out, int64_t ldo, void* stream);
+int dc_vn_backward(const float* dout, int64_t lddo, const float* in, int64_t ld, int32_t combine, int64_t n,
+                   int32_t co, const float* scale, const float* shift, const float* mean, const float* invstd,
+                   const float* gamma, int32_t training, float* din, int64_t lddi, float* dgamma, float* dbeta,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

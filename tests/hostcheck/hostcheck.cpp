@@ -8,6 +8,7 @@
 #include <vector>
 #include "../../deltaconv_amd/csrc/point_math.h"
 #include "../../deltaconv_amd/csrc/ell_math.h"
+#include "../../deltaconv_amd/csrc/nn_math.h"
 
 extern "C" {
 
@@ -115,5 +116,95 @@ void hc_knn_max_bwd(int V, const int* tptr, const int* tedge, int n, int k, cons
     using namespace dcell;
     if (V == 4) HC_LOOP(4, knn_max_bwd<4>(t, groups, tptr, tedge, k, arg, C, dout, ldo, dh, ldh, acc));
     else HC_LOOP(1, knn_max_bwd<1>(t, groups, tptr, tedge, k, arg, C, dout, ldo, dh, ldh, acc));
+}
+
+// ---- fused BN / activation / vector non-linearity: serial loops over the formulas of nn_math.h ----
+static void hc_coeffs(const std::vector<double>& s1, const std::vector<double>& s2, long R, int C, const float* gamma,
+                      const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift) {
+    for (int c = 0; c < C; ++c) {
+        const double m = s1[c] / R;
+        double var = s2[c] / R - m * m;
+        if (var < 0) var = 0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        mean[c] = (float)m; invstd[c] = (float)is;
+        scale[c] = (float)(gamma[c] * is); shift[c] = (float)(beta[c] - m * gamma[c] * is);
+    }
+}
+
+// y = leaky(bn(h)) + residual ; then backward for a given dy
+void hc_bn_act(const float* h, long R, int C, const float* gamma, const float* beta, float eps, float slope,
+               const float* residual, int training, const float* run_mean, const float* run_var, float* y,
+               const float* dy, float* dh, float* dgamma, float* dbeta) {
+    using namespace dcnn;
+    std::vector<float> mean(C), invstd(C), scale(C), shift(C);
+    if (training) {
+        std::vector<double> s1(C, 0.0), s2(C, 0.0);
+        for (long r = 0; r < R; ++r)
+            for (int c = 0; c < C; ++c) { s1[c] += h[r * C + c]; s2[c] += (double)h[r * C + c] * h[r * C + c]; }
+        hc_coeffs(s1, s2, R, C, gamma, beta, eps, mean.data(), invstd.data(), scale.data(), shift.data());
+    } else {
+        for (int c = 0; c < C; ++c) {
+            invstd[c] = 1.f / sqrtf(run_var[c] + eps); mean[c] = run_mean[c];
+            scale[c] = gamma[c] * invstd[c]; shift[c] = beta[c] - run_mean[c] * scale[c];
+        }
+    }
+    for (long r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c)
+            y[r * C + c] = act(fmaf(scale[c], h[r * C + c], shift[c]), slope) + (residual ? residual[r * C + c] : 0.f);
+    std::vector<double> a(C, 0.0), b(C, 0.0);
+    for (long r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c) {
+            float dz, dzx;
+            bn_bwd_terms(dy[r * C + c], h[r * C + c], scale[c], shift[c], mean[c], invstd[c], slope, dz, dzx);
+            a[c] += dz; b[c] += dzx;
+        }
+    for (int c = 0; c < C; ++c) { dbeta[c] = (float)a[c]; dgamma[c] = (float)b[c]; }
+    for (long r = 0; r < R; ++r)
+        for (int c = 0; c < C; ++c)
+            dh[r * C + c] = bn_bwd_dh(dy[r * C + c], h[r * C + c], scale[c], shift[c], mean[c], invstd[c], slope,
+                                      gamma[c] * invstd[c], (float)(a[c] / R), (float)(b[c] / R), training);
+}
+
+// vector block: in = [P|Q] (combine) or y; out; backward din for given dout
+void hc_vn(const float* in, long n, int co, int combine, const float* gamma, const float* beta, float eps,
+           int training, float* out, const float* dout, float* din, float* dgamma, float* dbeta) {
+    using namespace dcnn;
+    const long ld = combine ? 2 * co : co;
+    std::vector<float> mean(co), invstd(co), scale(co), shift(co);
+    auto load = [&](long i, int c, float& yu, float& yv) {
+        const float pu = in[(2 * i) * ld + c], pv = in[(2 * i + 1) * ld + c];
+        if (combine) vn_combine(pu, in[(2 * i) * ld + co + c], pv, in[(2 * i + 1) * ld + co + c], yu, yv);
+        else { yu = pu; yv = pv; }
+    };
+    if (training) {
+        std::vector<double> s1(co, 0.0), s2(co, 0.0);
+        for (long i = 0; i < n; ++i)
+            for (int c = 0; c < co; ++c) { float yu, yv; load(i, c, yu, yv); const float nn = vn_norm(yu, yv); s1[c] += nn; s2[c] += (double)nn * nn; }
+        hc_coeffs(s1, s2, n, co, gamma, beta, eps, mean.data(), invstd.data(), scale.data(), shift.data());
+    } else {  // bias mode: scale = 1, shift = beta (VectorNonLin without batchnorm)
+        for (int c = 0; c < co; ++c) { mean[c] = 0.f; invstd[c] = 1.f; scale[c] = 1.f; shift[c] = beta[c]; }
+    }
+    for (long i = 0; i < n; ++i)
+        for (int c = 0; c < co; ++c) {
+            float yu, yv; load(i, c, yu, yv);
+            const float s = vn_scale(vn_norm(yu, yv), scale[c], shift[c]);
+            out[(2 * i) * co + c] = yu * s; out[(2 * i + 1) * co + c] = yv * s;
+        }
+    std::vector<double> a(co, 0.0), b(co, 0.0);
+    for (long i = 0; i < n; ++i)
+        for (int c = 0; c < co; ++c) {
+            float yu, yv, dz, dzn; load(i, c, yu, yv);
+            vn_bwd_terms(yu, yv, dout[(2 * i) * co + c], dout[(2 * i + 1) * co + c], scale[c], shift[c], mean[c], invstd[c], dz, dzn);
+            a[c] += dz; b[c] += dzn;
+        }
+    for (int c = 0; c < co; ++c) { dbeta[c] = (float)a[c]; dgamma[c] = (float)b[c]; }
+    for (long i = 0; i < n; ++i)
+        for (int c = 0; c < co; ++c) {
+            float yu, yv, gu, gv; load(i, c, yu, yv);
+            vn_bwd_dy(yu, yv, dout[(2 * i) * co + c], dout[(2 * i + 1) * co + c], scale[c], shift[c], mean[c], invstd[c],
+                      (training ? gamma[c] : 1.f) * invstd[c], (float)(a[c] / n), (float)(b[c] / n), training, gu, gv);
+            din[(2 * i) * ld + c] = gu; din[(2 * i + 1) * ld + c] = gv;
+            if (combine) { din[(2 * i) * ld + co + c] = gv; din[(2 * i + 1) * ld + co + c] = -gu; }
+        }
 }
 }

@@ -1,0 +1,107 @@
+"""CPU check of the fused BatchNorm/activation and vector non-linearity formulas
+(deltaconv_amd/csrc/nn_math.h via tests/hostcheck) against torch autograd on the reference's own
+module definitions restated in oracle/nn.py."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle import geometry as geo
+from tests.helpers import rel_err, ROOT
+
+HC_DIR = os.path.join(ROOT, "tests", "hostcheck")
+
+
+@pytest.fixture(scope="module")
+def hc():
+    subprocess.run(["make", "-s", "-C", HC_DIR], check=True)
+    lib = ctypes.CDLL(os.path.join(HC_DIR, "libhostcheck.so"))
+    vp, ci, cl, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+    lib.hc_bn_act.argtypes = [vp, cl, ci, vp, vp, cf, cf, vp, ci, vp, vp, vp, vp, vp, vp, vp]
+    lib.hc_vn.argtypes = [vp, cl, ci, ci, vp, vp, cf, ci, vp, vp, vp, vp, vp]
+    return lib
+
+
+def P(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+@pytest.mark.parametrize("slope,training,use_res", [(0.2, 1, False), (0.2, 1, True), (1.0, 1, False), (0.2, 0, False)])
+def test_bn_act(hc, slope, training, use_res):
+    torch.manual_seed(0)
+    R, C = 500, 12
+    h = (torch.randn(R, C) * 2 + 0.5).requires_grad_(True)
+    gamma = (torch.rand(C) + 0.5).requires_grad_(True)
+    gamma.data[3] = -0.7
+    beta = (torch.randn(C) * 0.3).requires_grad_(True)
+    res = torch.randn(R, C) if use_res else None
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    z = F.batch_norm(h, rm.clone(), rv.clone(), gamma, beta, training=bool(training), momentum=0.1, eps=1e-5)
+    y_ref = F.leaky_relu(z, slope) if slope != 1.0 else z
+    if use_res:
+        y_ref = y_ref + res
+    dy = torch.randn(R, C)
+    gh, gg, gb = torch.autograd.grad(y_ref, [h, gamma, beta], dy)
+    y, dh, dg, db = torch.zeros(R, C), torch.zeros(R, C), torch.zeros(C), torch.zeros(C)
+    hc.hc_bn_act(P(h.detach()), R, C, P(gamma.detach()), P(beta.detach()), 1e-5, slope, P(res), training, P(rm), P(rv),
+                 P(y), P(dy), P(dh), P(dg), P(db))
+    assert rel_err(y, y_ref) < 1e-5 and rel_err(dh, gh) < 1e-4 and rel_err(dg, gg) < 1e-4 and rel_err(db, gb) < 1e-4
+
+
+@pytest.mark.parametrize("combine,training", [(1, 1), (0, 1), (0, 0), (1, 0)])
+def test_vector_nonlin(hc, combine, training):
+    torch.manual_seed(1)
+    n, co, K = 300, 8, 10
+    if combine:
+        a = torch.randn(2 * n, K, requires_grad=True)                 # v_cat
+        W = torch.randn(co, 2 * K) * 0.3                              # Linear on I_J(v_cat)
+        y_ref_in = F.linear(geo.I_J(a), W)
+        pq = F.linear(a, torch.cat([W[:, :K], W[:, K:]], 0)).detach() # [2n, 2co] = [P | Q]
+        inp = pq.contiguous()
+    else:
+        a = torch.randn(2 * n, co, requires_grad=True)
+        y_ref_in = a
+        inp = a.detach().contiguous()
+    inp[:2] = 0                                                       # a zero vector: |y| = 0 path
+    if combine:
+        with torch.no_grad():
+            a[:2] = 0
+        y_ref_in = F.linear(geo.I_J(a), W)
+    else:
+        with torch.no_grad():
+            a[:2] = 0
+        y_ref_in = a
+    bn = oracle.nn.BatchNorm1d(co) if training else None
+    vn = oracle.nn.VectorNonLin(co, batchnorm=bn)
+    if training:
+        with torch.no_grad():
+            bn.bn.weight.copy_(torch.rand(co) + 0.5)
+            bn.bn.bias.copy_(torch.randn(co) * 0.3)
+        gamma, beta = bn.bn.weight, bn.bn.bias
+        vn.train()
+    else:
+        with torch.no_grad():
+            vn.bias.copy_(torch.randn(co) * 0.3)
+        gamma, beta = torch.ones(co), vn.bias
+    out_ref = vn(y_ref_in)
+    dout = torch.randn(2 * n, co)
+    params = [a] + ([bn.bn.weight, bn.bn.bias] if training else [vn.bias])
+    grads = torch.autograd.grad(out_ref, params, dout)
+    ld = 2 * co if combine else co
+    out, din, dg, db = torch.zeros(2 * n, co), torch.zeros(2 * n, ld), torch.zeros(co), torch.zeros(co)
+    hc.hc_vn(P(inp), n, co, combine, P(gamma.detach().contiguous()), P(beta.detach().contiguous()), 1e-5, training,
+             P(out), P(dout), P(din), P(dg), P(db))
+    assert rel_err(out, out_ref) < 1e-5
+    if combine:   # chain d[P|Q] back to v_cat through the stacked weights
+        da = din @ torch.cat([W[:, :K], W[:, K:]], 0)
+    else:
+        da = din
+    assert rel_err(da, grads[0]) < 1e-4
+    if training:
+        assert rel_err(dg, grads[1]) < 1e-4 and rel_err(db, grads[2]) < 1e-4
+    else:
+        assert rel_err(db, grads[1]) < 1e-4

@@ -99,6 +99,12 @@ def main():
             rec("torch linear [Nt,4C]x[4C,C]", t, 4 * (5 * C * n + 4 * C * C), TF=round(2 * n * 4 * C * C / t / 1e6, 1), **kw)
             bn = torch.nn.BatchNorm1d(C).to(dev).train()
             rec("torch batch_norm+leaky [Nt,C]", timeit(lambda: torch.nn.functional.leaky_relu(bn(x), 0.2)), 8 * C * n, **kw)
+            from deltaconv_amd.nn import fused
+            rec("fused bn_stats+act fwd [Nt,C]", timeit(lambda: fused.bn_act(x, bn, 0.2)), 12 * C * n, **kw)
+            xg = x.clone().requires_grad_(True)
+            yg = fused.bn_act(xg, bn, 0.2)
+            gy = torch.randn_like(yg)
+            rec("fused bn_act bwd [Nt,C]", timeit(lambda: torch.autograd.grad(yg, xg, gy, retain_graph=True)), 20 * C * n, **kw)
     lib.raw("dc_set_option")(0, 1)
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
