@@ -1,0 +1,151 @@
+// Ordered two-stage column reduction over row-major [R, C] data + BatchNorm finalisation kernels,
+// shared by nn.hip (MLP stream) and edge.hip (layer-0 edge MLP).  Bit-reproducible: per-block
+// partials in fp64, then one wave per (quantity, column) with a fixed butterfly.
+#pragma once
+#include "common.h"
+#include <algorithm>
+
+namespace dccol {
+namespace {   // internal linkage: this header is included by several translation units
+
+constexpr int RT = 16;          // row lanes per block
+constexpr int CT = 16;          // column groups per block
+constexpr int ROWS_PER_CHUNK = 256;
+constexpr int TPB = RT * CT;    // 256
+
+template <int V>
+struct alignas(4 * V) FV {
+    float v[V];
+};
+template <int V>
+__device__ __forceinline__ FV<V> ldv(const float* p) { return *reinterpret_cast<const FV<V>*>(p); }
+template <int V>
+__device__ __forceinline__ void stv(float* p, const FV<V>& a) { *reinterpret_cast<FV<V>*>(p) = a; }
+
+// ---- generic ordered column reduction: NQ quantities per element ------------------------------
+// grid = (row_chunks, col_tiles); partial[(chunk*NQ + q)*C + col] (double)
+template <int V, int NQ, class F>
+__global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int chunks, double* __restrict__ partial) {
+    __shared__ double sm[NQ][RT][CT * V];
+    const int cgl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c0 = (blockIdx.y * CT + cgl) * V;
+    const long r0 = (long)blockIdx.x * ROWS_PER_CHUNK;
+    const long r1 = min(r0 + ROWS_PER_CHUNK, R);
+    double acc[NQ][V];   // fp64: sum x^2 - (sum x)^2 / R must survive cancellation (R can be 2)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[q][j] = 0.0;
+    if (c0 < C) {
+        for (long r = r0 + rl; r < r1; r += RT) {
+            double t[NQ][V];
+            f(r, c0, t);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[q][j] += t[q][j];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int j = 0; j < V; ++j) sm[q][rl][cgl * V + j] = acc[q][j];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NQ * CT * V; idx += TPB) {
+        const int q = idx / (CT * V), cl = idx % (CT * V);
+        const int col = blockIdx.y * CT * V + cl;
+        if (col < C) {
+            double s = 0;
+#pragma unroll
+            for (int rr = 0; rr < RT; ++rr) s += sm[q][rr][cl];
+            partial[((long)q * C + col) * chunks + blockIdx.x] = s;   // [q][col][chunk]
+        }
+    }
+}
+
+// sums[q*C + col] = sum over chunks: one wave per (q, col), lanes stride the chunks, butterfly
+// reduce -> the association is fixed by the structure (bit-reproducible).
+__global__ __launch_bounds__(64) void colreduce_final_kernel(const double* __restrict__ partial, int chunks,
+                                                             double* __restrict__ sums) {
+    const double* p = partial + (long)blockIdx.x * chunks;
+    double s = 0;
+    for (int ch = threadIdx.x; ch < chunks; ch += 64) s += p[ch];
+    s = dc_wave_sum(s);
+    if (threadIdx.x == 0) sums[blockIdx.x] = s;
+}
+
+// ---- finalize: batch statistics -> scale/shift (+ running statistics) -------------------------
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, long R, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / (double)R;
+    double var = sums[C + c] / (double)R - m * m;  // biased (normalisation)
+    if (var < 0) var = 0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = (float)m;
+    invstd[c] = (float)is;
+    scale[c] = (float)(g * is);
+    shift[c] = (float)(b - m * g * is);
+    if (running_mean) {  // nn.BatchNorm1d: unbiased variance into the running estimate
+        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    mean[c] = rm[c];
+    invstd[c] = is;
+    scale[c] = g * is;
+    shift[c] = b - rm[c] * g * is;
+}
+
+// dgamma = sum dz*xhat, dbeta = sum dz; also the per-column means the apply pass needs
+__global__ void bwd_finalize_kernel(const double* __restrict__ sums, long R, int C, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, float* __restrict__ m1, float* __restrict__ m2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] = (float)sums[c];
+    if (dgamma) dgamma[c] = (float)sums[C + c];
+    m1[c] = (float)(sums[c] / (double)R);
+    m2[c] = (float)(sums[C + c] / (double)R);
+}
+
+// ---- host helpers --------------------------------------------------------------------------
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int chunks_of(long R) { return (int)((R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK); }
+inline size_t ws_need(long R, int C) { return ((size_t)chunks_of(R) * 2 * C + 2 * (size_t)C) * 8 + 2 * (size_t)C * 4; }
+inline int stream_grid(long total) { return (int)std::min<long>((total + 255) / 256, 256L * 16); }
+
+struct Ws {
+    double* partial; double* sums; float* m1; float* m2;
+};
+inline Ws carve(void* ws, long R, int C) {
+    Ws w;
+    w.partial = static_cast<double*>(ws);
+    w.sums = w.partial + (size_t)chunks_of(R) * 2 * C;
+    w.m1 = reinterpret_cast<float*>(w.sums + 2 * (size_t)C);
+    w.m2 = w.m1 + C;
+    return w;
+}
+
+template <int V, class F>
+void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s) {
+    dim3 grid(chunks_of(R), dc_cdiv(C, CT * V));
+    hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, chunks_of(R), w.partial);
+    hipLaunchKernelGGL(colreduce_final_kernel, dim3(2 * C), dim3(64), 0, s, w.partial, chunks_of(R), w.sums);
+}
+
+
+}  // namespace
+}  // namespace dccol

@@ -1,0 +1,167 @@
+// Layer-0 edge MLP + max aggregation without the [E,C] tensor (math and derivation: edge_math.h).
+// Replaces, for a depth-1 `s_mlp_max` with centralized=True,
+//   scatter(s_mlp_max(x[col] - x[row]), row, reduce='max')   (/root/reference/deltaconv/nn/deltaconv.py:50-52)
+// i.e. index_select + addmm + native_batch_norm + leaky_relu + scatter_max over E = Nt*k rows.
+// HBM-bound gather passes: fwd 4C*Nt in + 13C*Nt out + 4E ids; bwd CSC pass ~9C*E gathered bytes.
+#include "common.h"
+#include "colreduce.h"
+#include "edge_math.h"
+
+namespace {
+using namespace dccol;
+using namespace dcedge;
+
+template <int V>
+struct EdgeStatsF {
+    const float* y; long ldy; const int* nbr; int k;
+    float *amax, *amin; unsigned char *argmax, *argmin; float* s1pt; long ldo, lda;
+    __device__ void operator()(long i, int c0, double (&t)[2][V]) const {
+        edge_gather<V>(i, c0, y, ldy, nbr, k, amax, amin, argmax, argmin, s1pt, ldo, lda, t);
+    }
+};
+
+template <int V>
+struct EdgeBwdF {   // writes dz* and returns (dz*, dz* ahat*)
+    const float *dout, *amax, *amin, *scale, *shift, *mean, *invstd; long lddo, ldo; float slope; float* dzs;
+    __device__ void operator()(long i, int c0, double (&t)[2][V]) const {
+        const FV<V> g = ldv<V>(dout + i * lddo + c0), mx = ldv<V>(amax + i * ldo + c0), mn = ldv<V>(amin + i * ldo + c0);
+        FV<V> dz;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float b;
+            edge_bwd_terms(g.v[q], mx.v[q], mn.v[q], scale[c0 + q], shift[c0 + q], mean[c0 + q], invstd[c0 + q], slope,
+                           dz.v[q], b);
+            t[0][q] = dz.v[q];
+            t[1][q] = b;
+        }
+        stv<V>(dzs + i * ldo + c0, dz);
+    }
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict__ amax, const float* __restrict__ amin,
+                                                         const unsigned char* __restrict__ argmax,
+                                                         const unsigned char* __restrict__ argmin, long n, int groups,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float slope,
+                                                         float* __restrict__ out, long ldo,
+                                                         unsigned char* __restrict__ arg) {
+    const long total = n * groups;
+    const int C = groups * V;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long i = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        const FV<V> mx = ldv<V>(amax + i * C + c0), mn = ldv<V>(amin + i * C + c0);
+        FV<V> o;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const int c = c0 + q;
+            o.v[q] = dcnn::act(fmaf(scale[c], pick(scale[c], mx.v[q], mn.v[q]), shift[c]), slope);
+            if (arg) arg[i * C + c] = scale[c] >= 0.f ? argmax[i * C + c] : argmin[i * C + c];
+        }
+        stv<V>(out + i * ldo + c0, o);
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(long total, int groups, int remap, const int* tptr,
+                                                       const int* tedge, int k, const float* y, long ldy,
+                                                       const float* dzs, const float* s1pt, long ldo,
+                                                       const unsigned char* argmax, const unsigned char* argmin,
+                                                       long lda, const float* scale, const float* mean,
+                                                       const float* invstd, const float* m1, const float* m2,
+                                                       int training, float* dy, long lddy) {
+    const long t = dc_xcd_block(remap) * 256 + threadIdx.x;
+    if (t >= total) return;
+    edge_bwd_point<V>(t, groups, tptr, tedge, k, y, ldy, dzs, s1pt, ldo, argmax, argmin, lda, scale, mean, invstd, m1, m2,
+                      training, dy, lddy);
+}
+}  // namespace
+
+// Gather pass over y[Nt,C] (= Linear(x), no bias): per point amax/amin of a_e = y_j - y_i with
+// first-extremal slots, s1pt = sum_s a_e; when compute_stats != 0 also the BatchNorm statistics over
+// all E edges -> mean, invstd, scale, shift (+ running statistics).  amax/amin/s1pt are [Nt,C]
+// contiguous, argmax/argmin uint8 [Nt,C].  Workspace: dc_bn_workspace_bytes(Nt, C).
+DC_EXPORT int dc_edge_gather_stats(const float* y, int64_t ldy, const int32_t* nbr, int32_t n, int32_t k, int32_t C,
+                                   int32_t compute_stats, const float* gamma, const float* beta, float eps,
+                                   float momentum, float* running_mean, float* running_var, float* amax, float* amin,
+                                   uint8_t* argmax, uint8_t* argmin, float* s1pt, float* mean, float* invstd,
+                                   float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(y && nbr && amax && amin && argmax && argmin && s1pt, "dc_edge_gather_stats: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && k <= 255 && C >= 1 && ldy >= C, "dc_edge_gather_stats: bad size");
+    DC_REQUIRE(!compute_stats || (mean && invstd && scale && shift), "dc_edge_gather_stats: null pointer");
+    if (!workspace || workspace_bytes < ws_need(n, C)) {
+        dc_set_error("dc_edge_gather_stats: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, n, C);
+    if (C % 4 == 0 && ldy % 4 == 0 && al16(y))
+        run_colreduce<4>(EdgeStatsF<4>{y, (long)ldy, nbr, k, amax, amin, argmax, argmin, s1pt, (long)C, (long)C}, n, C, w, s);
+    else
+        run_colreduce<1>(EdgeStatsF<1>{y, (long)ldy, nbr, k, amax, amin, argmax, argmin, s1pt, (long)C, (long)C}, n, C, w, s);
+    if (compute_stats)
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)n * k, C, gamma, beta,
+                           eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    DC_CHECK_LAUNCH("dc_edge_gather_stats");
+    return DC_OK;
+}
+
+// out[i,c] = leaky_slope(scale_c * (scale_c >= 0 ? amax : amin) + shift_c); arg (may be NULL) = slot
+DC_EXPORT int dc_edge_max_apply(const float* amax, const float* amin, const uint8_t* argmax, const uint8_t* argmin,
+                                int32_t n, int32_t C, const float* scale, const float* shift, float slope, float* out,
+                                int64_t ldo, uint8_t* arg, void* stream) {
+    DC_REQUIRE(amax && amin && argmax && argmin && scale && shift && out, "dc_edge_max_apply: null pointer");
+    DC_REQUIRE(n >= 0 && C >= 1 && ldo >= C && slope >= 0.f, "dc_edge_max_apply: bad size / negative slope");
+    if (n == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C % 4 == 0 && ldo % 4 == 0 && al16(out) && al16(amax) && al16(amin))
+        hipLaunchKernelGGL(edge_apply_kernel<4>, dim3(stream_grid((long)n * (C / 4))), dim3(256), 0, s, amax, amin, argmax,
+                           argmin, (long)n, C / 4, scale, shift, slope, out, (long)ldo, arg);
+    else
+        hipLaunchKernelGGL(edge_apply_kernel<1>, dim3(stream_grid((long)n * C)), dim3(256), 0, s, amax, amin, argmax,
+                           argmin, (long)n, C, scale, shift, slope, out, (long)ldo, arg);
+    DC_CHECK_LAUNCH("dc_edge_max_apply");
+    return DC_OK;
+}
+
+// Backward of the pair above: dy[Nt,C] (gradient w.r.t. y = Linear(x)), dgamma, dbeta.
+// dzs is an [Nt,C] scratch tensor.  Workspace: dc_bn_workspace_bytes(Nt, C).
+DC_EXPORT int dc_edge_max_backward(const float* dout, int64_t lddo, const float* y, int64_t ldy, const int32_t* tptr,
+                                   const int32_t* tedge, int32_t n, int32_t k, int32_t C, const float* amax,
+                                   const float* amin, const uint8_t* argmax, const uint8_t* argmin, const float* s1pt,
+                                   const float* scale, const float* shift, const float* mean, const float* invstd,
+                                   float slope, int32_t training, float* dzs, float* dy, int64_t lddy, float* dgamma,
+                                   float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(dout && y && tptr && tedge && amax && amin && argmax && argmin && s1pt && scale && shift && mean &&
+                   invstd && dzs && dy, "dc_edge_max_backward: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && k <= 255 && C >= 1 && lddo >= C && ldy >= C && lddy >= C, "dc_edge_max_backward: bad size");
+    if (!workspace || workspace_bytes < ws_need(n, C)) {
+        dc_set_error("dc_edge_max_backward: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, n, C);
+    const bool v4 = C % 4 == 0 && lddo % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && al16(dout) && al16(y) && al16(dy);
+    if (v4)
+        run_colreduce<4>(EdgeBwdF<4>{dout, amax, amin, scale, shift, mean, invstd, (long)lddo, (long)C, slope, dzs}, n, C, w, s);
+    else
+        run_colreduce<1>(EdgeBwdF<1>{dout, amax, amin, scale, shift, mean, invstd, (long)lddo, (long)C, slope, dzs}, n, C, w, s);
+    // m1, m2 are means over all E edges
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)n * k, C, dgamma, dbeta,
+                       w.m1, w.m2);
+    const int remap = dc_option(DC_OPT_XCD_REMAP);
+    if (v4) {
+        const long total = (long)n * (C / 4);
+        hipLaunchKernelGGL(edge_bwd_kernel<4>, dim3(dc_cdiv(total, 256)), dim3(256), 0, s, total, C / 4, remap, tptr, tedge, k,
+                           y, (long)ldy, dzs, s1pt, (long)C, argmax, argmin, (long)C, scale, mean, invstd, w.m1, w.m2,
+                           training, dy, (long)lddy);
+    } else {
+        const long total = (long)n * C;
+        hipLaunchKernelGGL(edge_bwd_kernel<1>, dim3(dc_cdiv(total, 256)), dim3(256), 0, s, total, C, remap, tptr, tedge, k, y,
+                           (long)ldy, dzs, s1pt, (long)C, argmax, argmin, (long)C, scale, mean, invstd, w.m1, w.m2,
+                           training, dy, (long)lddy);
+    }
+    DC_CHECK_LAUNCH("dc_edge_max_backward");
+    return DC_OK;
+}

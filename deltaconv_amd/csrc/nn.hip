@@ -12,97 +12,35 @@
 // sum): bit-reproducible, no fp atomics.  Element formulas: nn_math.h.
 #include "common.h"
 #include "nn_math.h"
-#include <algorithm>
+#include "colreduce.h"
 
 namespace {
 
 using namespace dcnn;
 
-constexpr int RT = 16;          // row lanes per block
-constexpr int CT = 16;          // column groups per block
-constexpr int ROWS_PER_CHUNK = 256;
-constexpr int TPB = RT * CT;    // 256
-
-template <int V>
-struct alignas(4 * V) FV {
-    float v[V];
-};
-template <int V>
-__device__ __forceinline__ FV<V> ldv(const float* p) { return *reinterpret_cast<const FV<V>*>(p); }
-template <int V>
-__device__ __forceinline__ void stv(float* p, const FV<V>& a) { *reinterpret_cast<FV<V>*>(p) = a; }
-
-// ---- generic ordered column reduction: NQ quantities per element ------------------------------
-// grid = (row_chunks, col_tiles); partial[(chunk*NQ + q)*C + col] (double)
-template <int V, int NQ, class F>
-__global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, double* __restrict__ partial) {
-    __shared__ float sm[NQ][RT][CT * V];
-    const int cgl = threadIdx.x % CT, rl = threadIdx.x / CT;
-    const int c0 = (blockIdx.y * CT + cgl) * V;
-    const long r0 = (long)blockIdx.x * ROWS_PER_CHUNK;
-    const long r1 = min(r0 + ROWS_PER_CHUNK, R);
-    float acc[NQ][V];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int j = 0; j < V; ++j) acc[q][j] = 0.f;
-    if (c0 < C) {
-        for (long r = r0 + rl; r < r1; r += RT) {
-            float t[NQ][V];
-            f(r, c0, t);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q)
-#pragma unroll
-                for (int j = 0; j < V; ++j) acc[q][j] += t[q][j];
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-#pragma unroll
-        for (int j = 0; j < V; ++j) sm[q][rl][cgl * V + j] = acc[q][j];
-    __syncthreads();
-    for (int idx = threadIdx.x; idx < NQ * CT * V; idx += TPB) {
-        const int q = idx / (CT * V), cl = idx % (CT * V);
-        const int col = blockIdx.y * CT * V + cl;
-        if (col < C) {
-            double s = 0;
-#pragma unroll
-            for (int rr = 0; rr < RT; ++rr) s += (double)sm[q][rr][cl];
-            partial[((long)blockIdx.x * NQ + q) * C + col] = s;
-        }
-    }
-}
-
-// sums[q*C + col] = sum over chunks (fixed order)
-__global__ void colreduce_final_kernel(const double* __restrict__ partial, int chunks, int nq, int C,
-                                       double* __restrict__ sums) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nq * C) return;
-    const int q = idx / C, col = idx % C;
-    double s = 0;
-    for (int ch = 0; ch < chunks; ++ch) s += partial[((long)ch * nq + q) * C + col];
-    sums[idx] = s;
-}
+using namespace dccol;
 
 // ---- functors ---------------------------------------------------------------------------------
 template <int V>
 struct StatsF {  // x, x^2
     const float* h; long ld;
-    __device__ void operator()(long r, int c0, float (&t)[2][V]) const {
+    __device__ void operator()(long r, int c0, double (&t)[2][V]) const {
         const FV<V> x = ldv<V>(h + r * ld + c0);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { t[0][j] = x.v[j]; t[1][j] = x.v[j] * x.v[j]; }
+        for (int j = 0; j < V; ++j) { t[0][j] = (double)x.v[j]; t[1][j] = (double)x.v[j] * (double)x.v[j]; }
     }
 };
 template <int V>
 struct BnBwdF {  // dz, dz*xhat
     const float *dy, *h, *scale, *shift, *mean, *invstd; long lddy, ldh; float slope;
-    __device__ void operator()(long r, int c0, float (&t)[2][V]) const {
+    __device__ void operator()(long r, int c0, double (&t)[2][V]) const {
         const FV<V> g = ldv<V>(dy + r * lddy + c0), x = ldv<V>(h + r * ldh + c0);
 #pragma unroll
-        for (int j = 0; j < V; ++j)
-            bn_bwd_terms(g.v[j], x.v[j], scale[c0 + j], shift[c0 + j], mean[c0 + j], invstd[c0 + j], slope, t[0][j],
-                         t[1][j]);
+        for (int j = 0; j < V; ++j) {
+            float a, b;
+            bn_bwd_terms(g.v[j], x.v[j], scale[c0 + j], shift[c0 + j], mean[c0 + j], invstd[c0 + j], slope, a, b);
+            t[0][j] = a; t[1][j] = b;
+        }
     }
 };
 // vector block: "row" = point i; input rows 2i, 2i+1 of pq (combine: [P | Q] with 2*co columns)
@@ -122,73 +60,29 @@ __device__ __forceinline__ void vn_load_y(const float* in, long ld, long i, int 
 template <int V>
 struct VnStatsF {  // n, n^2
     const float* in; long ld; int co, combine;
-    __device__ void operator()(long i, int c0, float (&t)[2][V]) const {
+    __device__ void operator()(long i, int c0, double (&t)[2][V]) const {
         FV<V> yu, yv;
         vn_load_y<V>(in, ld, i, c0, co, combine, yu, yv);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { const float n = vn_norm(yu.v[j], yv.v[j]); t[0][j] = n; t[1][j] = n * n; }
+        for (int j = 0; j < V; ++j) { const double n = vn_norm(yu.v[j], yv.v[j]); t[0][j] = n; t[1][j] = n * n; }
     }
 };
 template <int V>
 struct VnBwdF {  // dz, dz*nhat
     const float *in, *dout, *scale, *shift, *mean, *invstd; long ld, lddo; int co, combine;
-    __device__ void operator()(long i, int c0, float (&t)[2][V]) const {
+    __device__ void operator()(long i, int c0, double (&t)[2][V]) const {
         FV<V> yu, yv;
         vn_load_y<V>(in, ld, i, c0, co, combine, yu, yv);
         const FV<V> du = ldv<V>(dout + (2 * i) * lddo + c0), dv = ldv<V>(dout + (2 * i + 1) * lddo + c0);
 #pragma unroll
-        for (int j = 0; j < V; ++j)
+        for (int j = 0; j < V; ++j) {
+            float a, b;
             vn_bwd_terms(yu.v[j], yv.v[j], du.v[j], dv.v[j], scale[c0 + j], shift[c0 + j], mean[c0 + j],
-                         invstd[c0 + j], t[0][j], t[1][j]);
+                         invstd[c0 + j], a, b);
+            t[0][j] = a; t[1][j] = b;
+        }
     }
 };
-
-// ---- finalize: batch statistics -> scale/shift (+ running statistics) -------------------------
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, long R, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double m = sums[c] / (double)R;
-    double var = sums[C + c] / (double)R - m * m;  // biased (normalisation)
-    if (var < 0) var = 0;
-    const double is = 1.0 / sqrt(var + (double)eps);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    mean[c] = (float)m;
-    invstd[c] = (float)is;
-    scale[c] = (float)(g * is);
-    shift[c] = (float)(b - m * g * is);
-    if (running_mean) {  // nn.BatchNorm1d: unbiased variance into the running estimate
-        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-    }
-}
-
-__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
-                                      float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float is = 1.f / sqrtf(rv[c] + eps);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    mean[c] = rm[c];
-    invstd[c] = is;
-    scale[c] = g * is;
-    shift[c] = b - rm[c] * g * is;
-}
-
-// dgamma = sum dz*xhat, dbeta = sum dz; also the per-column means the apply pass needs
-__global__ void bwd_finalize_kernel(const double* __restrict__ sums, long R, int C, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, float* __restrict__ m1, float* __restrict__ m2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (dbeta) dbeta[c] = (float)sums[c];
-    if (dgamma) dgamma[c] = (float)sums[C + c];
-    m1[c] = (float)(sums[c] / (double)R);
-    m2[c] = (float)(sums[C + c] / (double)R);
-}
 
 // ---- streaming applies ---------------------------------------------------------------------
 template <int V>
@@ -297,32 +191,6 @@ __global__ __launch_bounds__(256) void vn_bwd_kernel(const float* __restrict__ i
             stv<V>(din + (2 * i + 1) * lddi + co + c0, ngu);
         }
     }
-}
-
-// ---- host helpers --------------------------------------------------------------------------
-inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-inline int chunks_of(long R) { return (int)((R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK); }
-inline size_t ws_need(long R, int C) { return ((size_t)chunks_of(R) * 2 * C + 2 * (size_t)C) * 8 + 2 * (size_t)C * 4; }
-inline int stream_grid(long total) { return (int)std::min<long>((total + 255) / 256, 256L * 16); }
-
-struct Ws {
-    double* partial; double* sums; float* m1; float* m2;
-};
-inline Ws carve(void* ws, long R, int C) {
-    Ws w;
-    w.partial = static_cast<double*>(ws);
-    w.sums = w.partial + (size_t)chunks_of(R) * 2 * C;
-    w.m1 = reinterpret_cast<float*>(w.sums + 2 * (size_t)C);
-    w.m2 = w.m1 + C;
-    return w;
-}
-
-template <int V, class F>
-void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s) {
-    dim3 grid(chunks_of(R), dc_cdiv(C, CT * V));
-    hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, w.partial);
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3(dc_cdiv(2 * C, 256)), dim3(256), 0, s, w.partial, chunks_of(R), 2, C,
-                       w.sums);
 }
 
 }  // namespace

@@ -5,8 +5,10 @@ What differs underneath: the kNN max-aggregation never materialises the [E,C] ga
 ``div v``, ``curl v`` and ``|v|`` come out of one gather pass, and the Hodge-Laplacian reuses them
 instead of recomputing two applies (operators.py:40,43 vs deltaconv.py:57)."""
 import torch
+import torch.nn.functional as F
 
-from .mlp import MLP, VectorMLP, run_mlp
+from .mlp import MLP, VectorMLP, MLPBlock, run_mlp
+from . import fused
 from .. import _ops
 from ..geometry.graph import as_graph
 
@@ -30,9 +32,7 @@ class DeltaConv(torch.nn.Module):
 
         # scalar stream: max aggregation over the k neighbours (deltaconv.py:50-54)
         if self.centralized:
-            nbr = graph.nbr.long()
-            x_edge = (x[nbr] - x.unsqueeze(1)).reshape(n * k, ci)
-            x_max = self.s_mlp_max(x_edge).view(n, k, -1).max(dim=1).values
+            x_max = self._centralized_max(x, graph)
         else:
             x_max = _ops.knn_max(self.s_mlp_max(x), graph)
 
@@ -47,6 +47,21 @@ class DeltaConv(torch.nn.Module):
             for blk in list(self.v_mlp)[1:]:
                 v = blk(v)
         return x, v
+
+    def _centralized_max(self, x, graph):
+        """max_s s_mlp_max(x_j - x_i)  (deltaconv.py:50-52).  Depth-1 MLP with a monotone piecewise-linear
+        activation: analytic form on y = Linear(x), no [E,C] tensor (csrc/edge_math.h).  Otherwise the
+        edge tensor is materialised and pushed through the fused blocks."""
+        blocks = list(self.s_mlp_max)
+        blk = blocks[0]
+        slope = fused.slope_of(blk[2]) if isinstance(blk, MLPBlock) else None
+        if len(blocks) == 1 and slope is not None and slope >= 0 and blk[0].bias is None:
+            y = F.linear(x, blk[0].weight)
+            return fused.edge_max_bn(y, graph, blk[1].bn, slope)
+        n, k = graph.n, graph.k
+        nbr = graph.nbr.long()
+        x_edge = (x[nbr] - x.unsqueeze(1)).reshape(n * k, x.shape[1])
+        return self.s_mlp_max(x_edge).view(n, k, -1).max(dim=1).values
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels})'

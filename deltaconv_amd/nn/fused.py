@@ -138,3 +138,61 @@ def vector_nonlin(inp, combine, vn):
             mom = 1.0 / float(bn.num_batches_tracked)
     rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
     return _VectorNonLin.apply(inp, combine, bn.weight, bn.bias, rm, rv, 2 if use_batch else 1, mom, float(bn.eps))
+
+
+class _EdgeMaxBN(torch.autograd.Function):
+    """x_max[i] = max_s leaky(bn(y_j - y_i)) over the k-list of i, BN statistics over all E edges,
+    without materialising any [E,C] tensor (csrc/edge_math.h)."""
+
+    @staticmethod
+    def forward(ctx, y, graph, gamma, beta, rm, rv, use_batch_stats, momentum, eps, slope):
+        y = _c(y)
+        n, c = y.shape
+        k, dev = graph.k, y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        stat = torch.empty(3, n, c, **f32)                   # amax, amin, s1pt
+        args = torch.empty(2, n, c, dtype=torch.uint8, device=dev)
+        coef = torch.empty(4, c, **f32)                      # mean, invstd, scale, shift
+        ws, nb = _ws(n, c, dev)
+        if not use_batch_stats:
+            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, c, coef[0], coef[1], coef[2], coef[3])
+        lib.call("dc_edge_gather_stats", y, c, graph.nbr, n, k, c, int(use_batch_stats), gamma, beta, eps, momentum,
+                 rm if use_batch_stats else None, rv if use_batch_stats else None, stat[0], stat[1], args[0], args[1],
+                 stat[2], coef[0], coef[1], coef[2], coef[3], ws, nb)
+        out = torch.empty(n, c, **f32)
+        lib.call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, c, coef[2], coef[3], slope, out, c, None)
+        ctx.save_for_backward(y, stat, args, coef)
+        ctx.graph, ctx.cfg = graph, (use_batch_stats, slope, gamma is not None, beta is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, stat, args, coef = ctx.saved_tensors
+        training, slope, has_g, has_b = ctx.cfg
+        g = ctx.graph
+        dout = _c(dout)
+        n, c = y.shape
+        dev = y.device
+        tptr, tedge = g.csc()
+        dzs = torch.empty(n, c, dtype=torch.float32, device=dev)
+        dy = torch.empty(n, c, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev) if has_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev) if has_b else None
+        ws, nb = _ws(n, c, dev)
+        lib.call("dc_edge_max_backward", dout, c, y, c, tptr, tedge, n, g.k, c, stat[0], stat[1], args[0], args[1],
+                 stat[2], coef[2], coef[3], coef[0], coef[1], slope, int(training), dzs, dy, c, dgamma, dbeta, ws, nb)
+        return dy, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def edge_max_bn(y, graph, bn, slope):
+    """bn: torch.nn.BatchNorm1d of the (single) s_mlp_max block; y = Linear(x)."""
+    require_gpu()
+    use_batch = bn.training or bn.running_mean is None
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    track = bn.training and bn.track_running_stats
+    if track:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            mom = 1.0 / float(bn.num_batches_tracked)
+    rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
+    return _EdgeMaxBN.apply(y, graph, bn.weight, bn.bias, rm, rv, use_batch, mom, float(bn.eps), float(slope))

@@ -141,6 +141,26 @@ int dc_vn_backward(const float* dout, int64_t lddo, const float* in, int64_t ld,
                    const float* gamma, int32_t training, float* din, int64_t lddi, float* dgamma, float* dbeta,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- layer-0 ("centralized") edge MLP + max aggregation without the [E,C] tensor ------------------
+ * scatter(s_mlp_max(x[col] - x[row]), row, reduce='max') -- deltaconv/nn/deltaconv.py:50-52 with a
+ * depth-1 s_mlp_max (nn/mlp.py:7-11).  y = Linear(x) [Nt,C]; edge pre-activation a_e = y_j - y_i.
+ * Derivation in deltaconv_amd/csrc/edge_math.h.  amax/amin/s1pt/dzs: [Nt,C] fp32 contiguous,
+ * argmax/argmin/arg: uint8 [Nt,C].  Workspace: dc_bn_workspace_bytes(Nt, C). */
+int dc_edge_gather_stats(const float* y, int64_t ldy, const int32_t* nbr, int32_t n, int32_t k, int32_t C,
+                         int32_t compute_stats, const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, float* amax, float* amin, uint8_t* argmax,
+                         uint8_t* argmin, float* s1pt, float* mean, float* invstd, float* scale, float* shift,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int dc_edge_max_apply(const float* amax, const float* amin, const uint8_t* argmax, const uint8_t* argmin, int32_t n,
+                      int32_t C, const float* scale, const float* shift, float slope, float* out, int64_t ldo,
+                      uint8_t* arg, void* stream);
+int dc_edge_max_backward(const float* dout, int64_t lddo, const float* y, int64_t ldy, const int32_t* tptr,
+                         const int32_t* tedge, int32_t n, int32_t k, int32_t C, const float* amax, const float* amin,
+                         const uint8_t* argmax, const uint8_t* argmin, const float* s1pt, const float* scale,
+                         const float* shift, const float* mean, const float* invstd, float slope, int32_t training,
+                         float* dzs, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include "../../deltaconv_amd/csrc/point_math.h"
 #include "../../deltaconv_amd/csrc/ell_math.h"
 #include "../../deltaconv_amd/csrc/nn_math.h"
+#include "../../deltaconv_amd/csrc/edge_math.h"
 
 extern "C" {
 
@@ -206,5 +207,47 @@ void hc_vn(const float* in, long n, int co, int combine, const float* gamma, con
             din[(2 * i) * ld + c] = gu; din[(2 * i + 1) * ld + c] = gv;
             if (combine) { din[(2 * i) * ld + co + c] = gv; din[(2 * i + 1) * ld + co + c] = -gu; }
         }
+}
+
+// ---- layer-0 edge MLP without the [E,C] tensor (edge_math.h): forward + backward, serial ----------
+void hc_edge(const float* y, const int* nbr, const int* tptr, const int* tedge, int n, int k, int C,
+             const float* gamma, const float* beta, float eps, float slope, int training, const float* run_mean,
+             const float* run_var, float* out, unsigned char* arg, const float* dout, float* dy, float* dgamma,
+             float* dbeta) {
+    using namespace dcedge;
+    std::vector<float> amax((size_t)n * C), amin((size_t)n * C), s1((size_t)n * C), dzs((size_t)n * C);
+    std::vector<unsigned char> amx((size_t)n * C), amn((size_t)n * C);
+    std::vector<double> q1(C, 0.0), q2(C, 0.0);
+    for (long i = 0; i < n; ++i)
+        for (int c = 0; c < C; ++c) {
+            double t[2][1];
+            edge_gather<1>(i, c, y, C, nbr, k, amax.data(), amin.data(), amx.data(), amn.data(), s1.data(), C, C, t);
+            q1[c] += t[0][0]; q2[c] += t[1][0];
+        }
+    std::vector<float> mean(C), invstd(C), scale(C), shift(C);
+    const long E = (long)n * k;
+    if (training) hc_coeffs(q1, q2, E, C, gamma, beta, eps, mean.data(), invstd.data(), scale.data(), shift.data());
+    else
+        for (int c = 0; c < C; ++c) {
+            invstd[c] = 1.f / sqrtf(run_var[c] + eps); mean[c] = run_mean[c];
+            scale[c] = gamma[c] * invstd[c]; shift[c] = beta[c] - run_mean[c] * scale[c];
+        }
+    for (long i = 0; i < n; ++i)
+        for (int c = 0; c < C; ++c) {
+            out[i * C + c] = dcnn::act(fmaf(scale[c], pick(scale[c], amax[i * C + c], amin[i * C + c]), shift[c]), slope);
+            arg[i * C + c] = scale[c] >= 0.f ? amx[i * C + c] : amn[i * C + c];
+        }
+    std::vector<double> a(C, 0.0), b(C, 0.0);
+    for (long i = 0; i < n; ++i)
+        for (int c = 0; c < C; ++c) {
+            float dz, dza;
+            edge_bwd_terms(dout[i * C + c], amax[i * C + c], amin[i * C + c], scale[c], shift[c], mean[c], invstd[c], slope, dz, dza);
+            dzs[i * C + c] = dz; a[c] += dz; b[c] += dza;
+        }
+    std::vector<float> m1(C), m2(C);
+    for (int c = 0; c < C; ++c) { dbeta[c] = (float)a[c]; dgamma[c] = (float)b[c]; m1[c] = (float)(a[c] / E); m2[c] = (float)(b[c] / E); }
+    for (long t = 0; t < (long)n * C; ++t)
+        edge_bwd_point<1>(t, C, tptr, tedge, k, y, C, dzs.data(), s1.data(), C, amx.data(), amn.data(), C, scale.data(),
+                          mean.data(), invstd.data(), m1.data(), m2.data(), training, dy, C);
 }
 }

@@ -49,7 +49,7 @@ def _compare(ours, ref, x, train=True, tol=2e-4):
             assert int(b1) == int(b2), n1
 
 
-@pytest.mark.parametrize("channels,rows", [((16, 32), 1000), ((12, 64, 64, 24), 4096), ((5, 7), 333)])
+@pytest.mark.parametrize("channels,rows", [((16, 32), 1000), ((12, 64, 64, 24), 4096), ((5, 7), 333), ((32, 16), 2)])
 def test_mlp_blocks(channels, rows):
     import deltaconv_amd as dc
     ours, ref = _pair(lambda: dc.nn.MLP(channels), lambda: oracle.nn.MLP(channels))
@@ -132,3 +132,52 @@ def test_vector_mlp_equivariance():
         t_out = (T @ mlp(v).view(-1, 2, co)).view(-1, co)
         out_t = mlp((T @ v.view(-1, 2, ci)).view(-1, ci))
         assert torch.allclose(t_out, out_t, atol=1e-5)
+
+
+def test_batchnorm_two_rows_no_cancellation():
+    """R = 2 with nearly equal rows (the classification head at batch 2): var = (dx/2)^2 must not be
+    lost to E[x^2] - E[x]^2 cancellation -> statistics are accumulated in fp64."""
+    import deltaconv_amd as dc
+    torch.manual_seed(5)
+    base = torch.randn(1, 64) * 3
+    x = torch.cat([base, base + 2e-3 * torch.randn(1, 64)], 0)
+    bn = dc.nn.BatchNorm1d(64).to(DEV).train()
+    ref = torch.nn.BatchNorm1d(64).double().train()
+    out = bn(x.to(DEV))
+    assert rel_err(out, ref(x.double())) < 1e-3
+
+
+@pytest.mark.parametrize("depth,train", [(1, True), (1, False), (2, True)])
+def test_centralized_layer_vs_oracle(depth, train):
+    """Layer 0: analytic (no [E,C] tensor) path for depth 1, materialised fused path for depth 2."""
+    import deltaconv_amd as dc
+    from deltaconv_amd.data import synthetic_batch
+    from oracle import geometry as geo
+    b = synthetic_batch(3, 0, seed=50, sizes=[400, 256, 300], dup_frac=0.03)
+    ours, ref = _pair(lambda: dc.nn.DeltaConv(3, 32, depth=depth, centralized=True, vector=True),
+                      lambda: oracle.nn.DeltaConv(3, 32, depth=depth, centralized=True, vector=True))
+    ours.train(train); ref.train(train)
+    ptr = geo.cloud_ptr(b.batch)
+    nbr = geo.knn(b.pos, 20, ptr)
+    xb, yb = geo.build_tangent_basis(b.norm)
+    Go, Do = geo.build_grad_div(b.pos, b.norm, xb, yb, nbr, ptr)
+    bd = b.to(DEV)
+    graph = dc.geometry.Graph.knn(bd.pos, 20, bd.batch)
+    assert torch.equal(graph.nbr.cpu().long(), nbr)
+    G, D = dc.geometry.build_grad_div(bd.pos, bd.norm, xb.to(DEV), yb.to(DEV), graph, bd.batch)
+    x = b.pos.clone().requires_grad_(True)
+    xd = bd.pos.clone().requires_grad_(True)
+    xo_, vo_ = ref(x, Go @ x, Go, Do, nbr)
+    xd_, vd_ = ours(xd, G @ xd, G, D, graph)
+    assert rel_err(xd_, xo_) < 1e-3 and rel_err(vd_, vo_) < 1e-3
+    if train:
+        wx, wv = torch.randn_like(xo_), torch.randn_like(vo_)
+        ((xo_ * wx).sum() + (vo_ * wv).sum()).backward()
+        ((xd_ * wx.to(DEV)).sum() + (vd_ * wv.to(DEV)).sum()).backward()
+        assert rel_err(xd.grad, x.grad) < 5e-3
+        for (n1, p1), (n2, p2) in zip(ours.named_parameters(), ref.named_parameters()):
+            if p2.grad is not None:
+                assert rel_err(p1.grad, p2.grad) < 5e-3, n1
+        for (n1, b1), (n2, b2) in zip(ours.named_buffers(), ref.named_buffers()):
+            if b2.dtype.is_floating_point:
+                assert rel_err(b1, b2) < 1e-3, n1

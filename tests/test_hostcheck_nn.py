@@ -105,3 +105,38 @@ def test_vector_nonlin(hc, combine, training):
         assert rel_err(dg, grads[1]) < 1e-4 and rel_err(db, grads[2]) < 1e-4
     else:
         assert rel_err(db, grads[1]) < 1e-4
+
+
+@pytest.mark.parametrize("slope,training", [(0.2, 1), (0.0, 1), (0.2, 0)])
+def test_edge_mlp_without_edge_tensor(hc, slope, training):
+    """edge_math.h (analytic max + moment statistics + closed-form BN backward) vs the materialised
+    reference formulation: BN over all E edge rows of y_j - y_i, LeakyReLU, max over the k-list."""
+    from deltaconv_amd.data import synthetic_batch
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    hc.hc_edge.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, vp, cf, cf, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+    hc.hc_csc_build.argtypes = [vp, ci, ci, vp, vp]
+    torch.manual_seed(2)
+    b = synthetic_batch(2, 0, seed=13, sizes=[60, 45], dup_frac=0.05)
+    n, k, C = b.pos.shape[0], 9, 6
+    nbr = geo.knn(b.pos, k, geo.cloud_ptr(b.batch))
+    nbr32 = nbr.to(torch.int32).contiguous()
+    tptr, tedge = torch.zeros(n + 1, dtype=torch.int32), torch.zeros(n * k, dtype=torch.int32)
+    hc.hc_csc_build(P(nbr32), n, k, P(tptr), P(tedge))
+    y = torch.randn(n, C, requires_grad=True)
+    gamma = torch.tensor([1.0, -0.8, 0.5, 1.5, -1.2, 0.7], requires_grad=True)
+    beta = (torch.randn(C) * 0.3).requires_grad_(True)
+    rm, rv = torch.randn(C) * 0.1, torch.rand(C) + 0.5
+    a = (y[nbr] - y[:, None, :]).reshape(n * k, C)
+    z = F.batch_norm(a, rm.clone(), rv.clone(), gamma, beta, training=bool(training), eps=1e-5)
+    h = F.leaky_relu(z, slope).view(n, k, C)
+    out_ref, arg_ref = h.max(dim=1)
+    dout = torch.randn(n, C)
+    gy, gg, gb = torch.autograd.grad(out_ref, [y, gamma, beta], dout)
+    out, arg = torch.zeros(n, C), torch.zeros(n, C, dtype=torch.uint8)
+    dy, dg, db = torch.zeros(n, C), torch.zeros(C), torch.zeros(C)
+    hc.hc_edge(P(y.detach()), P(nbr32), P(tptr), P(tedge), n, k, C, P(gamma.detach()), P(beta.detach()), 1e-5, slope,
+               training, P(rm), P(rv), P(out), P(arg), P(dout), P(dy), P(dg), P(db))
+    assert rel_err(out, out_ref) < 1e-5
+    if slope > 0:
+        assert torch.equal(arg.long(), arg_ref)
+    assert rel_err(dy, gy) < 1e-4 and rel_err(dg, gg) < 1e-4 and rel_err(db, gb) < 1e-4
