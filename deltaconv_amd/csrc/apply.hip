@@ -25,10 +25,40 @@ constexpr int TPB = 256;
 
 #define P_FWD const float *coef, const int *nbr, int k, const float *in, long ldi, float *out, long ldo
 #define A_FWD coef, nbr, k, in, ldi, out, ldo
-DC_ELL_KERNEL(grad_fwd, grad_fwd, P_FWD, A_FWD)
-DC_ELL_KERNEL(div_fwd, div_fwd, P_FWD, A_FWD)
-DC_ELL_KERNEL(divcurlnorm_fwd, divcurlnorm_fwd, P_FWD, A_FWD)
-DC_ELL_KERNEL(hodge_fwd, hodge_fwd, P_FWD, A_FWD)
+// forward kernels: V = vector width, U = neighbour rows requested per batch (gathers in flight)
+#define DC_ELL_FWD_KERNEL(NAME)                                                                        \
+    template <int V, int U>                                                                            \
+    __global__ __launch_bounds__(TPB) void NAME##_kernel(long total, int groups, int remap, P_FWD) {   \
+        const long t = dc_xcd_block(remap) * TPB + threadIdx.x;                                        \
+        if (t >= total) return;                                                                        \
+        NAME<V, U>(t, groups, A_FWD);                                                                  \
+    }
+DC_ELL_FWD_KERNEL(grad_fwd)
+DC_ELL_FWD_KERNEL(div_fwd)
+DC_ELL_FWD_KERNEL(divcurlnorm_fwd)
+DC_ELL_FWD_KERNEL(hodge_fwd)
+
+#define DC_LAUNCH_FWD(NAME, V, U, n, C, stream, ...)                                                        \
+    do {                                                                                                    \
+        const int groups_ = (C) / (V);                                                                      \
+        const long total_ = (long)(n) * groups_;                                                            \
+        hipLaunchKernelGGL((NAME##_kernel<V, U>), dim3(dc_cdiv(total_, TPB)), dim3(TPB), 0, stream, total_, \
+                           groups_, dc_option(DC_OPT_XCD_REMAP), __VA_ARGS__);                              \
+    } while (0)
+
+// DC_OPT_GATHER_BATCH: 0 (default) -> 10 rows in flight, 1 -> 4, 2 -> 20   (A/B switch)
+#define DC_DISPATCH_FWD(NAME, v, n, C, stream, ...)                                              \
+    do {                                                                                         \
+        const int ub_ = dc_option(DC_OPT_GATHER_BATCH);                                          \
+        if ((v) == 1)                                                                            \
+            DC_LAUNCH_FWD(NAME, 1, 4, n, C, stream, __VA_ARGS__);                                \
+        else if (ub_ == 1)                                                                       \
+            DC_LAUNCH_FWD(NAME, 4, 4, n, C, stream, __VA_ARGS__);                                \
+        else if (ub_ == 2)                                                                       \
+            DC_LAUNCH_FWD(NAME, 4, 20, n, C, stream, __VA_ARGS__);                               \
+        else                                                                                     \
+            DC_LAUNCH_FWD(NAME, 4, 10, n, C, stream, __VA_ARGS__);                               \
+    } while (0)
 
 #define P_T const float *coef, const int *tptr, const int *tedge, int k, const float *dy, long ldy, float *dx, long ldx, int acc
 #define A_T coef, tptr, tedge, k, dy, ldy, dx, ldx, acc
@@ -90,8 +120,8 @@ int check_common(const char* name, const void* a, const void* b, const void* c, 
         DC_REQUIRE(ldi >= (MINLDI) && ldo >= (MINLDO), #FN ": leading dimension smaller than the row");           \
         if (n == 0 || C == 0) return DC_OK;                                                                       \
         const int v = pick_v(C, {(long)ldi, (long)ldo}, {in, out});                                               \
-        DC_DISPATCH_V(KERNEL, v, n, C, static_cast<hipStream_t>(stream), coef, nbr, k, in, (long)ldi, out,        \
-                      (long)ldo);                                                                                 \
+        DC_DISPATCH_FWD(KERNEL, v, n, C, static_cast<hipStream_t>(stream), coef, nbr, k, in, (long)ldi, out,      \
+                        (long)ldo);                                                                               \
         DC_CHECK_LAUNCH(#FN);                                                                                     \
         return DC_OK;                                                                                             \
     }

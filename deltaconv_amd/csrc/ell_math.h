@@ -60,64 +60,101 @@ struct G2 {
 DC_HD G2 ldcoef(const float* coef, long e) { return *reinterpret_cast<const G2*>(coef + 2 * e); }
 
 // ---- forward applies -------------------------------------------------------------------------
+// Batched gather: U neighbours per batch -- all ids / coefficients of the batch are loaded first,
+// then all U neighbour rows are requested back-to-back (U gathers in flight per lane), then the
+// FMAs run.  The tail of the k-list is handled by clamping the slot and zeroing the coefficient.
+template <int U>
+struct Batch {
+    long j[U];
+    G2 g[U];
+};
+template <int U>
+DC_HD Batch<U> load_batch(const float* coef, const int* nbr, long i, int k, int s0) {
+    Batch<U> b;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int s = s0 + u;
+        const bool ok = s < k;
+        const long e = i * k + (ok ? s : k - 1);
+        b.j[u] = nbr[e];
+        const G2 g = ldcoef(coef, e);
+        b.g[u].a = ok ? g.a : 0.f;
+        b.g[u].b = ok ? g.b : 0.f;
+    }
+    return b;
+}
+
 // grad @ x : out[2i+a, c] = sum_s G[i,s,a] * x[nbr[i,s], c]          (torch_sparse spmm at
 // models/deltanet_base.py:78, nn/deltaconv.py:66)
-template <int V>
+template <int V, int U = 4>
 DC_HD void grad_fwd(long t, int groups, const float* G, const int* nbr, int k, const float* x, long ldx, float* out,
                     long ldo) {
     const long i = t / groups;
     const int c0 = (int)(t % groups) * V;
     Vec<V> au = vzero<V>(), av = vzero<V>();
-#pragma unroll 4
-    for (int s = 0; s < k; ++s) {
-        const long e = i * k + s;
-        const G2 g = ldcoef(G, e);
-        const Vec<V> xv = vload<V>(x + (long)nbr[e] * ldx + c0);
-        vfma<V>(au, g.a, xv);
-        vfma<V>(av, g.b, xv);
+    for (int s0 = 0; s0 < k; s0 += U) {
+        const Batch<U> b = load_batch<U>(G, nbr, i, k, s0);
+        Vec<V> xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = vload<V>(x + b.j[u] * ldx + c0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vfma<V>(au, b.g[u].a, xv[u]);
+            vfma<V>(av, b.g[u].b, xv[u]);
+        }
     }
     vstore<V>(out + (2 * i) * ldo + c0, au);
     vstore<V>(out + (2 * i + 1) * ldo + c0, av);
 }
 
 // div @ v : out[i, c] = sum_s D[i,s,0] * v[2j, c] + D[i,s,1] * v[2j+1, c]   (nn/deltaconv.py:57)
-template <int V>
+template <int V, int U = 4>
 DC_HD void div_fwd(long t, int groups, const float* D, const int* nbr, int k, const float* v, long ldv, float* out,
                    long ldo) {
     const long i = t / groups;
     const int c0 = (int)(t % groups) * V;
     Vec<V> acc = vzero<V>();
-#pragma unroll 4
-    for (int s = 0; s < k; ++s) {
-        const long e = i * k + s;
-        const G2 d = ldcoef(D, e);
-        const long j = nbr[e];
-        vfma<V>(acc, d.a, vload<V>(v + (2 * j) * ldv + c0));
-        vfma<V>(acc, d.b, vload<V>(v + (2 * j + 1) * ldv + c0));
+    for (int s0 = 0; s0 < k; s0 += U) {
+        const Batch<U> b = load_batch<U>(D, nbr, i, k, s0);
+        Vec<V> vu[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vu[u] = vload<V>(v + (2 * b.j[u]) * ldv + c0);
+            vv[u] = vload<V>(v + (2 * b.j[u] + 1) * ldv + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vfma<V>(acc, b.g[u].a, vu[u]);
+            vfma<V>(acc, b.g[u].b, vv[u]);
+        }
     }
     vstore<V>(out + i * ldo + c0, acc);
 }
 
 // Fused [div v | curl v | norm v] -> out[i, 0:C | C:2C | 2C:3C]  (nn/deltaconv.py:57 with
 // geometry/operators.py:4-7,23-27: curl = -div(J v), J(v) = (-v_v, v_u)).  v is gathered once.
-template <int V>
+template <int V, int U = 4>
 DC_HD void divcurlnorm_fwd(long t, int groups, const float* D, const int* nbr, int k, const float* v, long ldv,
                            float* out, long ldo) {
     const long i = t / groups;
     const int c0 = (int)(t % groups) * V;
     const int C = groups * V;
     Vec<V> dv = vzero<V>(), cv = vzero<V>();
-#pragma unroll 4
-    for (int s = 0; s < k; ++s) {
-        const long e = i * k + s;
-        const G2 d = ldcoef(D, e);
-        const long j = nbr[e];
-        const Vec<V> vu = vload<V>(v + (2 * j) * ldv + c0);
-        const Vec<V> vv = vload<V>(v + (2 * j + 1) * ldv + c0);
-        vfma<V>(dv, d.a, vu);
-        vfma<V>(dv, d.b, vv);
-        vfma<V>(cv, d.a, vv);   // -(D0 * (-v_v) + D1 * v_u)
-        vfma<V>(cv, -d.b, vu);
+    for (int s0 = 0; s0 < k; s0 += U) {
+        const Batch<U> b = load_batch<U>(D, nbr, i, k, s0);
+        Vec<V> vu[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vu[u] = vload<V>(v + (2 * b.j[u]) * ldv + c0);
+            vv[u] = vload<V>(v + (2 * b.j[u] + 1) * ldv + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vfma<V>(dv, b.g[u].a, vu[u]);
+            vfma<V>(dv, b.g[u].b, vv[u]);
+            vfma<V>(cv, b.g[u].a, vv[u]);   // -(D0 * (-v_v) + D1 * v_u)
+            vfma<V>(cv, -b.g[u].b, vu[u]);
+        }
     }
     const Vec<V> ou = vload<V>(v + (2 * i) * ldv + c0), ov = vload<V>(v + (2 * i + 1) * ldv + c0);
     Vec<V> nv;
@@ -132,24 +169,28 @@ DC_HD void divcurlnorm_fwd(long t, int groups, const float* D, const int* nbr, i
 // recomputes them; here they are read from dc[j, 0:C | C:2C]):
 //   hodge = -(grad(div v) + J grad(curl v))
 //   h_u = -(sum G_u dv_j - sum G_v cv_j),  h_v = -(sum G_v dv_j + sum G_u cv_j)
-template <int V>
+template <int V, int U = 4>
 DC_HD void hodge_fwd(long t, int groups, const float* G, const int* nbr, int k, const float* dc, long ldd, float* out,
                      long ldo) {
     const long i = t / groups;
     const int c0 = (int)(t % groups) * V;
     const int C = groups * V;
     Vec<V> hu = vzero<V>(), hv = vzero<V>();
-#pragma unroll 4
-    for (int s = 0; s < k; ++s) {
-        const long e = i * k + s;
-        const G2 g = ldcoef(G, e);
-        const long j = nbr[e];
-        const Vec<V> dv = vload<V>(dc + j * ldd + c0);
-        const Vec<V> cv = vload<V>(dc + j * ldd + C + c0);
-        vfma<V>(hu, -g.a, dv);
-        vfma<V>(hu, g.b, cv);
-        vfma<V>(hv, -g.b, dv);
-        vfma<V>(hv, -g.a, cv);
+    for (int s0 = 0; s0 < k; s0 += U) {
+        const Batch<U> b = load_batch<U>(G, nbr, i, k, s0);
+        Vec<V> dv[U], cv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            dv[u] = vload<V>(dc + b.j[u] * ldd + c0);
+            cv[u] = vload<V>(dc + b.j[u] * ldd + C + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            vfma<V>(hu, -b.g[u].a, dv[u]);
+            vfma<V>(hu, b.g[u].b, cv[u]);
+            vfma<V>(hv, -b.g[u].b, dv[u]);
+            vfma<V>(hv, -b.g[u].a, cv[u]);
+        }
     }
     vstore<V>(out + (2 * i) * ldo + c0, hu);
     vstore<V>(out + (2 * i + 1) * ldo + c0, hv);

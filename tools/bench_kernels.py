@@ -62,9 +62,10 @@ def main():
         graph.csc()
     rec("csc_build", timeit(csc, 20, 3), 12 * E)
     tptr, tedge = graph.csc()
-    for remap in (1, 0):
+    for remap, ub in ((1, 0), (1, 1), (1, 2), (0, 0)):
         lib.raw("dc_set_option")(0, remap)
-        for C in a.channels:
+        lib.raw("dc_set_option")(1, ub)
+        for C in (a.channels if (remap, ub) == (1, 0) else a.channels[:1]):
             x = torch.randn(n, C, device=dev)
             v = torch.randn(2 * n, C, device=dev)
             dcn = torch.randn(n, 3 * C, device=dev)
@@ -73,7 +74,7 @@ def main():
             y3 = torch.empty(n, 3 * C, device=dev)
             arg = torch.empty(n, C, dtype=torch.uint8, device=dev)
             ab = 12 * C * n + 12 * E
-            kw = dict(C=C, remap=remap)
+            kw = dict(C=C, remap=remap, ub=ub)
             call = lib.call
             rec("apply_grad", timeit(lambda: call("dc_apply_grad", grad.coef, graph.nbr, n, k, x, C, C, y2, C)), ab, **kw)
             rec("apply_div", timeit(lambda: call("dc_apply_div", div.coef, graph.nbr, n, k, v, C, C, y1, C)), ab, **kw)
@@ -106,6 +107,7 @@ def main():
             gy = torch.randn_like(yg)
             rec("fused bn_act bwd [Nt,C]", timeit(lambda: torch.autograd.grad(yg, xg, gy, retain_graph=True)), 20 * C * n, **kw)
     lib.raw("dc_set_option")(0, 1)
+    lib.raw("dc_set_option")(1, 0)
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
 
