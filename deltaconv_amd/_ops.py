@@ -17,10 +17,11 @@ class _Apply(torch.autograd.Function):
     """kind in {'grad','div'}: y = A @ x with A in ELL form."""
 
     @staticmethod
-    def forward(ctx, x, coef, graph, kind):
+    def forward(ctx, x, op, graph, kind):
+        coef = op.coef
         x = _f32c(x)
         n, k, c = graph.n, graph.k, x.shape[1]
-        ctx.graph, ctx.kind, ctx.coef = graph, kind, coef
+        ctx.graph, ctx.kind, ctx.op = graph, kind, op
         if kind == 'grad':
             assert x.shape[0] == n, f"grad @ x: x has {x.shape[0]} rows, graph has {n} points"
             out = torch.empty(2 * n, c, dtype=torch.float32, device=x.device)
@@ -38,10 +39,10 @@ class _Apply(torch.autograd.Function):
         tptr, tedge = g.csc()
         if ctx.kind == 'grad':
             dx = torch.empty(g.n, c, dtype=torch.float32, device=dy.device)
-            lib.call("dc_apply_grad_T", ctx.coef, tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
+            lib.call("dc_apply_grad_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
         else:
             dx = torch.empty(2 * g.n, c, dtype=torch.float32, device=dy.device)
-            lib.call("dc_apply_div_T", ctx.coef, tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
+            lib.call("dc_apply_div_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
         return dx, None, None, None
 
 
@@ -49,13 +50,14 @@ class _DivCurlNorm(torch.autograd.Function):
     """v[2Nt,C] -> [div v | curl v | norm v] [Nt,3C] in one gather pass."""
 
     @staticmethod
-    def forward(ctx, v, coef, graph):
+    def forward(ctx, v, op, graph):
         v = _f32c(v)
+        coef = op.coef
         n, k, c = graph.n, graph.k, v.shape[1]
         assert v.shape[0] == 2 * n
         out = torch.empty(n, 3 * c, dtype=torch.float32, device=v.device)
         lib.call("dc_apply_div_curl_norm", coef, graph.nbr, n, k, v, c, c, out, 3 * c)
-        ctx.graph, ctx.coef = graph, coef
+        ctx.graph, ctx.op = graph, op
         ctx.save_for_backward(v)
         return out
 
@@ -66,7 +68,7 @@ class _DivCurlNorm(torch.autograd.Function):
         g, c = ctx.graph, v.shape[1]
         tptr, tedge = g.csc()
         dv = torch.empty_like(v)
-        lib.call("dc_apply_div_curl_norm_T", ctx.coef, tptr, tedge, g.n, g.k, dout, c, 3 * c, v, c, dv, c, 0)
+        lib.call("dc_apply_div_curl_norm_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dout, c, 3 * c, v, c, dv, c, 0)
         return dv, None, None
 
 
@@ -74,14 +76,15 @@ class _Hodge(torch.autograd.Function):
     """dcn[Nt, >=2C] holding [div v | curl v | ...] -> hodge_laplacian(v) [2Nt,C]."""
 
     @staticmethod
-    def forward(ctx, dcn, coef, graph, c):
+    def forward(ctx, dcn, op, graph, c):
         dcn = _f32c(dcn)
+        coef = op.coef
         n, k = graph.n, graph.k
         ld = dcn.shape[1]
         assert dcn.shape[0] == n and ld >= 2 * c
         out = torch.empty(2 * n, c, dtype=torch.float32, device=dcn.device)
         lib.call("dc_apply_hodge", coef, graph.nbr, n, k, dcn, c, ld, out, c)
-        ctx.graph, ctx.coef, ctx.c, ctx.ld = graph, coef, c, ld
+        ctx.graph, ctx.op, ctx.c, ctx.ld = graph, op, c, ld
         return out
 
     @staticmethod
@@ -91,7 +94,7 @@ class _Hodge(torch.autograd.Function):
         tptr, tedge = g.csc()
         ddcn = torch.zeros(g.n, ld, dtype=torch.float32, device=dh.device) if ld > 2 * c else \
             torch.empty(g.n, ld, dtype=torch.float32, device=dh.device)
-        lib.call("dc_apply_hodge_T", ctx.coef, tptr, tedge, g.n, g.k, dh, c, c, ddcn, ld, 0)
+        lib.call("dc_apply_hodge_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dh, c, c, ddcn, ld, 0)
         return ddcn, None, None, None
 
 
@@ -122,16 +125,16 @@ class _KnnMax(torch.autograd.Function):
         return dh, None
 
 
-def apply_op(x, coef, graph, kind):
-    return _Apply.apply(x, coef, graph, kind)
+def apply_op(x, op):
+    return _Apply.apply(x, op, op.graph, op.kind)
 
 
 def div_curl_norm(v, div):
-    return _DivCurlNorm.apply(v, div.coef, div.graph)
+    return _DivCurlNorm.apply(v, div, div.graph)
 
 
 def hodge_from_dcn(dcn, grad, c):
-    return _Hodge.apply(dcn, grad.coef, grad.graph, c)
+    return _Hodge.apply(dcn, grad, grad.graph, c)
 
 
 def knn_max(h, graph):

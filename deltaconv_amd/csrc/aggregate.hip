@@ -3,35 +3,21 @@
 // (/root/reference/deltaconv/nn/deltaconv.py:52,54): the [E,C] tensor is never materialised;
 // the winning slot is kept as one byte per (point, channel).
 // HBM-bound: 4C*Nt in + 4C*Nt out + C*Nt arg + 4E ids per layer (reference: 4*C*E gathered).
+#include <initializer_list>
 #include "common.h"
-#include "ell_math.h"
+#include "ell_stage.h"
 
 namespace {
 using namespace dcell;
-constexpr int TPB = 256;
+using namespace dcstage;
 
 template <int V>
-__global__ __launch_bounds__(TPB) void knn_max_fwd_kernel(long total, int groups, int remap, const int* nbr, int k,
-                                                          const float* h, long ldh, float* out, long ldo,
-                                                          unsigned char* arg, long lda) {
-    const long t = dc_xcd_block(remap) * TPB + threadIdx.x;
-    if (t >= total) return;
-    knn_max_fwd<V>(t, groups, nbr, k, h, ldh, out, ldo, arg, lda);
-}
-
-template <int V>
-__global__ __launch_bounds__(TPB) void knn_max_bwd_kernel(long total, int groups, int remap, const int* tptr, const int* tedge,
-                                                          int k, const unsigned char* arg, long lda,
-                                                          const float* dout, long ldo, float* dh, long ldh, int acc) {
-    const long t = dc_xcd_block(remap) * TPB + threadIdx.x;
-    if (t >= total) return;
-    knn_max_bwd<V>(t, groups, tptr, tedge, k, arg, lda, dout, ldo, dh, ldh, acc);
-}
-
-inline bool vec_ok(int C, long a, long b, const void* p, const void* q) {
-    return C % 4 == 0 && a % 4 == 0 && b % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0 &&
-           (reinterpret_cast<uintptr_t>(q) & 15) == 0;
-}
+struct KnnMaxF {
+    const float* h; long ldh; float* out; long ldo; unsigned char* arg; long lda;
+    __device__ void operator()(long i, int c0, Row r, int k) const {
+        knn_max_fwd<V>(i, c0, r.ids, k, h, ldh, out, ldo, arg, lda);
+    }
+};
 }  // namespace
 
 DC_EXPORT int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float* out,
@@ -41,15 +27,10 @@ DC_EXPORT int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* 
     DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_max: leading dimension smaller than the row");
     if (n == 0 || C == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vec_ok(C, ldh, ldo, h, out)) {
-        const long total = (long)n * (C / 4);
-        hipLaunchKernelGGL(knn_max_fwd_kernel<4>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C / 4, dc_option(DC_OPT_XCD_REMAP), nbr, k, h,
-                           (long)ldh, out, (long)ldo, arg, (long)C);
-    } else {
-        const long total = (long)n * C;
-        hipLaunchKernelGGL(knn_max_fwd_kernel<1>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C, dc_option(DC_OPT_XCD_REMAP), nbr, k, h,
-                           (long)ldh, out, (long)ldo, arg, (long)C);
-    }
+    if (pick_v(C, {(long)ldh, (long)ldo}, {h, out}) == 4)
+        launch_fwd<4>(n, C, nullptr, nbr, k, KnnMaxF<4>{h, (long)ldh, out, (long)ldo, arg, (long)C}, s);
+    else
+        launch_fwd<1>(n, C, nullptr, nbr, k, KnnMaxF<1>{h, (long)ldh, out, (long)ldo, arg, (long)C}, s);
     DC_CHECK_LAUNCH("dc_knn_max");
     return DC_OK;
 }
@@ -62,15 +43,10 @@ DC_EXPORT int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int
     DC_REQUIRE(ldo >= C && ldh >= C, "dc_knn_max_backward: leading dimension smaller than the row");
     if (n == 0 || C == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vec_ok(C, ldo, ldh, dout, dh)) {
-        const long total = (long)n * (C / 4);
-        hipLaunchKernelGGL(knn_max_bwd_kernel<4>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C / 4, dc_option(DC_OPT_XCD_REMAP), tptr,
-                           tedge, k, arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate);
-    } else {
-        const long total = (long)n * C;
-        hipLaunchKernelGGL(knn_max_bwd_kernel<1>, dim3(dc_cdiv(total, TPB)), dim3(TPB), 0, s, total, C, dc_option(DC_OPT_XCD_REMAP), tptr, tedge, k,
-                           arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate);
-    }
+    if (pick_v(C, {(long)ldo, (long)ldh}, {dout, dh}) == 4)
+        launch_T<4>(n, C, nullptr, tptr, tedge, k, KnnMaxT<4>{arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate, C}, s);
+    else
+        launch_T<1>(n, C, nullptr, tptr, tedge, k, KnnMaxT<1>{arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate, C}, s);
     DC_CHECK_LAUNCH("dc_knn_max_backward");
     return DC_OK;
 }

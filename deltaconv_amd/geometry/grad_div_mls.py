@@ -21,6 +21,15 @@ class SparseOp:
     def __init__(self, kind, graph, coef):
         assert kind in ("grad", "div")
         self.kind, self.graph, self.coef = kind, graph, coef
+        self._coefT = None
+
+    def coefT(self):
+        """Coefficients in CSC order (for the transposed applies of the backward pass); built once."""
+        if self._coefT is None:
+            _, tedge = self.graph.csc()
+            self._coefT = torch.empty_like(self.coef)
+            lib.call("dc_csc_permute_coef", self.coef, tedge, tedge.numel(), self._coefT)
+        return self._coefT
 
     def size(self, i):
         n = self.graph.n
@@ -30,7 +39,7 @@ class SparseOp:
         return [self.size(0), self.size(1)]
 
     def __matmul__(self, x):
-        return _ops.apply_op(x, self.coef, self.graph, self.kind)
+        return _ops.apply_op(x, self)
 
     def coo(self):
         """(row, col, value) triplets in the reference's order (grad_div_mls.py:253-255,271-274)."""

@@ -52,6 +52,9 @@ int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_cloud
                  int32_t* tptr /*[Nt+1]*/, int32_t* tedge /*[Nt*k]*/, void* workspace, size_t workspace_bytes,
                  void* stream);
 
+/* coefT[t] = coef[tedge[t]]: G or D in CSC order for the transposed applies (once per batch). */
+int dc_csc_permute_coef(const float* coef, const int32_t* tedge, int64_t num_edges, float* coefT, void* stream);
+
 /* ---- tangent frames ------------------------------------------------------------------------ */
 /* build_tangent_basis -- deltaconv/geometry/grad_div_mls.py:50-69 */
 int dc_tangent_basis(const float* normal, int32_t n, float* x_basis, float* y_basis, void* stream);
@@ -85,15 +88,16 @@ int dc_apply_div_curl_norm(const float* D, const int32_t* nbr, int32_t n, int32_
 int dc_apply_hodge(const float* G, const int32_t* nbr, int32_t n, int32_t k, const float* dc, int32_t C, int64_t lddc,
                    float* out, int64_t ldo, void* stream);
 
-/* Transposed forms = backward of the four applies (operators carry no gradient).  accumulate != 0
- * adds into the destination (gradient accumulation without a separate add). */
-int dc_apply_grad_T(const float* G, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
+/* Transposed forms = backward of the four applies (operators carry no gradient).  The coefficient
+ * argument is the operator in CSC order (dc_csc_permute_coef).  accumulate != 0 adds into the
+ * destination (gradient accumulation without a separate add). */
+int dc_apply_grad_T(const float* GT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
                     int32_t C, int64_t ldy, float* dx, int64_t ldx, int32_t accumulate, void* stream);
-int dc_apply_div_T(const float* D, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
+int dc_apply_div_T(const float* DT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
                    int32_t C, int64_t ldy, float* dv, int64_t ldv, int32_t accumulate, void* stream);
-int dc_apply_hodge_T(const float* G, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dh,
+int dc_apply_hodge_T(const float* GT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dh,
                      int32_t C, int64_t ldh, float* ddc, int64_t lddc, int32_t accumulate, void* stream);
-int dc_apply_div_curl_norm_T(const float* D, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k,
+int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k,
                              const float* dout, int32_t C, int64_t ldo, const float* v, int64_t ldv, float* dv,
                              int64_t lddv, int32_t accumulate, void* stream);
 

@@ -66,57 +66,69 @@ void hc_csc_build(const int* nbr, int n, int k, int* tptr, int* tedge) {
     for (int j = 0; j < n; ++j) dcell::sort_column(tedge, tptr[j], tptr[j + 1]);
 }
 
-#define HC_LOOP(V, CALL)                                    \
-    do {                                                    \
-        const int groups = C / V;                           \
-        for (long t = 0; t < (long)n * groups; ++t) { CALL; } \
-    } while (0)
+// forward: loop all (point, channel group) work items with the rows taken from the global arrays
+#define HC_FWD(V, FN)                                                                               \
+    for (long i = 0; i < n; ++i)                                                                    \
+        for (int c0 = 0; c0 < C; c0 += V) FN<V>(i, c0, C, global_row(coef, nbr, i, k), k, in, ldi, out, ldo)
 
 // op: 0 grad, 1 div, 2 divcurlnorm, 3 hodge
 void hc_ell_fwd(int op, int V, const float* coef, const int* nbr, int n, int k, const float* in, int C, long ldi,
                 float* out, long ldo) {
     using namespace dcell;
     if (V == 4) {
-        if (op == 0) HC_LOOP(4, grad_fwd<4>(t, groups, coef, nbr, k, in, ldi, out, ldo));
-        if (op == 1) HC_LOOP(4, div_fwd<4>(t, groups, coef, nbr, k, in, ldi, out, ldo));
-        if (op == 2) HC_LOOP(4, divcurlnorm_fwd<4>(t, groups, coef, nbr, k, in, ldi, out, ldo));
-        if (op == 3) HC_LOOP(4, hodge_fwd<4>(t, groups, coef, nbr, k, in, ldi, out, ldo));
+        if (op == 0) HC_FWD(4, grad_fwd);
+        if (op == 1) HC_FWD(4, div_fwd);
+        if (op == 2) HC_FWD(4, divcurlnorm_fwd);
+        if (op == 3) HC_FWD(4, hodge_fwd);
     } else {
-        if (op == 0) HC_LOOP(1, grad_fwd<1>(t, groups, coef, nbr, k, in, ldi, out, ldo));
-        if (op == 1) HC_LOOP(1, div_fwd<1>(t, groups, coef, nbr, k, in, ldi, out, ldo));
-        if (op == 2) HC_LOOP(1, divcurlnorm_fwd<1>(t, groups, coef, nbr, k, in, ldi, out, ldo));
-        if (op == 3) HC_LOOP(1, hodge_fwd<1>(t, groups, coef, nbr, k, in, ldi, out, ldo));
+        if (op == 0) HC_FWD(1, grad_fwd);
+        if (op == 1) HC_FWD(1, div_fwd);
+        if (op == 2) HC_FWD(1, divcurlnorm_fwd);
+        if (op == 3) HC_FWD(1, hodge_fwd);
     }
 }
 
+#define HC_T(V, OPINIT)                                           \
+    for (long j = 0; j < n; ++j)                                  \
+        for (int c0 = 0; c0 < C; c0 += V) walk_column(OPINIT, j, c0, coefT.data(), tptr, tedge, k)
+
+// transposed: coefficients are first permuted into CSC order (as dc_csc_permute_coef does)
 void hc_ell_T(int op, int V, const float* coef, const int* tptr, const int* tedge, int n, int k, const float* dy,
               int C, long ldy, float* dx, long ldx, int acc, const float* v, long ldv) {
     using namespace dcell;
+    std::vector<float> coefT((size_t)n * k * 2);
+    for (long t = 0; t < (long)n * k; ++t) { coefT[2 * t] = coef[2 * (long)tedge[t]]; coefT[2 * t + 1] = coef[2 * (long)tedge[t] + 1]; }
     if (V == 4) {
-        if (op == 0) HC_LOOP(4, grad_T<4>(t, groups, coef, tptr, tedge, k, dy, ldy, dx, ldx, acc));
-        if (op == 1) HC_LOOP(4, div_T<4>(t, groups, coef, tptr, tedge, k, dy, ldy, dx, ldx, acc));
-        if (op == 2) HC_LOOP(4, divcurlnorm_T<4>(t, groups, coef, tptr, tedge, k, dy, ldy, v, ldv, dx, ldx, acc));
-        if (op == 3) HC_LOOP(4, hodge_T<4>(t, groups, coef, tptr, tedge, k, dy, ldy, dx, ldx, acc));
+        if (op == 0) HC_T(4, (GradT<4>{dy, ldy, dx, ldx, acc, C}));
+        if (op == 1) HC_T(4, (DivT<4>{dy, ldy, dx, ldx, acc, C}));
+        if (op == 2) HC_T(4, (DivCurlNormT<4>{dy, ldy, v, ldv, dx, ldx, acc, C}));
+        if (op == 3) HC_T(4, (HodgeT<4>{dy, ldy, dx, ldx, acc, C}));
     } else {
-        if (op == 0) HC_LOOP(1, grad_T<1>(t, groups, coef, tptr, tedge, k, dy, ldy, dx, ldx, acc));
-        if (op == 1) HC_LOOP(1, div_T<1>(t, groups, coef, tptr, tedge, k, dy, ldy, dx, ldx, acc));
-        if (op == 2) HC_LOOP(1, divcurlnorm_T<1>(t, groups, coef, tptr, tedge, k, dy, ldy, v, ldv, dx, ldx, acc));
-        if (op == 3) HC_LOOP(1, hodge_T<1>(t, groups, coef, tptr, tedge, k, dy, ldy, dx, ldx, acc));
+        if (op == 0) HC_T(1, (GradT<1>{dy, ldy, dx, ldx, acc, C}));
+        if (op == 1) HC_T(1, (DivT<1>{dy, ldy, dx, ldx, acc, C}));
+        if (op == 2) HC_T(1, (DivCurlNormT<1>{dy, ldy, v, ldv, dx, ldx, acc, C}));
+        if (op == 3) HC_T(1, (HodgeT<1>{dy, ldy, dx, ldx, acc, C}));
     }
 }
 
 void hc_knn_max(int V, const int* nbr, int n, int k, const float* h, int C, long ldh, float* out, long ldo,
                 unsigned char* arg) {
     using namespace dcell;
-    if (V == 4) HC_LOOP(4, knn_max_fwd<4>(t, groups, nbr, k, h, ldh, out, ldo, arg, C));
-    else HC_LOOP(1, knn_max_fwd<1>(t, groups, nbr, k, h, ldh, out, ldo, arg, C));
+    for (long i = 0; i < n; ++i)
+        for (int c0 = 0; c0 < C; c0 += V) {
+            if (V == 4) knn_max_fwd<4>(i, c0, nbr + i * k, k, h, ldh, out, ldo, arg, C);
+            else knn_max_fwd<1>(i, c0, nbr + i * k, k, h, ldh, out, ldo, arg, C);
+        }
 }
 
 void hc_knn_max_bwd(int V, const int* tptr, const int* tedge, int n, int k, const unsigned char* arg,
                     const float* dout, int C, long ldo, float* dh, long ldh, int acc) {
     using namespace dcell;
-    if (V == 4) HC_LOOP(4, knn_max_bwd<4>(t, groups, tptr, tedge, k, arg, C, dout, ldo, dh, ldh, acc));
-    else HC_LOOP(1, knn_max_bwd<1>(t, groups, tptr, tedge, k, arg, C, dout, ldo, dh, ldh, acc));
+    for (long j = 0; j < n; ++j)
+        for (int c0 = 0; c0 < C; c0 += V) {
+            if (V == 4) walk_column(KnnMaxT<4>{arg, (long)C, dout, ldo, dh, ldh, acc, C}, j, c0, nullptr, tptr, tedge, k);
+            else walk_column(KnnMaxT<1>{arg, (long)C, dout, ldo, dh, ldh, acc, C}, j, c0, nullptr, tptr, tedge, k);
+        }
 }
 
 // ---- fused BN / activation / vector non-linearity: serial loops over the formulas of nn_math.h ----

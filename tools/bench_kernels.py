@@ -62,10 +62,10 @@ def main():
         graph.csc()
     rec("csc_build", timeit(csc, 20, 3), 12 * E)
     tptr, tedge = graph.csc()
-    for remap, ub in ((1, 0), (1, 1), (1, 2), (0, 0)):
+    GT, DT = grad.coefT(), div.coefT()
+    for remap in (1, 0):
         lib.raw("dc_set_option")(0, remap)
-        lib.raw("dc_set_option")(1, ub)
-        for C in (a.channels if (remap, ub) == (1, 0) else a.channels[:1]):
+        for C in (a.channels if remap else a.channels[:1]):
             x = torch.randn(n, C, device=dev)
             v = torch.randn(2 * n, C, device=dev)
             dcn = torch.randn(n, 3 * C, device=dev)
@@ -74,7 +74,7 @@ def main():
             y3 = torch.empty(n, 3 * C, device=dev)
             arg = torch.empty(n, C, dtype=torch.uint8, device=dev)
             ab = 12 * C * n + 12 * E
-            kw = dict(C=C, remap=remap, ub=ub)
+            kw = dict(C=C, remap=remap)
             call = lib.call
             rec("apply_grad", timeit(lambda: call("dc_apply_grad", grad.coef, graph.nbr, n, k, x, C, C, y2, C)), ab, **kw)
             rec("apply_div", timeit(lambda: call("dc_apply_div", div.coef, graph.nbr, n, k, v, C, C, y1, C)), ab, **kw)
@@ -82,13 +82,13 @@ def main():
                 20 * C * n + 12 * E, **kw)
             rec("apply_hodge", timeit(lambda: call("dc_apply_hodge", grad.coef, graph.nbr, n, k, dcn, C, 3 * C, y2, C)),
                 16 * C * n + 12 * E, **kw)
-            rec("apply_grad_T", timeit(lambda: call("dc_apply_grad_T", grad.coef, tptr, tedge, n, k, y2, C, C, y1, C, 0)),
+            rec("apply_grad_T", timeit(lambda: call("dc_apply_grad_T", GT, tptr, tedge, n, k, y2, C, C, y1, C, 0)),
                 12 * C * n + 16 * E, **kw)
-            rec("apply_div_T", timeit(lambda: call("dc_apply_div_T", div.coef, tptr, tedge, n, k, y1, C, C, y2, C, 0)),
+            rec("apply_div_T", timeit(lambda: call("dc_apply_div_T", DT, tptr, tedge, n, k, y1, C, C, y2, C, 0)),
                 12 * C * n + 16 * E, **kw)
-            rec("apply_div_curl_norm_T", timeit(lambda: call("dc_apply_div_curl_norm_T", div.coef, tptr, tedge, n, k, y3, C, 3 * C, v, C, y2, C, 0)),
+            rec("apply_div_curl_norm_T", timeit(lambda: call("dc_apply_div_curl_norm_T", DT, tptr, tedge, n, k, y3, C, 3 * C, v, C, y2, C, 0)),
                 28 * C * n + 16 * E, **kw)
-            rec("apply_hodge_T", timeit(lambda: call("dc_apply_hodge_T", grad.coef, tptr, tedge, n, k, y2, C, C, dcn, 3 * C, 0)),
+            rec("apply_hodge_T", timeit(lambda: call("dc_apply_hodge_T", GT, tptr, tedge, n, k, y2, C, C, dcn, 3 * C, 0)),
                 16 * C * n + 16 * E, **kw)
             rec("knn_max", timeit(lambda: call("dc_knn_max", graph.nbr, n, k, x, C, C, y1, C, arg)), 9 * C * n + 4 * E, **kw)
             rec("knn_max_backward", timeit(lambda: call("dc_knn_max_backward", tptr, tedge, n, k, arg, y1, C, C, x, C, 0)),
@@ -107,7 +107,6 @@ def main():
             gy = torch.randn_like(yg)
             rec("fused bn_act bwd [Nt,C]", timeit(lambda: torch.autograd.grad(yg, xg, gy, retain_graph=True)), 20 * C * n, **kw)
     lib.raw("dc_set_option")(0, 1)
-    lib.raw("dc_set_option")(1, 0)
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
 
