@@ -37,16 +37,33 @@ def parse():
     return ap.parse_args()
 
 
-def apply_roofline(model_graph, grad, div, C, iters=200):
-    """Live measurement of the dominant kernel family (ELL operator apply) with HIP events on the
-    stream the kernels are launched on.  Algorithmic bytes per apply:
-    12*C*Nt + 12*E (input once, output once, ids + coefficients once)."""
-    n, k = model_graph.n, model_graph.k
+def apply_roofline(graph, grad, div, C, iters=200):
+    """Live measurement of the dominant kernel family -- the ELL operator applies -- with HIP events on
+    the stream the kernels are launched on (torch's current stream; the C ABI launches there).
+    Algorithmic bytes per launch: input once + output once +
+    ids/coefficients once:  grad/div 12*C*Nt + 12*E,  div|curl|norm 20*C*Nt + 12*E,  hodge 16*C*Nt + 12*E.
+    The headline kernel is the fused div|curl|norm apply (largest forward apply of every DeltaConv
+    layer); the other members of the family are listed beside it."""
+    from deltaconv_amd._lib import lib
+    n, k = graph.n, graph.k
     dev = grad.coef.device
+    E = n * k
     x = torch.randn(n, C, device=dev)
     v = torch.randn(2 * n, C, device=dev)
-    res = {}
-    for name, fn in (("grad", lambda: grad @ x), ("div", lambda: div @ v)):
+    dcn = torch.randn(n, 3 * C, device=dev)
+    y1 = torch.empty(n, C, device=dev)
+    y2 = torch.empty(2 * n, C, device=dev)
+    y3 = torch.empty(n, 3 * C, device=dev)
+    cases = {
+        "div_curl_norm": (lambda: lib.call("dc_apply_div_curl_norm", div.coef, graph.nbr, n, k, v, C, C, y3, 3 * C),
+                          20 * C * n + 12 * E),
+        "grad": (lambda: lib.call("dc_apply_grad", grad.coef, graph.nbr, n, k, x, C, C, y2, C), 12 * C * n + 12 * E),
+        "div": (lambda: lib.call("dc_apply_div", div.coef, graph.nbr, n, k, v, C, C, y1, C), 12 * C * n + 12 * E),
+        "hodge": (lambda: lib.call("dc_apply_hodge", grad.coef, graph.nbr, n, k, dcn, C, 3 * C, y2, C),
+                  16 * C * n + 12 * E),
+    }
+    fam = {}
+    for name, (fn, nbytes) in cases.items():
         for _ in range(10):
             fn()
         torch.cuda.synchronize()
@@ -56,13 +73,13 @@ def apply_roofline(model_graph, grad, div, C, iters=200):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters * 1e-3      # seconds per launch
-    nbytes = 12 * C * n + 12 * n * k
-    t = 0.5 * (res["grad"] + res["div"])
-    return dict(bound="hbm", achieved=nbytes / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=nbytes / t / 1e9 / HBM_PEAK_GBS, traffic=None,
-                kernel="dc_apply_grad/dc_apply_div (ELL SpMM)", channels=C,
-                bytes_per_launch=nbytes, us_per_launch=dict(grad=res["grad"] * 1e6, div=res["div"] * 1e6))
+        t = e0.elapsed_time(e1) / iters * 1e-3
+        fam[name] = dict(us=round(t * 1e6, 2), bytes=nbytes, GBs=round(nbytes / t / 1e9, 1),
+                         frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4))
+    head = fam["div_curl_norm"]
+    return dict(bound="hbm", achieved=head["GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=head["frac"],
+                traffic=None, kernel="divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)", channels=C,
+                bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam)
 
 
 def cpu_baseline(args):

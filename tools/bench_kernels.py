@@ -36,9 +36,22 @@ def main():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--channels", type=int, nargs="+", default=[64, 128, 256])
     ap.add_argument("--json", default=None)
+    ap.add_argument("--sorted", action="store_true", help="Morton-sort the points of every cloud first")
     a = ap.parse_args()
     dev = "cuda"
-    b = synthetic_batch(a.batch, a.points, seed=7).to(dev)
+    b = synthetic_batch(a.batch, a.points, seed=7)
+    if a.sorted:
+        q = ((b.pos.clamp(-1, 1) * 0.5 + 0.5) * 1023).long()
+
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        perm = torch.sort((b.batch << 32) | code, stable=True).indices
+        b.pos, b.norm = b.pos[perm].contiguous(), b.norm[perm].contiguous()
+    b = b.to(dev)
     rows = []
 
     def rec(name, us, nbytes, **kw):
