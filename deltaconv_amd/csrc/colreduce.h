@@ -63,40 +63,60 @@ __global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int 
     }
 }
 
-// sums[q*C + col] = sum over chunks: one wave per (q, col), lanes stride the chunks, butterfly
-// reduce -> the association is fixed by the structure (bit-reproducible).
-__global__ __launch_bounds__(64) void colreduce_final_kernel(const double* __restrict__ partial, int chunks,
-                                                             double* __restrict__ sums) {
-    const double* p = partial + (long)blockIdx.x * chunks;
-    double s = 0;
-    for (int ch = threadIdx.x; ch < chunks; ch += 64) s += p[ch];
-    s = dc_wave_sum(s);
-    if (threadIdx.x == 0) sums[blockIdx.x] = s;
+// Final stage: one wave per column, lanes stride the chunks of both quantities, butterfly reduce
+// (association fixed by the structure -> bit-reproducible), then lane 0 runs the finaliser FIN
+// (statistics -> scale/shift + running statistics, or backward sums -> dgamma/dbeta/means) --
+// no separate finalize launch.
+template <class FIN>
+__global__ __launch_bounds__(64) void colreduce_final_kernel(const double* __restrict__ partial, int chunks, int C,
+                                                             FIN fin) {
+    const int col = blockIdx.x;
+    const double* p0 = partial + (long)col * chunks;
+    const double* p1 = partial + ((long)C + col) * chunks;
+    double s0 = 0, s1 = 0;
+    for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+        s0 += p0[ch];
+        s1 += p1[ch];
+    }
+    s0 = dc_wave_sum(s0);
+    s1 = dc_wave_sum(s1);
+    if (threadIdx.x == 0) fin(col, s0, s1);
 }
 
-// ---- finalize: batch statistics -> scale/shift (+ running statistics) -------------------------
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, long R, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double m = sums[c] / (double)R;
-    double var = sums[C + c] / (double)R - m * m;  // biased (normalisation)
-    if (var < 0) var = 0;
-    const double is = 1.0 / sqrt(var + (double)eps);
-    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-    mean[c] = (float)m;
-    invstd[c] = (float)is;
-    scale[c] = (float)(g * is);
-    shift[c] = (float)(b - m * g * is);
-    if (running_mean) {  // nn.BatchNorm1d: unbiased variance into the running estimate
-        const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+// batch statistics -> mean/invstd/scale/shift (+ running statistics, unbiased variance)
+struct BnFin {
+    long R; const float *gamma, *beta; float eps, momentum; float *running_mean, *running_var;
+    float *mean, *invstd, *scale, *shift;
+    __device__ void operator()(int c, double s0, double s1) const {
+        const double m = s0 / (double)R;
+        double var = s1 / (double)R - m * m;  // biased (normalisation)
+        if (var < 0) var = 0;
+        const double is = 1.0 / sqrt(var + (double)eps);
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        mean[c] = (float)m;
+        invstd[c] = (float)is;
+        scale[c] = (float)(g * is);
+        shift[c] = (float)(b - m * g * is);
+        if (running_mean) {
+            const double unb = R > 1 ? var * (double)R / (double)(R - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
     }
-}
+};
+// backward sums: dgamma = sum dz*xhat, dbeta = sum dz; per-column means for the apply pass
+struct BwdFin {
+    long R; float *dgamma, *dbeta, *m1, *m2;
+    __device__ void operator()(int c, double s0, double s1) const {
+        if (dbeta) dbeta[c] = (float)s0;
+        if (dgamma) dgamma[c] = (float)s1;
+        m1[c] = (float)(s0 / (double)R);
+        m2[c] = (float)(s1 / (double)R);
+    }
+};
+struct NoFin {
+    __device__ void operator()(int, double, double) const {}
+};
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                       float eps, int C, float* mean, float* invstd, float* scale, float* shift) {
@@ -108,17 +128,6 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     invstd[c] = is;
     scale[c] = g * is;
     shift[c] = b - rm[c] * g * is;
-}
-
-// dgamma = sum dz*xhat, dbeta = sum dz; also the per-column means the apply pass needs
-__global__ void bwd_finalize_kernel(const double* __restrict__ sums, long R, int C, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, float* __restrict__ m1, float* __restrict__ m2) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    if (dbeta) dbeta[c] = (float)sums[c];
-    if (dgamma) dgamma[c] = (float)sums[C + c];
-    m1[c] = (float)(sums[c] / (double)R);
-    m2[c] = (float)(sums[C + c] / (double)R);
 }
 
 // ---- host helpers --------------------------------------------------------------------------
@@ -139,11 +148,11 @@ inline Ws carve(void* ws, long R, int C) {
     return w;
 }
 
-template <int V, class F>
-void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s) {
+template <int V, class F, class FIN>
+void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s, FIN fin) {
     dim3 grid(chunks_of(R), dc_cdiv(C, CT * V));
     hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, chunks_of(R), w.partial);
-    hipLaunchKernelGGL(colreduce_final_kernel, dim3(2 * C), dim3(64), 0, s, w.partial, chunks_of(R), w.sums);
+    hipLaunchKernelGGL((colreduce_final_kernel<FIN>), dim3(C), dim3(64), 0, s, w.partial, chunks_of(R), C, fin);
 }
 
 

@@ -96,13 +96,15 @@ DC_EXPORT int dc_edge_gather_stats(const float* y, int64_t ldy, const int32_t* n
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, n, C);
-    if (C % 4 == 0 && ldy % 4 == 0 && al16(y))
-        run_colreduce<4>(EdgeStatsF<4>{y, (long)ldy, nbr, k, amax, amin, argmax, argmin, s1pt, (long)C, (long)C}, n, C, w, s);
-    else
-        run_colreduce<1>(EdgeStatsF<1>{y, (long)ldy, nbr, k, amax, amin, argmax, argmin, s1pt, (long)C, (long)C}, n, C, w, s);
-    if (compute_stats)
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)n * k, C, gamma, beta,
-                           eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+    const bool v4 = C % 4 == 0 && ldy % 4 == 0 && al16(y);
+    const EdgeStatsF<4> f4{y, (long)ldy, nbr, k, amax, amin, argmax, argmin, s1pt, (long)C, (long)C};
+    const EdgeStatsF<1> f1{y, (long)ldy, nbr, k, amax, amin, argmax, argmin, s1pt, (long)C, (long)C};
+    if (compute_stats) {   // statistics over all E = n*k edges
+        const BnFin fin{(long)n * k, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+        if (v4) run_colreduce<4>(f4, n, C, w, s, fin); else run_colreduce<1>(f1, n, C, w, s, fin);
+    } else {
+        if (v4) run_colreduce<4>(f4, n, C, w, s, NoFin{}); else run_colreduce<1>(f1, n, C, w, s, NoFin{});
+    }
     DC_CHECK_LAUNCH("dc_edge_gather_stats");
     return DC_OK;
 }
@@ -143,13 +145,11 @@ DC_EXPORT int dc_edge_max_backward(const float* dout, int64_t lddo, const float*
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, n, C);
     const bool v4 = C % 4 == 0 && lddo % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && al16(dout) && al16(y) && al16(dy);
+    const BwdFin fin{(long)n * k, dgamma, dbeta, w.m1, w.m2};   // m1, m2 are means over all E edges
     if (v4)
-        run_colreduce<4>(EdgeBwdF<4>{dout, amax, amin, scale, shift, mean, invstd, (long)lddo, (long)C, slope, dzs}, n, C, w, s);
+        run_colreduce<4>(EdgeBwdF<4>{dout, amax, amin, scale, shift, mean, invstd, (long)lddo, (long)C, slope, dzs}, n, C, w, s, fin);
     else
-        run_colreduce<1>(EdgeBwdF<1>{dout, amax, amin, scale, shift, mean, invstd, (long)lddo, (long)C, slope, dzs}, n, C, w, s);
-    // m1, m2 are means over all E edges
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)n * k, C, dgamma, dbeta,
-                       w.m1, w.m2);
+        run_colreduce<1>(EdgeBwdF<1>{dout, amax, amin, scale, shift, mean, invstd, (long)lddo, (long)C, slope, dzs}, n, C, w, s, fin);
     const int remap = dc_option(DC_OPT_XCD_REMAP);
     if (v4) {
         const long total = (long)n * (C / 4);

@@ -214,12 +214,11 @@ DC_EXPORT int dc_bn_stats(const float* h, int64_t R, int32_t C, int64_t ldh, con
     DC_WS_CHECK("dc_bn_stats", R, C)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, R, C);
+    const BnFin fin{(long)R, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
     if (C % 4 == 0 && ldh % 4 == 0 && al16(h))
-        run_colreduce<4>(StatsF<4>{h, (long)ldh}, R, C, w, s);
+        run_colreduce<4>(StatsF<4>{h, (long)ldh}, R, C, w, s, fin);
     else
-        run_colreduce<1>(StatsF<1>{h, (long)ldh}, R, C, w, s);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)R, C, gamma, beta, eps,
-                       momentum, running_mean, running_var, mean, invstd, scale, shift);
+        run_colreduce<1>(StatsF<1>{h, (long)ldh}, R, C, w, s, fin);
     DC_CHECK_LAUNCH("dc_bn_stats");
     return DC_OK;
 }
@@ -267,12 +266,11 @@ DC_EXPORT int dc_bn_act_backward(const float* dy, int64_t lddy, const float* h, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, R, C);
     const bool v4 = C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && lddh % 4 == 0 && al16(dy) && al16(h) && al16(dh);
+    const BwdFin fin{(long)R, dgamma, dbeta, w.m1, w.m2};
     if (v4)
-        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s);
+        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
     else
-        run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s);
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(dc_cdiv(C, 256)), dim3(256), 0, s, w.sums, (long)R, C, dgamma, dbeta, w.m1,
-                       w.m2);
+        run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
     if (v4)
         hipLaunchKernelGGL(bn_act_bwd_kernel<4>, dim3(stream_grid(R * (C / 4))), dim3(256), 0, s, dy, (long)lddy, h,
                            (long)ldh, (long)R, C / 4, scale, shift, mean, invstd, gamma, slope, training, w.m1, w.m2, dh,
@@ -296,12 +294,11 @@ DC_EXPORT int dc_vn_stats(const float* in, int64_t n, int32_t co, int64_t ld, in
     DC_WS_CHECK("dc_vn_stats", n, co)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, n, co);
+    const BnFin fin{(long)n, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
     if (co % 4 == 0 && ld % 4 == 0 && al16(in))
-        run_colreduce<4>(VnStatsF<4>{in, (long)ld, co, combine}, n, co, w, s);
+        run_colreduce<4>(VnStatsF<4>{in, (long)ld, co, combine}, n, co, w, s, fin);
     else
-        run_colreduce<1>(VnStatsF<1>{in, (long)ld, co, combine}, n, co, w, s);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(dc_cdiv(co, 256)), dim3(256), 0, s, w.sums, (long)n, co, gamma, beta, eps,
-                       momentum, running_mean, running_var, mean, invstd, scale, shift);
+        run_colreduce<1>(VnStatsF<1>{in, (long)ld, co, combine}, n, co, w, s, fin);
     DC_CHECK_LAUNCH("dc_vn_stats");
     return DC_OK;
 }
@@ -335,12 +332,11 @@ DC_EXPORT int dc_vn_backward(const float* dout, int64_t lddo, const float* in, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, n, co);
     const bool v4 = co % 4 == 0 && ld % 4 == 0 && lddo % 4 == 0 && lddi % 4 == 0 && al16(in) && al16(dout) && al16(din);
+    const BwdFin fin{(long)n, dgamma, dbeta, w.m1, w.m2};
     if (v4)
-        run_colreduce<4>(VnBwdF<4>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s);
+        run_colreduce<4>(VnBwdF<4>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s, fin);
     else
-        run_colreduce<1>(VnBwdF<1>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s);
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3(dc_cdiv(co, 256)), dim3(256), 0, s, w.sums, (long)n, co, dgamma, dbeta,
-                       w.m1, w.m2);
+        run_colreduce<1>(VnBwdF<1>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s, fin);
     if (v4)
         hipLaunchKernelGGL(vn_bwd_kernel<4>, dim3(stream_grid(n * (co / 4))), dim3(256), 0, s, in, (long)ld, combine, dout,
                            (long)lddo, (long)n, co / 4, scale, shift, mean, invstd, gamma, training, w.m1, w.m2, din,

@@ -4,7 +4,7 @@ from torch.nn import Sequential as Seq, Dropout, Linear
 
 from .deltanet_base import DeltaNetBase, _ptr_info
 from .pool import global_max_pool, global_mean_pool
-from ..nn import MLP
+from ..nn import MLP, fused
 
 
 class DeltaNetClassification(torch.nn.Module):
@@ -19,6 +19,10 @@ class DeltaNetClassification(torch.nn.Module):
             Linear(256, num_classes))
 
     def forward(self, data):
+        with fused.defer_counters():
+            return self._forward(data)
+
+    def _forward(self, data):
         conv_out = self.deltanet_base(data)
         x = self.lin_embedding(torch.cat(conv_out, dim=1))
         info = _ptr_info(data)

@@ -4,7 +4,7 @@ from torch.nn import Sequential as Seq, Dropout, LeakyReLU, Linear
 
 from .deltanet_base import DeltaNetBase, _ptr_info
 from .pool import global_max_pool
-from ..nn import MLP
+from ..nn import MLP, fused
 
 
 class DeltaNetSegmentation(torch.nn.Module):
@@ -24,6 +24,10 @@ class DeltaNetSegmentation(torch.nn.Module):
             Linear(256, 128), LeakyReLU(negative_slope=0.2), Linear(128, num_classes))
 
     def forward(self, data):
+        with fused.defer_counters():
+            return self._forward(data)
+
+    def _forward(self, data):
         conv_out = self.deltanet_base(data)
         x = self.lin_global(torch.cat(conv_out, dim=1))
         batch = data.batch

@@ -7,8 +7,9 @@ instead of recomputing two applies (operators.py:40,43 vs deltaconv.py:57)."""
 import torch
 import torch.nn.functional as F
 
-from .mlp import MLP, VectorMLP, MLPBlock, run_mlp
+from .mlp import MLP, VectorMLP, MLPBlock, VectorBlock, run_mlp
 from . import fused
+from .layer import DeltaConvLayerFn, LayerCfg
 from .. import _ops
 from ..geometry.graph import as_graph
 
@@ -26,7 +27,43 @@ class DeltaConv(torch.nn.Module):
         self.s_mlp = MLP([in_channels * 4] + [out_channels] * depth)
         self.v_mlp = VectorMLP([in_channels * 4 + out_channels * 2] + [out_channels] * depth) if vector else None
 
+    fuse_layer = True   # one autograd node per layer (nn/layer.py) when the layer qualifies
+
+    def _fusable(self):
+        """depth-1 MLPs with BatchNorm, piecewise-linear activations, ReLU vector non-linearity, no bias."""
+        mlps = [self.s_mlp_max, self.s_mlp] + ([self.v_mlp] if self.v_mlp is not None else [])
+        if any(len(m) != 1 for m in mlps):
+            return None
+        bm, bs = self.s_mlp_max[0], self.s_mlp[0]
+        if not (isinstance(bm, MLPBlock) and isinstance(bs, MLPBlock)) or bm[0].bias is not None or bs[0].bias is not None:
+            return None
+        sm, ss = fused.slope_of(bm[2]), fused.slope_of(bs[2])
+        if sm is None or ss is None or (self.centralized and sm < 0):
+            return None
+        if self.v_mlp is not None:
+            bv = self.v_mlp[0]
+            if not isinstance(bv, VectorBlock) or bv[1].batchnorm is None or not isinstance(bv[1].nonlin, torch.nn.ReLU):
+                return None
+        return sm, ss
+
     def forward(self, x, v, grad, div, edge_index):
+        graph = as_graph(edge_index, grad.graph)
+        slopes = self._fusable() if self.fuse_layer else None
+        if slopes is None:
+            return self.forward_composed(x, v, grad, div, graph)
+        bm, bs = self.s_mlp_max[0], self.s_mlp[0]
+        bv = self.v_mlp[0] if self.v_mlp is not None else None
+        cfg = LayerCfg(graph, grad, div, bm[1].bn, bs[1].bn, bv[1].batchnorm.bn if bv is not None else None,
+                       self.centralized, slopes[0], slopes[1], bv is not None)
+        vb = bv[1].batchnorm.bn if bv is not None else None
+        x_new, v_new = DeltaConvLayerFn.apply(
+            x, v, bm[0].weight, bm[1].bn.weight, bm[1].bn.bias, bs[0].weight, bs[1].bn.weight, bs[1].bn.bias,
+            bv[0].weight if bv is not None else None, vb.weight if vb is not None else None,
+            vb.bias if vb is not None else None, cfg)
+        return x_new, (v_new if bv is not None else v)
+
+    def forward_composed(self, x, v, grad, div, edge_index):
+        """The same layer as a chain of small autograd nodes (any depth / activation)."""
         graph = as_graph(edge_index, grad.graph)
         n, k, ci = graph.n, graph.k, self.in_channels
 

@@ -18,6 +18,35 @@ def _ws(rows, c, device):
     return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device), nbytes
 
 
+_PENDING, _DEFER = [], [0]
+
+
+def bump_counter(bn):
+    """num_batches_tracked += 1; inside ``defer_counters()`` the increments of a whole forward pass
+    are applied by one multi-tensor launch instead of one tiny kernel per BatchNorm."""
+    if _DEFER[0] and bn.momentum is not None:
+        _PENDING.append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked.add_(1)
+
+
+def flush_counters():
+    if _PENDING:
+        torch._foreach_add_(_PENDING, 1)
+        _PENDING.clear()
+
+
+class defer_counters:
+    def __enter__(self):
+        _DEFER[0] += 1
+
+    def __exit__(self, *exc):
+        _DEFER[0] -= 1
+        if _DEFER[0] == 0:
+            flush_counters()
+        return False
+
+
 def slope_of(act):
     """negative slope of a piecewise-linear activation module, or None if it is something else."""
     if isinstance(act, torch.nn.LeakyReLU):
@@ -73,7 +102,7 @@ def bn_act(h, bn, slope, residual=None):
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     rm, rv = (bn.running_mean, bn.running_var) if (bn.training and bn.track_running_stats) or not use_batch else (None, None)
     if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
+        bump_counter(bn)
         if bn.momentum is None:
             mom = 1.0 / float(bn.num_batches_tracked)
     return _BNAct.apply(h, bn.weight, bn.bias, rm, rv, use_batch, mom, float(bn.eps), float(slope), residual)
@@ -133,7 +162,7 @@ def vector_nonlin(inp, combine, vn):
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     track = bn.training and bn.track_running_stats
     if track:
-        bn.num_batches_tracked.add_(1)
+        bump_counter(bn)
         if bn.momentum is None:
             mom = 1.0 / float(bn.num_batches_tracked)
     rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
@@ -191,7 +220,7 @@ def edge_max_bn(y, graph, bn, slope):
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     track = bn.training and bn.track_running_stats
     if track:
-        bn.num_batches_tracked.add_(1)
+        bump_counter(bn)
         if bn.momentum is None:
             mom = 1.0 / float(bn.num_batches_tracked)
     rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)

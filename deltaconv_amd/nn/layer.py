@@ -1,0 +1,222 @@
+"""One DeltaConv layer as a single autograd node with a hand-written backward.
+
+Same arithmetic as ``DeltaConv.forward_composed`` (reference: deltaconv/nn/deltaconv.py:44-70), but
+instead of ~25 small autograd nodes glued by ATen ``cat`` / ``add`` / ``copy`` kernels, the layer
+owns its buffers:
+
+* ``div v | curl v | |v|`` is written straight into columns [ci, 4ci) of the s_mlp operand,
+  ``hodge(v)`` and ``grad x'`` straight into columns [ci, 2ci+co) of the v_mlp operand (kernels take
+  leading dimensions) -- no ``torch.cat``;
+* in the backward pass every transposed apply accumulates in place (``accumulate=1``) into the
+  gradient buffer of the tensor it belongs to -- no autograd ``add`` kernels, no zero fills;
+* the residual ``x_max + s_mlp(...)`` is folded into the BatchNorm/LeakyReLU kernel.
+
+Dense GEMMs are library calls (tuned, see deltaconv_amd/tuning).  Used when every MLP of the layer
+has depth 1 and standard activations (all reference models except the depth-2 segmentation net,
+which takes the composed path).
+"""
+import torch
+
+from .._lib import lib
+from . import fused
+
+_F32 = torch.float32
+
+
+def _c(t):
+    return t if (t.dtype == _F32 and t.is_contiguous()) else t.contiguous().float()
+
+
+def _rows(t):
+    """(tensor, leading dimension) for a row-major matrix view whose rows may be strided."""
+    if t.dtype != _F32 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        t = t.contiguous().float()
+    return t, t.stride(0)
+
+
+class LayerCfg:
+    """Non-tensor state of one call: graph, operators, BatchNorm modules, flags."""
+
+    def __init__(self, graph, grad, div, bn_m, bn_s, bn_v, centralized, slope_m, slope_s, vector):
+        self.graph, self.grad, self.div = graph, grad, div
+        self.bn_m, self.bn_s, self.bn_v = bn_m, bn_s, bn_v
+        self.centralized, self.slope_m, self.slope_s, self.vector = centralized, slope_m, slope_s, vector
+
+
+def _bn_mode(bn):
+    """-> (use_batch_stats, momentum, running_mean, running_var) and bumps num_batches_tracked."""
+    use_batch = bn.training or bn.running_mean is None
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    track = bn.training and bn.track_running_stats
+    if track:
+        fused.bump_counter(bn)
+        if bn.momentum is None:
+            mom = 1.0 / float(bn.num_batches_tracked)
+    rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
+    return use_batch, mom, rm, rv
+
+
+def _bn_coeffs(h, rows, c, ld, bn, gamma, beta, dev, vn_combine=None):
+    """Batch (or running) statistics of h -> coef[4,c] = mean, invstd, scale, shift."""
+    use_batch, mom, rm, rv = _bn_mode(bn)
+    coef = torch.empty(4, c, dtype=_F32, device=dev)
+    if use_batch:
+        ws, nb = fused._ws(rows, c, dev)
+        if vn_combine is None:
+            lib.call("dc_bn_stats", h, rows, c, ld, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1],
+                     coef[2], coef[3], ws, nb)
+        else:
+            lib.call("dc_vn_stats", h, rows, c, ld, int(vn_combine), gamma, beta, float(bn.eps), mom, rm, rv,
+                     coef[0], coef[1], coef[2], coef[3], ws, nb)
+    else:
+        lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, float(bn.eps), c, coef[0], coef[1], coef[2], coef[3])
+    return coef, use_batch
+
+
+class DeltaConvLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, v, Wm, gm, bm, Ws, gs, bs, Wv, gv, bv, cfg):
+        g = cfg.graph
+        n, k = g.n, g.k
+        x, v = _c(x), _c(v)
+        dev = x.device
+        ci, co = x.shape[1], Wm.shape[0]
+        f32 = dict(dtype=_F32, device=dev)
+        call = lib.call
+        G, D = cfg.grad.coef, cfg.div.coef
+
+        # ---- scalar stream, max aggregation over the k neighbours (deltaconv.py:50-54)
+        x_max = torch.empty(n, co, **f32)
+        if cfg.centralized:
+            y0 = x @ Wm.t()
+            stat = torch.empty(3, n, co, **f32)
+            args = torch.empty(2, n, co, dtype=torch.uint8, device=dev)
+            use_m, mom, rm, rv = _bn_mode(cfg.bn_m)
+            coef_m = torch.empty(4, co, **f32)
+            ws, nb = fused._ws(n, co, dev)
+            if not use_m:
+                call("dc_bn_eval_coeffs", gm, bm, rm, rv, float(cfg.bn_m.eps), co, coef_m[0], coef_m[1], coef_m[2],
+                     coef_m[3])
+            call("dc_edge_gather_stats", y0, co, g.nbr, n, k, co, int(use_m), gm, bm, float(cfg.bn_m.eps), mom,
+                 rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
+                 coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)
+            call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], cfg.slope_m,
+                 x_max, co, None)
+            max_saved = (y0, stat, args)
+        else:
+            hm = x @ Wm.t()
+            coef_m, use_m = _bn_coeffs(hm, n, co, co, cfg.bn_m, gm, bm, dev)
+            ym = torch.empty(n, co, **f32)
+            call("dc_bn_act", hm, n, co, co, coef_m[2], coef_m[3], cfg.slope_m, None, co, ym, co)
+            arg = torch.empty(n, co, dtype=torch.uint8, device=dev)
+            call("dc_knn_max", g.nbr, n, k, ym, co, co, x_max, co, arg)
+            max_saved = (hm, arg)
+
+        # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)
+        x_cat = torch.empty(n, 4 * ci, **f32)
+        x_cat[:, :ci].copy_(x)
+        call("dc_apply_div_curl_norm", D, g.nbr, n, k, v, ci, ci, x_cat[:, ci:], 4 * ci)
+        hs = x_cat @ Ws.t()
+        coef_s, use_s = _bn_coeffs(hs, n, co, co, cfg.bn_s, gs, bs, dev)
+        x_new = torch.empty(n, co, **f32)
+        call("dc_bn_act", hs, n, co, co, coef_s[2], coef_s[3], cfg.slope_s, x_max, co, x_new, co)
+
+        # ---- vector stream: [v | hodge v | grad x'] and its 90-degree rotation -> v_mlp (deltaconv.py:64-68)
+        if cfg.vector:
+            K = 2 * ci + co
+            v_cat = torch.empty(2 * n, K, **f32)
+            v_cat[:, :ci].copy_(v)
+            call("dc_apply_hodge", G, g.nbr, n, k, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
+            call("dc_apply_grad", G, g.nbr, n, k, x_new, co, co, v_cat[:, 2 * ci:], K)
+            Wst = torch.cat([Wv[:, :K], Wv[:, K:]], dim=0)            # [2co, K]: the I_J fold (mlp.VectorBlock)
+            PQ = v_cat @ Wst.t()                                      # [2n, 2co] = [P | Q]
+            coef_v, use_v = _bn_coeffs(PQ, n, co, 2 * co, cfg.bn_v, gv, bv, dev, vn_combine=1)
+            v_new = torch.empty(2 * n, co, **f32)
+            call("dc_vn_apply", PQ, n, co, 2 * co, 1, coef_v[2], coef_v[3], v_new, co)
+        else:
+            v_cat = PQ = coef_v = Wst = None
+            use_v = False
+            v_new = None                   # the caller passes v through untouched (deltaconv.py:64,70)
+
+        ctx.cfg = cfg
+        ctx.flags = (use_m, use_s, use_v, ci, co)
+        ctx.max_saved = max_saved
+        ctx.save_for_backward(x, v, Wm, gm, Ws, gs, Wst, gv, coef_m, x_cat, hs, coef_s, v_cat, PQ, coef_v)
+        return x_new, v_new
+
+    @staticmethod
+    def backward(ctx, dx_new, dv_new):
+        cfg = ctx.cfg
+        x, v, Wm, gm, Ws, gs, Wst, gv, coef_m, x_cat, hs, coef_s, v_cat, PQ, coef_v = ctx.saved_tensors
+        use_m, use_s, use_v, ci, co = ctx.flags
+        g = cfg.graph
+        n, k = g.n, g.k
+        dev = x.device
+        f32 = dict(dtype=_F32, device=dev)
+        call = lib.call
+        tptr, tedge = g.csc()
+        need_x, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dWv = dgv = dbv = None
+
+        dxn = _c(dx_new) if dx_new is not None else torch.zeros(n, co, **f32)
+        dv_cat = None
+        if cfg.vector and dv_new is not None:
+            K = 2 * ci + co
+            dvn, lddvn = _rows(dv_new)
+            dPQ = torch.empty_like(PQ)
+            dgv, dbv = torch.empty(co, **f32), torch.empty(co, **f32)
+            ws, nb = fused._ws(n, co, dev)
+            call("dc_vn_backward", dvn, lddvn, PQ, 2 * co, 1, n, co, coef_v[2], coef_v[3], coef_v[0], coef_v[1], gv,
+                 int(use_v), dPQ, 2 * co, dgv, dbv, ws, nb)
+            dWst = dPQ.t() @ v_cat                                    # [2co, K]
+            dWv = torch.cat([dWst[:co], dWst[co:]], dim=1)            # back to the [co, 2K] layout of v_mlp
+            dv_cat = dPQ @ Wst                                        # [2n, K]
+            # grad^T of the `grad @ x'` block accumulates into d x'
+            if dx_new is not None:
+                dxn = dxn.clone() if dxn.data_ptr() == dx_new.data_ptr() else dxn
+            call("dc_apply_grad_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, dxn, co, 1)
+
+        # ---- s_mlp block (residual: d x_max = d x')
+        dhs = torch.empty_like(hs)
+        dgs, dbs = torch.empty(co, **f32), torch.empty(co, **f32)
+        ws, nb = fused._ws(n, co, dev)
+        call("dc_bn_act_backward", dxn, co, hs, co, n, co, coef_s[2], coef_s[3], coef_s[0], coef_s[1], gs, cfg.slope_s,
+             int(use_s), dhs, co, dgs, dbs, ws, nb)
+        dWs = dhs.t() @ x_cat
+        d_xcat = dhs @ Ws                                             # [n, 4ci] = d[x | div | curl | norm]
+        if dv_cat is not None:   # hodge^T accumulates into d[div | curl]
+            call("dc_apply_hodge_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, ci:], ci, 2 * ci + co,
+                 d_xcat[:, ci:], 4 * ci, 1)
+        dv = None
+        if need_v:
+            if dv_cat is not None:          # accumulate on top of d v from the v_mlp operand, in place
+                dv = dv_cat[:, :ci]
+                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, ci,
+                     dv, 2 * ci + co, 1)
+            else:
+                dv = torch.empty(2 * n, ci, **f32)
+                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, ci,
+                     dv, ci, 0)
+
+        # ---- max-aggregation branch (d x_max = d x')
+        dgm, dbm = torch.empty(co, **f32), torch.empty(co, **f32)
+        ws, nb = fused._ws(n, co, dev)
+        if cfg.centralized:
+            y0, stat, args = ctx.max_saved
+            dzs, dy0 = torch.empty(n, co, **f32), torch.empty(n, co, **f32)
+            call("dc_edge_max_backward", dxn, co, y0, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
+                 stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slope_m, int(use_m), dzs, dy0, co, dgm, dbm,
+                 ws, nb)
+            dpre = dy0
+        else:
+            hm, arg = ctx.max_saved
+            dym = torch.empty(n, co, **f32)
+            call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, co, dym, co, 0)
+            dpre = torch.empty_like(hm)
+            call("dc_bn_act_backward", dym, co, hm, co, n, co, coef_m[2], coef_m[3], coef_m[0], coef_m[1], gm,
+                 cfg.slope_m, int(use_m), dpre, co, dgm, dbm, ws, nb)
+        dWm = dpre.t() @ x
+        dx = torch.addmm(d_xcat[:, :ci], dpre, Wm) if need_x else None
+        nz = lambda t, ref: t if ref is not None else None
+        return (dx, dv, dWm, nz(dgm, gm), nz(dbm, gm), dWs, nz(dgs, gs), nz(dbs, gs), dWv, nz(dgv, gv), nz(dbv, gv),
+                None)

@@ -181,3 +181,60 @@ def test_centralized_layer_vs_oracle(depth, train):
         for (n1, b1), (n2, b2) in zip(ours.named_buffers(), ref.named_buffers()):
             if b2.dtype.is_floating_point:
                 assert rel_err(b1, b2) < 1e-3, n1
+
+
+@pytest.mark.parametrize("centralized,vector,ci,co", [(True, True, 3, 32), (False, True, 32, 64), (False, False, 64, 64),
+                                                      (False, True, 6, 10)])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_layer_matches_composed(centralized, vector, ci, co, train):
+    """nn/layer.py (one autograd node, in-place accumulation, no cat) vs the chain of small nodes."""
+    import deltaconv_amd as dc
+    from deltaconv_amd.data import synthetic_batch
+    b = synthetic_batch(2, 512, seed=60).to(DEV)
+    graph = dc.geometry.Graph.knn(b.pos, 20, b.batch)
+    xb, yb = dc.geometry.build_tangent_basis(b.norm)
+    G, D = dc.geometry.build_grad_div(b.pos, b.norm, xb, yb, graph, b.batch)
+    torch.manual_seed(7)
+    conv = dc.nn.DeltaConv(ci, co, depth=1, centralized=centralized, vector=vector).to(DEV)
+    with torch.no_grad():
+        for n_, p_ in conv.named_parameters():
+            if n_.endswith("bn.weight"):
+                v_ = torch.linspace(0.4, 1.6, p_.numel(), device=DEV); v_[::5] *= -1
+                p_.copy_(v_)
+            if n_.endswith("bn.bias"):
+                p_.copy_(torch.linspace(-0.3, 0.3, p_.numel(), device=DEV))
+    conv.train(train)
+    assert conv._fusable() is not None
+    x0 = torch.randn(graph.n, ci, device=DEV)
+    v0 = torch.randn(2 * graph.n, ci, device=DEV)
+    res = []
+    sd0 = {k_: t.clone() for k_, t in conv.state_dict().items()}
+    for fuse in (True, False):
+        conv.load_state_dict(sd0)
+        conv.zero_grad()
+        conv.fuse_layer = fuse
+        x = x0.clone().requires_grad_(True)
+        v = v0.clone().requires_grad_(True)
+        xo, vo = conv(x, v, G, D, graph)
+        gen = torch.Generator(device=DEV).manual_seed(1)
+        loss = (xo * torch.randn(xo.shape, device=DEV, generator=gen)).sum() + \
+               (vo * torch.randn(vo.shape, device=DEV, generator=gen)).sum()
+        if train:
+            loss.backward()
+        res.append((xo.detach(), vo.detach(), x.grad, v.grad,
+                    {n_: (p_.grad.clone() if p_.grad is not None else None) for n_, p_ in conv.named_parameters()},
+                    {n_: b_.clone() for n_, b_ in conv.named_buffers()}))
+    (x1, v1, gx1, gv1, gp1, bf1), (x2, v2, gx2, gv2, gp2, bf2) = res
+    assert rel_err(x1, x2) < 1e-5 and rel_err(v1, v2) < 1e-5
+    if train:
+        assert rel_err(gx1, gx2) < 1e-4 and rel_err(gv1, gv2) < 1e-4
+        for n_ in gp1:
+            if gp2[n_] is None:
+                assert gp1[n_] is None, n_
+            else:
+                assert rel_err(gp1[n_], gp2[n_]) < 1e-4, n_
+    for n_ in bf1:
+        if bf1[n_].dtype.is_floating_point:
+            assert rel_err(bf1[n_], bf2[n_]) < 1e-5, n_
+        else:
+            assert int(bf1[n_]) == int(bf2[n_]), n_
