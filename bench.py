@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="library default GEMM heuristics")
+    ap.add_argument("--fresh-tuning", action="store_true", help="ignore shipped GEMM tuning results (tools/tune_gemm.sh)")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -134,8 +135,9 @@ def main():
     from deltaconv_amd.dp import FlatGradDataParallel
 
     if not args.no_tuned_gemm:
-        from deltaconv_amd.tuning import enable_tuned_gemms
-        enable_tuned_gemms()
+        if not args.fresh_tuning:                 # --fresh-tuning: TunableOp is driven by the environment
+            from deltaconv_amd.tuning import enable_tuned_gemms
+            enable_tuned_gemms()
     torch.manual_seed(1)
     model = dc.models.DeltaNetClassification(3, 40, num_neighbors=args.k).to(dev).train()
     ddp = FlatGradDataParallel(model)
