@@ -10,7 +10,6 @@ namespace {   // internal linkage: this header is included by several translatio
 
 constexpr int RT = 16;          // row lanes per block
 constexpr int CT = 16;          // column groups per block
-constexpr int ROWS_PER_CHUNK = 256;
 constexpr int TPB = RT * CT;    // 256
 
 template <int V>
@@ -25,12 +24,13 @@ __device__ __forceinline__ void stv(float* p, const FV<V>& a) { *reinterpret_cas
 // ---- generic ordered column reduction: NQ quantities per element ------------------------------
 // grid = (row_chunks, col_tiles); partial[(chunk*NQ + q)*C + col] (double)
 template <int V, int NQ, class F>
-__global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int chunks, double* __restrict__ partial) {
+__global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int chunks, int rpc,
+                                                        double* __restrict__ partial) {
     __shared__ double sm[NQ][RT][CT * V];
     const int cgl = threadIdx.x % CT, rl = threadIdx.x / CT;
     const int c0 = (blockIdx.y * CT + cgl) * V;
-    const long r0 = (long)blockIdx.x * ROWS_PER_CHUNK;
-    const long r1 = min(r0 + ROWS_PER_CHUNK, R);
+    const long r0 = (long)blockIdx.x * rpc;
+    const long r1 = min(r0 + rpc, R);
     double acc[NQ][V];   // fp64: sum x^2 - (sum x)^2 / R must survive cancellation (R can be 2)
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
@@ -132,8 +132,14 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // ---- host helpers --------------------------------------------------------------------------
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-inline int chunks_of(long R) { return (int)((R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK); }
-inline size_t ws_need(long R, int C) { return ((size_t)chunks_of(R) * 2 * C + 2 * (size_t)C) * 8 + 2 * (size_t)C * 4; }
+// rows per block: enough blocks (~1500) to fill 256 CUs even for narrow matrices; multiple of RT
+inline int rows_per_chunk(long R, int C) {
+    const long coltiles = (C + CT * 4 - 1) / (CT * 4);
+    long rpc = (R * coltiles / 1536 + RT - 1) / RT * RT;
+    return (int)std::min<long>(std::max<long>(rpc, RT), 512);
+}
+inline int chunks_of(long R, int C) { const int rpc = rows_per_chunk(R, C); return (int)((R + rpc - 1) / rpc); }
+inline size_t ws_need(long R, int C) { return ((size_t)chunks_of(R, C) * 2 * C + 2 * (size_t)C) * 8 + 2 * (size_t)C * 4; }
 inline int stream_grid(long total) { return (int)std::min<long>((total + 255) / 256, 256L * 16); }
 
 struct Ws {
@@ -142,7 +148,7 @@ struct Ws {
 inline Ws carve(void* ws, long R, int C) {
     Ws w;
     w.partial = static_cast<double*>(ws);
-    w.sums = w.partial + (size_t)chunks_of(R) * 2 * C;
+    w.sums = w.partial + (size_t)chunks_of(R, C) * 2 * C;
     w.m1 = reinterpret_cast<float*>(w.sums + 2 * (size_t)C);
     w.m2 = w.m1 + C;
     return w;
@@ -150,9 +156,10 @@ inline Ws carve(void* ws, long R, int C) {
 
 template <int V, class F, class FIN>
 void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s, FIN fin) {
-    dim3 grid(chunks_of(R), dc_cdiv(C, CT * V));
-    hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, chunks_of(R), w.partial);
-    hipLaunchKernelGGL((colreduce_final_kernel<FIN>), dim3(C), dim3(64), 0, s, w.partial, chunks_of(R), C, fin);
+    const int rpc = rows_per_chunk(R, C), chunks = chunks_of(R, C);
+    dim3 grid(chunks, dc_cdiv(C, CT * V));
+    hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, chunks, rpc, w.partial);
+    hipLaunchKernelGGL((colreduce_final_kernel<FIN>), dim3(C), dim3(64), 0, s, w.partial, chunks, C, fin);
 }
 
 

@@ -53,9 +53,17 @@ __global__ void csc_fill_kernel(const int* __restrict__ nbr, long ne, int* __res
     if (e < ne) tedge[atomicAdd(cursor + nbr[e], 1)] = (int)e;
 }
 
-__global__ void csc_sort_kernel(const int* __restrict__ tptr, int n, int* __restrict__ tedge) {
-    const int j = blockIdx.x * TPB + threadIdx.x;
-    if (j < n) dcell::sort_column(tedge, tptr[j], tptr[j + 1]);
+// Order every column by edge id without a serial sort: edge e counts the entries of its column that
+// are smaller (O(in-degree) reads, all E edges in parallel) and writes itself at that rank.
+__global__ void csc_rank_kernel(const int* __restrict__ nbr, long ne, const int* __restrict__ tptr,
+                                const int* __restrict__ unordered, int* __restrict__ tedge) {
+    const long e = (long)blockIdx.x * TPB + threadIdx.x;
+    if (e >= ne) return;
+    const int j = nbr[e];
+    const int lo = tptr[j], hi = tptr[j + 1];
+    int rank = 0;
+    for (int p = lo; p < hi; ++p) rank += unordered[p] < (int)e;
+    tedge[lo + rank] = (int)e;
 }
 __global__ void csc_permute_kernel(const float2* __restrict__ coef, const int* __restrict__ tedge, long ne,
                                    float2* __restrict__ coefT) {
@@ -77,7 +85,8 @@ DC_EXPORT int dc_csc_permute_coef(const float* coef, const int32_t* tedge, int64
     return DC_OK;
 }
 
-DC_EXPORT size_t dc_csc_workspace_bytes(int32_t num_points) { return (size_t)num_points * 4; }
+// workspace: fill cursors [Nt] + the unordered fill [Nt*k]  (k <= 255)
+DC_EXPORT size_t dc_csc_workspace_bytes(int32_t num_points) { return (size_t)num_points * 4 * 256; }
 
 DC_EXPORT int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
                            int32_t k, int32_t* tptr, int32_t* tedge, void* workspace, size_t workspace_bytes,
@@ -87,7 +96,7 @@ DC_EXPORT int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t
     DC_REQUIRE((long long)num_points * k < 2147483647LL, "dc_csc_build: edge ids overflow int32");
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (num_points == 0 || num_clouds == 0) return DC_OK;
-    if (!workspace || workspace_bytes < dc_csc_workspace_bytes(num_points)) {
+    if (!workspace || workspace_bytes < (size_t)num_points * 4 * ((size_t)k + 1)) {
         dc_set_error("dc_csc_build: workspace too small");
         return DC_ERR_WORKSPACE;
     }
@@ -99,8 +108,9 @@ DC_EXPORT int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t
     }
     hipLaunchKernelGGL(csc_count_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, cnt);
     hipLaunchKernelGGL(csc_scan_kernel, dim3(num_clouds), dim3(TPB), 0, s, cloud_ptr, k, num_clouds, cnt, tptr);
-    hipLaunchKernelGGL(csc_fill_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, cnt, tedge);
-    hipLaunchKernelGGL(csc_sort_kernel, dim3(dc_cdiv(num_points, TPB)), dim3(TPB), 0, s, tptr, num_points, tedge);
+    int* unordered = cnt + num_points;
+    hipLaunchKernelGGL(csc_fill_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, cnt, unordered);
+    hipLaunchKernelGGL(csc_rank_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, tptr, unordered, tedge);
     DC_CHECK_LAUNCH("dc_csc_build");
     return DC_OK;
 }

@@ -272,10 +272,19 @@ struct KnnMaxT {
     DC_HD void step(long i, int s, G2, int c0) {
         bool any = false;
         bool hit[V];
+        if (V == 4) {   // the four slot bytes in one 32-bit load (c0 and lda are multiples of 4)
+            const unsigned w = *reinterpret_cast<const unsigned*>(arg + i * lda + c0);
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-            hit[q] = arg[i * lda + c0 + q] == (unsigned char)s;
-            any = any || hit[q];
+            for (int q = 0; q < V; ++q) {
+                hit[q] = ((w >> (8 * q)) & 0xffu) == (unsigned)s;
+                any = any || hit[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                hit[q] = arg[i * lda + c0 + q] == (unsigned char)s;
+                any = any || hit[q];
+            }
         }
         if (any) {
             const Vec<V> g = vload<V>(dout + i * ldo + c0);

@@ -70,7 +70,7 @@ class Graph:
             dev = self.nbr.device
             tptr = torch.empty(self.n + 1, dtype=torch.int32, device=dev)
             tedge = torch.empty(self.n * self.k, dtype=torch.int32, device=dev)
-            ws = torch.empty(self.n, dtype=torch.int32, device=dev)
+            ws = torch.empty(self.n * (self.k + 1), dtype=torch.int32, device=dev)
             lib.call("dc_csc_build", self.nbr, self.ptr, self.num_clouds, self.n, self.k, tptr, tedge, ws,
                      ws.numel() * 4)
             self._csc = (tptr, tedge)

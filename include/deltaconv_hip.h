@@ -47,7 +47,7 @@ int dc_knn(const float* pos, const int32_t* cloud_ptr, int32_t num_clouds, int32
 
 /* Transposed adjacency of nbr (in-edges per point, ascending edge id).  Stands in for the A^T
  * products torch_sparse autograd performs and torch_scatter's arg-indexed backward. */
-size_t dc_csc_workspace_bytes(int32_t num_points);
+size_t dc_csc_workspace_bytes(int32_t num_points);   /* upper bound for any k <= 255; 4*Nt*(k+1) suffices */
 int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points, int32_t k,
                  int32_t* tptr /*[Nt+1]*/, int32_t* tedge /*[Nt*k]*/, void* workspace, size_t workspace_bytes,
                  void* stream);
