@@ -21,7 +21,7 @@ CONFIGS = {
     "C2_modelnet40": (32, 1024, 20, True, "cls", dict(in_channels=3, num_classes=40), {}),
     "C3_scanobjectnn": (32, 2048, 20, False, "cls",
                         dict(in_channels=3, num_classes=15, conv_channels=[64, 64, 64, 128], grad_regularizer=1e-2),
-                        dict(outlier_frac=0.05, jitter=0.005)),
+                        dict(outlier_frac=0.05, jitter=0.005, num_classes=15)),
     "C4_shapenet": (16, 2048, 20, True, "seg", dict(in_channels=3, num_classes=50, categorical_vector=True),
                     dict(dup_frac=0.03, per_point_labels=True, categories=16, num_classes=50)),
     "C5_shapeseg": (8, 4096, 30, True, "seg",
