@@ -78,8 +78,16 @@ def apply_roofline(graph, grad, div, C, iters=200):
         fam[name] = dict(us=round(t * 1e6, 2), bytes=nbytes, GBs=round(nbytes / t / 1e9, 1),
                          frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4))
     head = fam["div_curl_norm"]
+    traffic = None      # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc)
+    try:
+        import json as _json
+        pmc = _json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_divcurlnorm.json")))
+        if C == 64 and n == 32768 and k == 20:
+            traffic = pmc["traffic_bytes"]
+    except Exception:
+        pass
     return dict(bound="hbm", achieved=head["GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=head["frac"],
-                traffic=None, kernel="divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)", channels=C,
+                traffic=traffic, kernel="divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)", channels=C,
                 bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam)
 
 

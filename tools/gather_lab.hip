@@ -98,6 +98,37 @@ __global__ __launch_bounds__(1024) void k_slab(const unsigned short* nbrS, const
     }
 }
 
+
+// ---- D: block-local dedup: tile = 16 points x 64 channels; the UNIQUE neighbour rows of the tile are
+// staged into LDS once (coalesced 256-B rows through the TA), all k*16 gathers then read LDS rows
+// (a 16-lane group reads one aligned 256-B row = all 64 banks once: conflict-free ds_read_b128).
+__global__ __launch_bounds__(256) void k_dedup(const int* tile_ptr, const int* uniq, const unsigned short* loc,
+                                               const G2* coef, int k, const float* x, long ldx, float* out, long ldo,
+                                               int slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    F4* rows = (F4*)smem;  // [U][16]
+    const long b = xcd_block(1);
+    const long tile = b / slabs;
+    const int c0 = (int)(b % slabs) * 64;
+    const int u0 = tile_ptr[tile], U = tile_ptr[tile + 1] - u0;
+    const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    for (int r = grp; r < U; r += 16) rows[r * 16 + lane16] = *(const F4*)(x + (long)uniq[u0 + r] * ldx + c0 + lane16 * 4);
+    __syncthreads();
+    const long i = tile * 16 + grp;
+    const unsigned short* lp = loc + i * k;
+    const G2* cp = coef + i * k;
+    F4 au = {0, 0, 0, 0}, av = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int s = 0; s < k; ++s) {
+        const G2 g = cp[s];
+        const F4 xv = rows[(int)lp[s] * 16 + lane16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { au.v[q] = fmaf(g.a, xv.v[q], au.v[q]); av.v[q] = fmaf(g.b, xv.v[q], av.v[q]); }
+    }
+    *(F4*)(out + (2 * i) * ldo + c0 + lane16 * 4) = au;
+    *(F4*)(out + (2 * i + 1) * ldo + c0 + lane16 * 4) = av;
+}
+
 // ---- C: plain streaming copy of the same byte volume (in + out) for reference ------------------
 __global__ void k_copy(const F4* in, F4* out, long n_in, long n_out) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, st = (long)gridDim.x * blockDim.x;
@@ -216,6 +247,42 @@ int main(int argc, char** argv) {
                 double md = 0;
                 for (size_t i = 0; i < a.size(); ++i) md = std::max(md, (double)fabsf(a[i] - b2[i]));
                 printf("  slab-vs-staged max abs diff %.3g\n", md);
+            }
+
+            RUN_STAGED(4, 256, 1, 0, "staged U4 tpb256 remap (again)")
+            {   // block-dedup prototype (tile = 16 points)
+                const long tiles = Nt / 16;
+                std::vector<int> tptr(tiles + 1, 0), uq; std::vector<unsigned short> loc(E);
+                int umax = 0; double uavg = 0;
+                for (long t = 0; t < tiles; ++t) {
+                    std::vector<int> ids;
+                    for (long i = t * 16; i < t * 16 + 16; ++i) for (int s2 = 0; s2 < k; ++s2) ids.push_back(nbr[i * k + s2]);
+                    std::sort(ids.begin(), ids.end()); ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+                    for (long i = t * 16; i < t * 16 + 16; ++i) for (int s2 = 0; s2 < k; ++s2)
+                        loc[i * k + s2] = (unsigned short)(std::lower_bound(ids.begin(), ids.end(), nbr[i * k + s2]) - ids.begin());
+                    tptr[t + 1] = tptr[t] + (int)ids.size(); umax = std::max(umax, (int)ids.size()); uavg += ids.size();
+                    uq.insert(uq.end(), ids.begin(), ids.end());
+                }
+                int *d_tp, *d_uq; unsigned short* d_loc;
+                CK(hipMalloc(&d_tp, tptr.size() * 4)); CK(hipMalloc(&d_uq, uq.size() * 4)); CK(hipMalloc(&d_loc, E * 2));
+                CK(hipMemcpy(d_tp, tptr.data(), tptr.size() * 4, hipMemcpyHostToDevice));
+                CK(hipMemcpy(d_uq, uq.data(), uq.size() * 4, hipMemcpyHostToDevice));
+                CK(hipMemcpy(d_loc, loc.data(), E * 2, hipMemcpyHostToDevice));
+                const int slabs = C / 64;
+                const size_t ldsb = (size_t)umax * 256;
+                CK(hipFuncSetAttribute((const void*)k_dedup, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+                float us = timeit([&] {
+                    hipLaunchKernelGGL(k_dedup, dim3(tiles * slabs), dim3(256), ldsb, 0, d_tp, d_uq, d_loc, d_coef, k, d_x, (long)C,
+                                       d_out2, (long)C, slabs);
+                });
+                char lab[128]; snprintf(lab, sizeof lab, "block-dedup LDS (U avg %.0f max %d, %zu KB)", uavg / tiles, umax, ldsb / 1024);
+                printf("  %-44s %8.2f us  %7.1f GB/s\n", lab, us, mb / us * 1e3);
+                std::vector<float> a(2 * Nt * C), b2(2 * Nt * C);
+                CK(hipMemcpy(a.data(), d_out, a.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(b2.data(), d_out2, b2.size() * 4, hipMemcpyDeviceToHost));
+                double md = 0; for (size_t q = 0; q < a.size(); ++q) md = std::max(md, (double)fabsf(a[q] - b2[q]));
+                printf("  dedup-vs-staged max abs diff %.3g\n", md);
+                CK(hipFree(d_tp)); CK(hipFree(d_uq)); CK(hipFree(d_loc));
             }
             {
                 float us = timeit([&] {
