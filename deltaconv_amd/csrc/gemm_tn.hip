@@ -1,0 +1,172 @@
+// Tall-skinny transposed GEMM on the fp32 matrix cores:  C[M,N] = A^T B,  A [R,M], B [R,N], R >> M,N.
+//
+// This is the weight-gradient GEMM of every per-point Linear layer (dW = dY^T X with R = Nt or 2Nt
+// = 32768..65536 rows and M,N = 64..512 features): ATen/rocBLAS `mm` in the reference's autograd of
+// /root/reference/deltaconv/nn/mlp.py:9,15.  The vendor library reaches 27-98 TFLOP/s on these
+// shapes (tuned); the reduction dimension is the long one, so the work is split over row slabs.
+//
+// Mapping (CDNA4): v_mfma_f32_32x32x2_f32 takes A[i][k] and B[k][j] with lane l holding
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].  With both operands row-major over the SAME
+// row index r (= k), lane l simply loads A[r0 + (l>>5)][m0 + (l&31)] and B[r0 + (l>>5)][n0 + (l&31)]:
+// two coalesced 128-byte row segments per instruction, no LDS, no transposes.  A workgroup is
+// 4 waves in a 2x2 arrangement, each wave owns a 64x64 (or 32-wide at the edges) block of C in 4
+// independent 32x32 accumulators and streams its row slab with a software-pipelined (double
+// buffered) register prefetch of 8 k-steps.  Partials [slab][M][N] are then summed in slab order
+// by a second kernel: deterministic, no atomics.  Exact fp32 (the MFMA is an fmaf chain).
+// Bound: MFMA (157 TFLOP/s fp32 peak); operand traffic is 1 KB per 256 MFMA-cycles per wave.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int KU = 8;  // k-steps (of 2 rows) per pipeline stage
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
+                                                      const float* __restrict__ B, long ldb, long R, int M, int N,
+                                                      int tiles_n, int rows_per_slab, float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x, slab = blockIdx.y;
+    const int m0 = (tile / tiles_n) * (64 * WM) + (wave >> 1) * (32 * WM);
+    const int n0 = (tile % tiles_n) * (64 * WN) + (wave & 1) * (32 * WN);
+    if (m0 >= M || n0 >= N) return;  // wave-uniform
+    bool mv[WM], nv[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) mv[i] = m0 + 32 * i < M;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) nv[j] = n0 + 32 * j < N;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const long r_begin = (long)slab * rows_per_slab;
+    const long r_end = min(R, r_begin + rows_per_slab);
+    const int kh = lane >> 5, cl = lane & 31;
+
+    float a_cur[KU][WM], b_cur[KU][WN], a_nxt[KU][WM], b_nxt[KU][WN];
+    auto load_stage = [&](long r0, float (&a)[KU][WM], float (&b)[KU][WN]) {
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const long row = r0 + 2 * u + kh;
+            const bool ok = row < r_end;
+            const long rr = ok ? row : r_begin;  // clamped address, value zeroed below
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const float v = mv[i] ? A[rr * lda + m0 + 32 * i + cl] : 0.f;
+                a[u][i] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const float v = nv[j] ? B[rr * ldb + n0 + 32 * j + cl] : 0.f;
+                b[u][j] = ok ? v : 0.f;
+            }
+        }
+    };
+
+    load_stage(r_begin, a_cur, b_cur);
+    for (long r = r_begin; r < r_end; r += 2 * KU) {
+        const long rn = r + 2 * KU;
+        if (rn < r_end) load_stage(rn, a_nxt, b_nxt);  // prefetch the next stage under the MFMAs
+#pragma unroll
+        for (int u = 0; u < KU; ++u)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][i], b_cur[u][j], acc[i][j], 0, 0, 0);
+        if (rn < r_end) {
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a_cur[u][i] = a_nxt[u][i];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b_cur[u][j] = b_nxt[u][j];
+            }
+        }
+    }
+
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float* p = partial + (long)slab * M * N;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            if (!mv[i] || !nv[j]) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
+                p[(long)(m0 + 32 * i + row) * N + n0 + 32 * j + cl] = acc[i][j][q];
+            }
+        }
+}
+
+// C[m][n] = sum over slabs, in slab order (bit-reproducible)
+__global__ void gemm_tn_reduce_kernel(const float* __restrict__ partial, int slabs, long mn, int N, float* __restrict__ C,
+                                      long ldc, int accumulate) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= mn) return;
+    float s = 0.f;
+    for (int sl = 0; sl < slabs; ++sl) s += partial[(long)sl * mn + t];
+    float* dst = C + (t / N) * ldc + (t % N);
+    *dst = accumulate ? *dst + s : s;
+}
+
+struct Plan {
+    int wm, wn, tiles_m, tiles_n, slabs, rows_per_slab;
+};
+Plan make_plan(long R, int M, int N) {
+    Plan p;
+    p.wm = (M % 128 == 0 || M > 64) ? 2 : 1;
+    p.wn = (N % 128 == 0 || N > 64) ? 2 : 1;
+    p.tiles_m = dc_cdiv(M, 64 * p.wm);
+    p.tiles_n = dc_cdiv(N, 64 * p.wn);
+    const int tiles = p.tiles_m * p.tiles_n;
+    int slabs = std::max(1, 512 / tiles);                       // ~2 workgroups per CU
+    long rps = (R + slabs - 1) / slabs;
+    rps = std::max<long>((rps + 2 * KU - 1) / (2 * KU) * (2 * KU), 2 * KU * 4);
+    p.rows_per_slab = (int)rps;
+    p.slabs = (int)((R + rps - 1) / rps);
+    return p;
+}
+
+}  // namespace
+
+DC_EXPORT size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N) {
+    const Plan p = make_plan(R, M, N);
+    return (size_t)p.slabs * M * N * sizeof(float);
+}
+
+// C[M,N] (ldc) (+)= A^T B with A [R,M] (lda), B [R,N] (ldb); M and N multiples of 32.
+DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N,
+                         float* C, int64_t ldc, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    DC_REQUIRE(A && B && C, "dc_gemm_tn: null pointer");
+    DC_REQUIRE(R >= 1 && M >= 32 && N >= 32 && M % 32 == 0 && N % 32 == 0, "dc_gemm_tn: M, N must be multiples of 32");
+    DC_REQUIRE(lda >= M && ldb >= N && ldc >= N, "dc_gemm_tn: leading dimension smaller than the row");
+    if (!workspace || workspace_bytes < dc_gemm_tn_workspace_bytes(R, M, N)) {
+        dc_set_error("dc_gemm_tn: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    const Plan p = make_plan(R, M, N);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* partial = static_cast<float*>(workspace);
+    dim3 grid(p.tiles_m * p.tiles_n, p.slabs);
+#define DC_TN_LAUNCH(WM, WN)                                                                                       \
+    hipLaunchKernelGGL((gemm_tn_kernel<WM, WN>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, (long)R, M, N, \
+                       p.tiles_n, p.rows_per_slab, partial)
+    if (p.wm == 2 && p.wn == 2) DC_TN_LAUNCH(2, 2);
+    else if (p.wm == 2) DC_TN_LAUNCH(2, 1);
+    else if (p.wn == 2) DC_TN_LAUNCH(1, 2);
+    else DC_TN_LAUNCH(1, 1);
+    const long mn = (long)M * N;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 256)), dim3(256), 0, s, partial, p.slabs, mn, N, C, (long)ldc,
+                       accumulate);
+    DC_CHECK_LAUNCH("dc_gemm_tn");
+    return DC_OK;
+}

@@ -225,3 +225,21 @@ def edge_max_bn(y, graph, bn, slope):
             mom = 1.0 / float(bn.num_batches_tracked)
     rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
     return _EdgeMaxBN.apply(y, graph, bn.weight, bn.bias, rm, rv, use_batch, mom, float(bn.eps), float(slope))
+
+
+USE_MFMA_TN = True      # A/B switch: hand-written fp32-MFMA kernel for the tall-skinny weight gradients
+
+
+def gemm_tn(a, b):
+    """a.t() @ b for a [R,M], b [R,N] (weight gradient dW = dY^T X).  Tall-skinny problems go to the
+    hand-written fp32-MFMA split-K kernel (csrc/gemm_tn.hip); everything else to the library."""
+    r, m = a.shape
+    n = b.shape[1]
+    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m % 32 == 0 and n % 32 == 0 and m * n <= 256 * 512
+            and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
+        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+        nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, n)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
+        lib.call("dc_gemm_tn", a, a.stride(0), b, b.stride(0), r, m, n, out, n, 0, ws, ws.numel() * 4)
+        return out
+    return a.t() @ b

@@ -168,7 +168,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
             ws, nb = fused._ws(n, co, dev)
             call("dc_vn_backward", dvn, lddvn, PQ, 2 * co, 1, n, co, coef_v[2], coef_v[3], coef_v[0], coef_v[1], gv,
                  int(use_v), dPQ, 2 * co, dgv, dbv, ws, nb)
-            dWst = dPQ.t() @ v_cat                                    # [2co, K]
+            dWst = fused.gemm_tn(dPQ, v_cat)                                    # [2co, K]
             dWv = torch.cat([dWst[:co], dWst[co:]], dim=1)            # back to the [co, 2K] layout of v_mlp
             dv_cat = dPQ @ Wst                                        # [2n, K]
             # grad^T of the `grad @ x'` block accumulates into d x'
@@ -182,7 +182,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
         ws, nb = fused._ws(n, co, dev)
         call("dc_bn_act_backward", dxn, co, hs, co, n, co, coef_s[2], coef_s[3], coef_s[0], coef_s[1], gs, cfg.slope_s,
              int(use_s), dhs, co, dgs, dbs, ws, nb)
-        dWs = dhs.t() @ x_cat
+        dWs = fused.gemm_tn(dhs, x_cat)
         d_xcat = dhs @ Ws                                             # [n, 4ci] = d[x | div | curl | norm]
         if dv_cat is not None:   # hodge^T accumulates into d[div | curl]
             call("dc_apply_hodge_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, ci:], ci, 2 * ci + co,
@@ -215,7 +215,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
             dpre = torch.empty_like(hm)
             call("dc_bn_act_backward", dym, co, hm, co, n, co, coef_m[2], coef_m[3], coef_m[0], coef_m[1], gm,
                  cfg.slope_m, int(use_m), dpre, co, dgm, dbm, ws, nb)
-        dWm = dpre.t() @ x
+        dWm = fused.gemm_tn(dpre, x)
         dx = torch.addmm(d_xcat[:, :ci], dpre, Wm) if need_x else None
         nz = lambda t, ref: t if ref is not None else None
         return (dx, dv, dWm, nz(dgm, gm), nz(dbm, gm), dWs, nz(dgs, gs), nz(dbs, gs), dWv, nz(dgv, gv), nz(dbv, gv),

@@ -238,3 +238,24 @@ def test_fused_layer_matches_composed(centralized, vector, ci, co, train):
             assert rel_err(bf1[n_], bf2[n_]) < 1e-5, n_
         else:
             assert int(bf1[n_]) == int(bf2[n_]), n_
+
+
+@pytest.mark.parametrize("R,M,N", [(32768, 64, 64), (32768, 256, 128), (65536, 128, 192), (65536, 256, 256),
+                                   (32768, 256, 512), (10000, 96, 32), (8193, 32, 160)])
+def test_mfma_gemm_tn(R, M, N):
+    """Hand-written fp32-MFMA tall-skinny weight-gradient GEMM vs fp64 matmul (exact fp32 fma chain:
+    error of the fp32 class, ~1e-7 * sum|a b|), strided operands (column blocks of concat buffers),
+    bit-reproducible."""
+    from deltaconv_amd.nn import fused
+    torch.manual_seed(R % 97)
+    abig = torch.randn(R, M + 8, device=DEV)
+    bbig = torch.randn(R, N + 12, device=DEV)
+    a, b = abig[:, 4:4 + M], bbig[:, 8:8 + N]
+    assert fused.USE_MFMA_TN
+    c = fused.gemm_tn(a, b)
+    ref = a.double().t() @ b.double()
+    scale = float((a.abs().double().t() @ b.abs().double()).max())
+    assert float((c.double() - ref).abs().max()) < 2e-6 * scale
+    assert torch.equal(c, fused.gemm_tn(a, b))
+    lib_res = a.t() @ b
+    assert float((lib_res.double() - ref).abs().max()) < 1e-5 * scale   # the library is no closer

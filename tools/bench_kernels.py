@@ -120,6 +120,14 @@ def main():
             gy = torch.randn_like(yg)
             rec("fused bn_act bwd [Nt,C]", timeit(lambda: torch.autograd.grad(yg, xg, gy, retain_graph=True)), 20 * C * n, **kw)
     lib.raw("dc_set_option")(0, 1)
+    from deltaconv_amd.nn import fused
+    for (R, M, N) in ((32768, 64, 64), (32768, 64, 256), (32768, 128, 64), (32768, 128, 256), (32768, 256, 128),
+                      (32768, 256, 512), (65536, 128, 192), (65536, 256, 256)):
+        A, Bm = torch.randn(R, M, device=dev), torch.randn(R, N, device=dev)
+        t1 = timeit(lambda: fused.gemm_tn(A, Bm), 50, 5)
+        t2 = timeit(lambda: A.t() @ Bm, 50, 5)
+        rec(f"gemm_tn MFMA {R}x{M}x{N}", t1, 4 * R * (M + N), TF=round(2 * R * M * N / t1 / 1e6, 1))
+        rec(f"gemm_tn library {R}x{M}x{N}", t2, 4 * R * (M + N), TF=round(2 * R * M * N / t2 / 1e6, 1))
     if a.json:
         json.dump(rows, open(a.json, "w"), indent=1)
 
