@@ -20,7 +20,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int KU = 8;  // k-steps (of 2 rows) per pipeline stage
+constexpr int KU = 8;  // k-steps (of 2 rows) per pipeline stage 
 
 template <int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, long lda,
@@ -50,45 +50,62 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int kh = lane >> 5, cl = lane & 31;
 
     float a_cur[KU][WM], b_cur[KU][WN], a_nxt[KU][WM], b_nxt[KU][WN];
-    auto load_stage = [&](long r0, float (&a)[KU][WM], float (&b)[KU][WN]) {
+    // Branch-free loads: out-of-range 32-column blocks / rows are read from a clamped (valid) address
+    // and zeroed with a select, so the stage is a straight run of global_load_dword.
+    const float* ap[WM];
+    const float* bp[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) ap[i] = A + (mv[i] ? m0 + 32 * i : m0) + cl;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bp[j] = B + (nv[j] ? n0 + 32 * j : n0) + cl;
+    // Full stages: 2*KU valid rows, a straight run of unconditional loads (invalid 32-column blocks
+    // read a clamped valid column and their products are simply never stored).
+    auto load_full = [&](long r0, float (&a)[KU][WM], float (&b)[KU][WN]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const long row = r0 + 2 * u + kh;
-            const bool ok = row < r_end;
-            const long rr = ok ? row : r_begin;  // clamped address, value zeroed below
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                const float v = mv[i] ? A[rr * lda + m0 + 32 * i + cl] : 0.f;
-                a[u][i] = ok ? v : 0.f;
-            }
+            for (int i = 0; i < WM; ++i) a[u][i] = ap[i][row * lda];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const float v = nv[j] ? B[rr * ldb + n0 + 32 * j + cl] : 0.f;
-                b[u][j] = ok ? v : 0.f;
-            }
+            for (int j = 0; j < WN; ++j) b[u][j] = bp[j][row * ldb];
         }
     };
-
-    load_stage(r_begin, a_cur, b_cur);
-    for (long r = r_begin; r < r_end; r += 2 * KU) {
-        const long rn = r + 2 * KU;
-        if (rn < r_end) load_stage(rn, a_nxt, b_nxt);  // prefetch the next stage under the MFMAs
+    auto mfma_stage = [&](const float (&a)[KU][WM], const float (&b)[KU][WN]) {
 #pragma unroll
         for (int u = 0; u < KU; ++u)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[u][i], b_cur[u][j], acc[i][j], 0, 0, 0);
-        if (rn < r_end) {
-#pragma unroll
-            for (int u = 0; u < KU; ++u) {
-#pragma unroll
-                for (int i = 0; i < WM; ++i) a_cur[u][i] = a_nxt[u][i];
-#pragma unroll
-                for (int j = 0; j < WN; ++j) b_cur[u][j] = b_nxt[u][j];
-            }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+    };
+
+    // Ping-pong register buffers, loop unrolled by two stages: no register copies, so the MFMAs of
+    // stage s only wait for stage s while the loads of stage s+1 stay in flight (vmcnt = one stage).
+    const long full_end = r_begin + (r_end - r_begin) / (2 * KU) * (2 * KU);
+    const long S = 2 * KU;
+    if (r_begin < full_end) load_full(r_begin, a_cur, b_cur);
+    for (long r = r_begin; r < full_end; r += 2 * S) {
+        if (r + S < full_end) load_full(r + S, a_nxt, b_nxt);
+        mfma_stage(a_cur, b_cur);
+        if (r + S < full_end) {
+            if (r + 2 * S < full_end) load_full(r + 2 * S, a_cur, b_cur);
+            mfma_stage(a_nxt, b_nxt);
         }
+    }
+    if (full_end < r_end) {   // ragged tail of the slab: clamp the row, zero the value
+        const long last_row = r_end - 1;
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const long row = full_end + 2 * u + kh;
+            const bool ok = row <= last_row;
+            const long rr = ok ? row : last_row;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) { const float v = ap[i][rr * lda]; a_cur[u][i] = ok ? v : 0.f; }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) { const float v = bp[j][rr * ldb]; b_cur[u][j] = ok ? v : 0.f; }
+        }
+        mfma_stage(a_cur, b_cur);
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -106,15 +123,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
 }
 
-// C[m][n] = sum over slabs, in slab order (bit-reproducible)
-__global__ void gemm_tn_reduce_kernel(const float* __restrict__ partial, int slabs, long mn, int N, float* __restrict__ C,
-                                      long ldc, int accumulate) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= mn) return;
+// C[m][n] = sum over slabs.  Block = 16 waves x 64 consecutive elements: wave w sums slabs w, w+16, ...
+// (coalesced 256-B reads, all loads of a thread in flight), then the 16 partial sums are added in
+// wave order through LDS -- a fixed association, bit-reproducible.
+constexpr int RED_WAVES = 16;
+__global__ __launch_bounds__(64 * RED_WAVES) void gemm_tn_reduce_kernel(const float* __restrict__ partial, int slabs,
+                                                                        long mn, int N, float* __restrict__ C, long ldc,
+                                                                        int accumulate) {
+    __shared__ float sm[RED_WAVES][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int sl = 0; sl < slabs; ++sl) s += partial[(long)sl * mn + t];
-    float* dst = C + (t / N) * ldc + (t % N);
-    *dst = accumulate ? *dst + s : s;
+    if (e < mn) {
+#pragma unroll 8
+        for (int sl = w; sl < slabs; sl += RED_WAVES) s += partial[(long)sl * mn + e];
+    }
+    sm[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && e < mn) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < RED_WAVES; ++q) t += sm[q][lane];
+        float* dst = C + (e / N) * ldc + (e % N);
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 struct Plan {
@@ -127,7 +159,7 @@ Plan make_plan(long R, int M, int N) {
     p.tiles_m = dc_cdiv(M, 64 * p.wm);
     p.tiles_n = dc_cdiv(N, 64 * p.wn);
     const int tiles = p.tiles_m * p.tiles_n;
-    int slabs = std::max(1, 512 / tiles);                       // ~2 workgroups per CU
+    int slabs = std::min(128, std::max(1, 512 / tiles));        // ~2 workgroups per CU, bounded partial traffic
     long rps = (R + slabs - 1) / slabs;
     rps = std::max<long>((rps + 2 * KU - 1) / (2 * KU) * (2 * KU), 2 * KU * 4);
     p.rows_per_slab = (int)rps;
@@ -165,8 +197,8 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     else if (p.wn == 2) DC_TN_LAUNCH(1, 2);
     else DC_TN_LAUNCH(1, 1);
     const long mn = (long)M * N;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 256)), dim3(256), 0, s, partial, p.slabs, mn, N, C, (long)ldc,
-                       accumulate);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 64)), dim3(64 * RED_WAVES), 0, s, partial, p.slabs, mn, N, C,
+                       (long)ldc, accumulate);
     DC_CHECK_LAUNCH("dc_gemm_tn");
     return DC_OK;
 }

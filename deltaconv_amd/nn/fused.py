@@ -235,7 +235,9 @@ def gemm_tn(a, b):
     hand-written fp32-MFMA split-K kernel (csrc/gemm_tn.hip); everything else to the library."""
     r, m = a.shape
     n = b.shape[1]
-    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m % 32 == 0 and n % 32 == 0 and m * n <= 256 * 512
+    # measured window (profiles/r01i_kernels.log): the MFMA kernel wins for 16K <= M*N <= 64K outputs
+    # (e.g. 256x128: 31 vs 62 us tuned library); smaller / larger problems stay with the library
+    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m % 32 == 0 and n % 32 == 0 and 16384 <= m * n <= 65536
             and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
         nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, n)

@@ -251,11 +251,20 @@ def test_mfma_gemm_tn(R, M, N):
     abig = torch.randn(R, M + 8, device=DEV)
     bbig = torch.randn(R, N + 12, device=DEV)
     a, b = abig[:, 4:4 + M], bbig[:, 8:8 + N]
-    assert fused.USE_MFMA_TN
-    c = fused.gemm_tn(a, b)
+    from deltaconv_amd._lib import lib
+
+    def mfma_tn(a_, b_):
+        out = torch.empty(M, N, device=DEV)
+        nb = lib.raw("dc_gemm_tn_workspace_bytes")(R, M, N)
+        ws = torch.empty((nb + 3) // 4, device=DEV)
+        lib.call("dc_gemm_tn", a_, a_.stride(0), b_, b_.stride(0), R, M, N, out, N, 0, ws, ws.numel() * 4)
+        return out
+
+    c = mfma_tn(a, b)
     ref = a.double().t() @ b.double()
     scale = float((a.abs().double().t() @ b.abs().double()).max())
     assert float((c.double() - ref).abs().max()) < 2e-6 * scale
-    assert torch.equal(c, fused.gemm_tn(a, b))
+    assert torch.equal(c, mfma_tn(a, b))
+    assert float((fused.gemm_tn(a, b).double() - ref).abs().max()) < 1e-5 * scale   # dispatcher (either path)
     lib_res = a.t() @ b
     assert float((lib_res.double() - ref).abs().max()) < 1e-5 * scale   # the library is no closer

@@ -121,6 +121,8 @@ def main():
             rec("fused bn_act bwd [Nt,C]", timeit(lambda: torch.autograd.grad(yg, xg, gy, retain_graph=True)), 20 * C * n, **kw)
     lib.raw("dc_set_option")(0, 1)
     from deltaconv_amd.nn import fused
+    from deltaconv_amd.tuning import enable_tuned_gemms
+    enable_tuned_gemms()                      # the library side of the comparison uses its tuned solutions
     for (R, M, N) in ((32768, 64, 64), (32768, 64, 256), (32768, 128, 64), (32768, 128, 256), (32768, 256, 128),
                       (32768, 256, 512), (65536, 128, 192), (65536, 256, 256)):
         A, Bm = torch.randn(R, M, device=dev), torch.randn(R, N, device=dev)
