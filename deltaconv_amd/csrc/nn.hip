@@ -201,6 +201,114 @@ struct VnBwdBody {
     }
 };
 
+// ---- embedding head: BatchNorm + LeakyReLU fused with the per-cloud max / mean pooling -------------
+// (reference: MLP([sum c, 1024]) -> global_max_pool | global_mean_pool, models/deltanet_classification.py:
+// 42-49; -> global_max_pool, deltanet_segmentation.py:58-61).  The [Nt,1024] activation is never written:
+// forward reads h once and emits pooled[B, 2C] (+ the arg-max row), backward rebuilds
+// dy[i,c] = dmax[b,c]*[i == arg[b,c]] + dmean[b,c]/N on the fly inside the BN-backward passes.
+// Equal-size clouds (N rows each).
+template <int V>
+__global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__ h, long ldh, int N, int C,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float slope, int with_mean,
+                                                       float* __restrict__ pooled, long ldp, int* __restrict__ argmax) {
+    __shared__ float smx[RT][CT * V];
+    __shared__ float ssm[RT][CT * V];
+    __shared__ int sam[RT][CT * V];
+    const int cloud = blockIdx.x;
+    const int cgl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c0 = (blockIdx.y * CT + cgl) * V;
+    float mx[V], sm[V], sc[V], sh[V];
+    int am[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        mx[j] = -INFINITY; sm[j] = 0.f; am[j] = 0;
+        sc[j] = c0 < C ? scale[c0 + j] : 0.f; sh[j] = c0 < C ? shift[c0 + j] : 0.f;
+    }
+    if (c0 < C) {
+        const float* base = h + (long)cloud * N * ldh + c0;
+        for (int r = rl; r < N; r += RT) {
+            const FV<V> x = ldv<V>(base + (long)r * ldh);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float y = act(fmaf(sc[j], x.v[j], sh[j]), slope);
+                sm[j] += y;
+                if (y > mx[j]) { mx[j] = y; am[j] = r; }   // rows ascend: first maximal row of this lane
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) { smx[rl][cgl * V + j] = mx[j]; ssm[rl][cgl * V + j] = sm[j]; sam[rl][cgl * V + j] = am[j]; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < CT * V; idx += TPB) {
+        const int col = blockIdx.y * CT * V + idx;
+        if (col >= C) continue;
+        float m = smx[0][idx], t = ssm[0][idx];
+        int a = sam[0][idx];
+#pragma unroll
+        for (int rr = 1; rr < RT; ++rr) {   // fixed order; ties -> lowest row
+            const float v = smx[rr][idx];
+            const int ar = sam[rr][idx];
+            if (v > m || (v == m && ar < a)) { m = v; a = ar; }
+            t += ssm[rr][idx];
+        }
+        pooled[(long)cloud * ldp + col] = m;
+        if (with_mean) pooled[(long)cloud * ldp + C + col] = t / (float)N;
+        argmax[(long)cloud * C + col] = a;
+    }
+}
+
+// dy rebuilt from the pooled gradients (dp[b, 0:C] = d max, dp[b, C:2C] = d mean)
+template <int V>
+__device__ __forceinline__ FV<V> pool_dy(const float* dp, long ldp, const int* argmax, int N, int C, int with_mean,
+                                         long r, int c0) {
+    const long b = r / N;
+    const int row = (int)(r - b * N);
+    FV<V> g;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        float v = argmax[b * C + c0 + j] == row ? dp[b * ldp + c0 + j] : 0.f;
+        if (with_mean) v += dp[b * ldp + C + c0 + j] / (float)N;
+        g.v[j] = v;
+    }
+    return g;
+}
+template <int V>
+struct PoolBwdF {  // reduction functor: dz, dz*xhat
+    const float *dp, *h, *scale, *shift, *mean, *invstd; const int* argmax; long ldp, ldh; int N, C, with_mean; float slope;
+    __device__ void operator()(long r, int c0, double (&t)[2][V]) const {
+        const FV<V> g = pool_dy<V>(dp, ldp, argmax, N, C, with_mean, r, c0), x = ldv<V>(h + r * ldh + c0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float a, b;
+            bn_bwd_terms(g.v[j], x.v[j], scale[c0 + j], shift[c0 + j], mean[c0 + j], invstd[c0 + j], slope, a, b);
+            t[0][j] = a; t[1][j] = b;
+        }
+    }
+};
+template <int V>
+struct PoolBwdBody {
+    const float *dp, *h, *scale, *shift, *mean, *invstd, *gamma, *m1, *m2; const int* argmax; float* dh;
+    long ldp, ldh, lddh; int N, C, with_mean; float slope; int training;
+    float sc[V], sh[V], mu[V], is[V], gi[V], a1[V], a2[V];
+    __device__ void init(int c0) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = c0 + j;
+            sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+            gi[j] = (gamma ? gamma[c] : 1.f) * invstd[c]; a1[j] = m1[c]; a2[j] = m2[c];
+        }
+    }
+    __device__ void row(long r, int c0) {
+        const FV<V> g = pool_dy<V>(dp, ldp, argmax, N, C, with_mean, r, c0), x = ldv<V>(h + r * ldh + c0);
+        FV<V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+            o.v[j] = bn_bwd_dh(g.v[j], x.v[j], sc[j], sh[j], mu[j], is[j], slope, gi[j], a1[j], a2[j], training);
+        stv<V>(dh + r * lddh + c0, o);
+    }
+};
+
 template <int V, class BODY>
 void run_tile(BODY body, long R, int C, hipStream_t s) {
     const long coltiles = dc_cdiv(C, CT * V);
@@ -356,5 +464,55 @@ DC_EXPORT int dc_vn_backward(const float* dout, int64_t lddo, const float* in, i
         run_tile<1>(VnBwdBody<1>{in, dout, scale, shift, mean, invstd, gamma, w.m1, w.m2, din, (long)ld, (long)lddo,
                                  (long)lddi, co, combine, training}, n, co, s);
     DC_CHECK_LAUNCH("dc_vn_backward");
+    return DC_OK;
+}
+
+// ---- embedding head fused with per-cloud pooling ---------------------------------------------------
+// pooled[B, ldp] = [max_i y | mean_i y] over the N rows of each cloud, y = leaky(scale*h + shift);
+// argmax[B, C] = first maximal row within the cloud.  with_mean == 0 writes only the max block.
+DC_EXPORT int dc_bn_act_pool(const float* h, int64_t ldh, int32_t num_clouds, int32_t N, int32_t C, const float* scale,
+                             const float* shift, float slope, int32_t with_mean, float* pooled, int64_t ldp,
+                             int32_t* argmax, void* stream) {
+    DC_REQUIRE(h && scale && shift && pooled && argmax, "dc_bn_act_pool: null pointer");
+    DC_REQUIRE(num_clouds >= 1 && N >= 1 && C >= 1 && ldh >= C && ldp >= (with_mean ? 2 * C : C), "dc_bn_act_pool: bad size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C % 4 == 0 && ldh % 4 == 0 && al16(h))
+        hipLaunchKernelGGL(pool_fwd_kernel<4>, dim3(num_clouds, dc_cdiv(C, CT * 4)), dim3(TPB), 0, s, h, (long)ldh, N, C, scale,
+                           shift, slope, with_mean, pooled, (long)ldp, argmax);
+    else
+        hipLaunchKernelGGL(pool_fwd_kernel<1>, dim3(num_clouds, dc_cdiv(C, CT)), dim3(TPB), 0, s, h, (long)ldh, N, C, scale,
+                           shift, slope, with_mean, pooled, (long)ldp, argmax);
+    DC_CHECK_LAUNCH("dc_bn_act_pool");
+    return DC_OK;
+}
+
+// Backward of dc_bn_act_pool through the BatchNorm: dh[B*N, C], dgamma, dbeta from dpooled[B, ldp].
+DC_EXPORT int dc_bn_act_pool_backward(const float* dpooled, int64_t ldp, const int32_t* argmax, const float* h,
+                                      int64_t ldh, int32_t num_clouds, int32_t N, int32_t C, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, const float* gamma,
+                                      float slope, int32_t with_mean, int32_t training, float* dh, int64_t lddh,
+                                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    DC_REQUIRE(dpooled && argmax && h && scale && shift && mean && invstd && dh, "dc_bn_act_pool_backward: null pointer");
+    DC_REQUIRE(num_clouds >= 1 && N >= 1 && C >= 1 && ldh >= C && lddh >= C && ldp >= (with_mean ? 2 * C : C),
+               "dc_bn_act_pool_backward: bad size");
+    const long R = (long)num_clouds * N;
+    DC_WS_CHECK("dc_bn_act_pool_backward", R, C)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, R, C);
+    const BwdFin fin{R, dgamma, dbeta, w.m1, w.m2};
+    const bool v4 = C % 4 == 0 && ldh % 4 == 0 && lddh % 4 == 0 && al16(h) && al16(dh);
+    if (v4) {
+        run_colreduce<4>(PoolBwdF<4>{dpooled, h, scale, shift, mean, invstd, argmax, (long)ldp, (long)ldh, N, C, with_mean, slope},
+                         R, C, w, s, fin);
+        run_tile<4>(PoolBwdBody<4>{dpooled, h, scale, shift, mean, invstd, gamma, w.m1, w.m2, argmax, dh, (long)ldp, (long)ldh,
+                                   (long)lddh, N, C, with_mean, slope, training}, R, C, s);
+    } else {
+        run_colreduce<1>(PoolBwdF<1>{dpooled, h, scale, shift, mean, invstd, argmax, (long)ldp, (long)ldh, N, C, with_mean, slope},
+                         R, C, w, s, fin);
+        run_tile<1>(PoolBwdBody<1>{dpooled, h, scale, shift, mean, invstd, gamma, w.m1, w.m2, argmax, dh, (long)ldp, (long)ldh,
+                                   (long)lddh, N, C, with_mean, slope, training}, R, C, s);
+    }
+    DC_CHECK_LAUNCH("dc_bn_act_pool_backward");
     return DC_OK;
 }

@@ -3,7 +3,7 @@ import torch
 from torch.nn import Sequential as Seq, Dropout, Linear
 
 from .deltanet_base import DeltaNetBase, _ptr_info
-from .pool import global_max_pool, global_mean_pool
+from .pool import embed_and_pool
 from ..nn import MLP, fused
 
 
@@ -24,7 +24,6 @@ class DeltaNetClassification(torch.nn.Module):
 
     def _forward(self, data):
         conv_out = self.deltanet_base(data)
-        x = self.lin_embedding(torch.cat(conv_out, dim=1))
-        info = _ptr_info(data)
-        x = torch.cat([global_max_pool(x, info), global_mean_pool(x, info)], dim=1)
+        # lin_embedding -> [global max | global mean] (deltanet_classification.py:42-49), pooling fused in
+        x = embed_and_pool(self.lin_embedding, torch.cat(conv_out, dim=1), _ptr_info(data), with_mean=True)
         return self.classification_head(x)

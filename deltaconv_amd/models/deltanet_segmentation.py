@@ -3,7 +3,7 @@ import torch
 from torch.nn import Sequential as Seq, Dropout, LeakyReLU, Linear
 
 from .deltanet_base import DeltaNetBase, _ptr_info
-from .pool import global_max_pool
+from .pool import embed_and_pool
 from ..nn import MLP, fused
 
 
@@ -29,9 +29,9 @@ class DeltaNetSegmentation(torch.nn.Module):
 
     def _forward(self, data):
         conv_out = self.deltanet_base(data)
-        x = self.lin_global(torch.cat(conv_out, dim=1))
         batch = data.batch
-        x_max = global_max_pool(x, _ptr_info(data))[batch]
+        # lin_global -> global max pool -> broadcast back to the points (deltanet_segmentation.py:58-61)
+        x_max = embed_and_pool(self.lin_global, torch.cat(conv_out, dim=1), _ptr_info(data), with_mean=False)[batch]
         if self.categorical_vector:
             x_max = torch.cat([x_max, self.lin_categorical(data.category)[batch]], dim=1)
         return self.segmentation_head(torch.cat([x_max] + conv_out, dim=1))

@@ -22,3 +22,24 @@ def global_mean_pool(x, ptr_info):
         return x.view(nc, mx, x.shape[1]).mean(dim=1)
     p = ptr.tolist()
     return torch.stack([x[p[b]:p[b + 1]].mean(dim=0) for b in range(nc)])
+
+
+def embed_and_pool(mlp, x, ptr_info, with_mean):
+    """``pool(mlp(x))`` for the embedding MLP in front of the global pooling.  With equal-size clouds
+    and a single [Linear -> BatchNorm -> piecewise-linear] block the BatchNorm/activation is fused with
+    the pooling (the [Nt, E] activation is never written); otherwise the plain composition."""
+    import torch.nn.functional as F
+    from ..nn import fused
+    from ..nn.mlp import MLPBlock
+    _, nc, mx = ptr_info
+    blocks = list(mlp)
+    last = blocks[-1]
+    slope = fused.slope_of(last[2]) if isinstance(last, MLPBlock) else None
+    if _equal(ptr_info, x.shape[0]) and slope is not None and x.is_cuda:
+        for blk in blocks[:-1]:
+            x = blk(x)
+        h = F.linear(x, last[0].weight, last[0].bias)
+        return fused.bn_act_pool(h, last[1].bn, slope, nc, mx, with_mean)
+    x = mlp(x)
+    mxp = global_max_pool(x, ptr_info)
+    return torch.cat([mxp, global_mean_pool(x, ptr_info)], dim=1) if with_mean else mxp

@@ -245,3 +245,58 @@ def gemm_tn(a, b):
         lib.call("dc_gemm_tn", a, a.stride(0), b, b.stride(0), r, m, n, out, n, 0, ws, ws.numel() * 4)
         return out
     return a.t() @ b
+
+
+class _BNActPool(torch.autograd.Function):
+    """pooled[B, (2)C] = [max | mean] over each cloud of leaky(batch_norm(h)); the [B*N, C] activation is
+    never materialised, in either direction (csrc/nn.hip: pool_fwd_kernel, PoolBwdF, PoolBwdBody)."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, rm, rv, use_batch_stats, momentum, eps, slope, num_clouds, n_per, with_mean):
+        h = _c(h)
+        r, c = h.shape
+        dev = h.device
+        coef = torch.empty(4, c, dtype=torch.float32, device=dev)
+        if use_batch_stats:
+            ws, nb = _ws(r, c, dev)
+            lib.call("dc_bn_stats", h, r, c, c, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1], coef[2],
+                     coef[3], ws, nb)
+        else:
+            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, c, coef[0], coef[1], coef[2], coef[3])
+        width = 2 * c if with_mean else c
+        pooled = torch.empty(num_clouds, width, dtype=torch.float32, device=dev)
+        arg = torch.empty(num_clouds, c, dtype=torch.int32, device=dev)
+        lib.call("dc_bn_act_pool", h, c, num_clouds, n_per, c, coef[2], coef[3], slope, int(with_mean), pooled, width,
+                 arg)
+        ctx.save_for_backward(h, coef, gamma, arg)
+        ctx.cfg = (use_batch_stats, slope, num_clouds, n_per, with_mean, gamma is not None, beta is not None)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        h, coef, gamma, arg = ctx.saved_tensors
+        training, slope, num_clouds, n_per, with_mean, has_g, has_b = ctx.cfg
+        dpooled = _c(dpooled)
+        r, c = h.shape
+        dev = h.device
+        dh = torch.empty_like(h)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev) if has_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev) if has_b else None
+        ws, nb = _ws(r, c, dev)
+        lib.call("dc_bn_act_pool_backward", dpooled, dpooled.shape[1], arg, h, c, num_clouds, n_per, c, coef[2], coef[3],
+                 coef[0], coef[1], gamma, slope, int(with_mean), int(training), dh, c, dgamma, dbeta, ws, nb)
+        return dh, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+
+
+def bn_act_pool(h, bn, slope, num_clouds, n_per, with_mean):
+    require_gpu()
+    use_batch = bn.training or bn.running_mean is None
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    track = bn.training and bn.track_running_stats
+    if track:
+        bump_counter(bn)
+        if bn.momentum is None:
+            mom = 1.0 / float(bn.num_batches_tracked)
+    rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
+    return _BNActPool.apply(h, bn.weight, bn.bias, rm, rv, use_batch, mom, float(bn.eps), float(slope), num_clouds,
+                            n_per, with_mean)

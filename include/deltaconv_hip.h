@@ -173,6 +173,19 @@ size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N);
 int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N, float* C,
                int64_t ldc, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- embedding head fused with the per-cloud pooling -------------------------------------------------
+ * MLP([sum c, E]) -> global_max_pool | global_mean_pool  (deltaconv/models/deltanet_classification.py:42-49),
+ * -> global_max_pool (deltanet_segmentation.py:58-61).  h = Linear output [B*N, C] (equal-size clouds);
+ * the [B*N, C] activation is never written.  pooled[B, ldp] = [max | mean]; argmax[B, C] = row in cloud. */
+int dc_bn_act_pool(const float* h, int64_t ldh, int32_t num_clouds, int32_t N, int32_t C, const float* scale,
+                   const float* shift, float slope, int32_t with_mean, float* pooled, int64_t ldp, int32_t* argmax,
+                   void* stream);
+int dc_bn_act_pool_backward(const float* dpooled, int64_t ldp, const int32_t* argmax, const float* h, int64_t ldh,
+                            int32_t num_clouds, int32_t N, int32_t C, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, const float* gamma, float slope,
+                            int32_t with_mean, int32_t training, float* dh, int64_t lddh, float* dgamma, float* dbeta,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

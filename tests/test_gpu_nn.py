@@ -268,3 +268,30 @@ def test_mfma_gemm_tn(R, M, N):
     assert float((fused.gemm_tn(a, b).double() - ref).abs().max()) < 1e-5 * scale   # dispatcher (either path)
     lib_res = a.t() @ b
     assert float((lib_res.double() - ref).abs().max()) < 1e-5 * scale   # the library is no closer
+
+
+@pytest.mark.parametrize("with_mean,train,B,N,C", [(True, True, 4, 256, 64), (False, True, 3, 100, 20), (True, False, 2, 64, 8)])
+def test_bn_act_pool_fused(with_mean, train, B, N, C):
+    """Embedding head fused with per-cloud pooling vs the plain composition (oracle modules on CPU)."""
+    import deltaconv_amd as dc
+    from deltaconv_amd.nn import fused
+    ours, ref = _pair(lambda: dc.nn.MLP((12, C)), lambda: oracle.nn.MLP((12, C)))
+    ours.train(train); ref.train(train)
+    x = torch.randn(B * N, 12)
+    x[5] = x[3]                                   # duplicate row -> tie in the max: lowest row wins
+    xo = x.clone().requires_grad_(True)
+    xd = x.to(DEV).requires_grad_(True)
+    y = ref(xo).view(B, N, C)
+    po = torch.cat([y.max(1).values, y.mean(1)], 1) if with_mean else y.max(1).values
+    info = (torch.arange(0, (B + 1) * N, N, dtype=torch.int32, device=DEV), B, N)
+    pd = dc.models.pool.embed_and_pool(ours, xd, info, with_mean)
+    assert rel_err(pd, po) < 2e-4
+    if train:
+        w = torch.randn_like(po)
+        po.backward(w); pd.backward(w.to(DEV))
+        assert rel_err(xd.grad, xo.grad) < 1e-3
+        for (n1, p1), (n2, p2) in zip(ours.named_parameters(), ref.named_parameters()):
+            assert rel_err(p1.grad, p2.grad) < 1e-3, n1
+        for (n1, b1), (n2, b2) in zip(ours.named_buffers(), ref.named_buffers()):
+            if b2.dtype.is_floating_point:
+                assert rel_err(b1, b2) < 2e-4, n1
