@@ -258,26 +258,38 @@ __global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__
     }
 }
 
-// dy rebuilt from the pooled gradients (dp[b, 0:C] = d max, dp[b, C:2C] = d mean)
+// dy rebuilt from the pooled gradients (dp[b, 0:C] = d max, dp[b, C:2C] = d mean).  A thread walks
+// ascending rows of fixed columns, so the per-cloud values (d max, d mean / N, arg-max row) are cached
+// in registers and reloaded only when the row crosses into the next cloud.
 template <int V>
-__device__ __forceinline__ FV<V> pool_dy(const float* dp, long ldp, const int* argmax, int N, int C, int with_mean,
-                                         long r, int c0) {
-    const long b = r / N;
-    const int row = (int)(r - b * N);
-    FV<V> g;
+struct PoolDy {
+    const float* dp; const int* argmax; long ldp; int N, C, with_mean;
+    int cur_b; float dmx[V], dme[V]; int ar[V];
+    __device__ void reset() { cur_b = -1; }
+    __device__ FV<V> get(long r, int c0) {
+        const int b = (int)((unsigned)r / (unsigned)N);   // r < 2^31 (checked on the host)
+        if (b != cur_b) {
+            cur_b = b;
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-        float v = argmax[b * C + c0 + j] == row ? dp[b * ldp + c0 + j] : 0.f;
-        if (with_mean) v += dp[b * ldp + C + c0 + j] / (float)N;
-        g.v[j] = v;
+            for (int j = 0; j < V; ++j) {
+                dmx[j] = dp[(long)b * ldp + c0 + j];
+                dme[j] = with_mean ? dp[(long)b * ldp + C + c0 + j] / (float)N : 0.f;
+                ar[j] = argmax[(long)b * C + c0 + j];
+            }
+        }
+        const int row = (int)r - b * N;
+        FV<V> g;
+#pragma unroll
+        for (int j = 0; j < V; ++j) g.v[j] = (ar[j] == row ? dmx[j] : 0.f) + dme[j];
+        return g;
     }
-    return g;
-}
+};
 template <int V>
 struct PoolBwdF {  // reduction functor: dz, dz*xhat
-    const float *dp, *h, *scale, *shift, *mean, *invstd; const int* argmax; long ldp, ldh; int N, C, with_mean; float slope;
-    __device__ void operator()(long r, int c0, double (&t)[2][V]) const {
-        const FV<V> g = pool_dy<V>(dp, ldp, argmax, N, C, with_mean, r, c0), x = ldv<V>(h + r * ldh + c0);
+    PoolDy<V> dy; const float *h, *scale, *shift, *mean, *invstd; long ldh; float slope; int primed;
+    __device__ void operator()(long r, int c0, double (&t)[2][V]) {
+        if (!primed) { dy.reset(); primed = 1; }
+        const FV<V> g = dy.get(r, c0), x = ldv<V>(h + r * ldh + c0);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float a, b;
@@ -288,10 +300,11 @@ struct PoolBwdF {  // reduction functor: dz, dz*xhat
 };
 template <int V>
 struct PoolBwdBody {
-    const float *dp, *h, *scale, *shift, *mean, *invstd, *gamma, *m1, *m2; const int* argmax; float* dh;
-    long ldp, ldh, lddh; int N, C, with_mean; float slope; int training;
+    PoolDy<V> dy; const float *h, *scale, *shift, *mean, *invstd, *gamma, *m1, *m2; float* dh;
+    long ldh, lddh; float slope; int training;
     float sc[V], sh[V], mu[V], is[V], gi[V], a1[V], a2[V];
     __device__ void init(int c0) {
+        dy.reset();
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const int c = c0 + j;
@@ -300,7 +313,7 @@ struct PoolBwdBody {
         }
     }
     __device__ void row(long r, int c0) {
-        const FV<V> g = pool_dy<V>(dp, ldp, argmax, N, C, with_mean, r, c0), x = ldv<V>(h + r * ldh + c0);
+        const FV<V> g = dy.get(r, c0), x = ldv<V>(h + r * ldh + c0);
         FV<V> o;
 #pragma unroll
         for (int j = 0; j < V; ++j)
@@ -502,16 +515,25 @@ DC_EXPORT int dc_bn_act_pool_backward(const float* dpooled, int64_t ldp, const i
     const Ws w = carve(workspace, R, C);
     const BwdFin fin{R, dgamma, dbeta, w.m1, w.m2};
     const bool v4 = C % 4 == 0 && ldh % 4 == 0 && lddh % 4 == 0 && al16(h) && al16(dh);
+    DC_REQUIRE(R < 2147483647L, "dc_bn_act_pool_backward: too many rows");
     if (v4) {
-        run_colreduce<4>(PoolBwdF<4>{dpooled, h, scale, shift, mean, invstd, argmax, (long)ldp, (long)ldh, N, C, with_mean, slope},
-                         R, C, w, s, fin);
-        run_tile<4>(PoolBwdBody<4>{dpooled, h, scale, shift, mean, invstd, gamma, w.m1, w.m2, argmax, dh, (long)ldp, (long)ldh,
-                                   (long)lddh, N, C, with_mean, slope, training}, R, C, s);
+        PoolBwdF<4> f{};
+        f.dy.dp = dpooled; f.dy.argmax = argmax; f.dy.ldp = ldp; f.dy.N = N; f.dy.C = C; f.dy.with_mean = with_mean;
+        f.h = h; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd; f.ldh = ldh; f.slope = slope; f.primed = 0;
+        run_colreduce<4>(f, R, C, w, s, fin);
+        PoolBwdBody<4> b{};
+        b.dy = f.dy; b.h = h; b.scale = scale; b.shift = shift; b.mean = mean; b.invstd = invstd; b.gamma = gamma;
+        b.m1 = w.m1; b.m2 = w.m2; b.dh = dh; b.ldh = ldh; b.lddh = lddh; b.slope = slope; b.training = training;
+        run_tile<4>(b, R, C, s);
     } else {
-        run_colreduce<1>(PoolBwdF<1>{dpooled, h, scale, shift, mean, invstd, argmax, (long)ldp, (long)ldh, N, C, with_mean, slope},
-                         R, C, w, s, fin);
-        run_tile<1>(PoolBwdBody<1>{dpooled, h, scale, shift, mean, invstd, gamma, w.m1, w.m2, argmax, dh, (long)ldp, (long)ldh,
-                                   (long)lddh, N, C, with_mean, slope, training}, R, C, s);
+        PoolBwdF<1> f{};
+        f.dy.dp = dpooled; f.dy.argmax = argmax; f.dy.ldp = ldp; f.dy.N = N; f.dy.C = C; f.dy.with_mean = with_mean;
+        f.h = h; f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = invstd; f.ldh = ldh; f.slope = slope; f.primed = 0;
+        run_colreduce<1>(f, R, C, w, s, fin);
+        PoolBwdBody<1> b{};
+        b.dy = f.dy; b.h = h; b.scale = scale; b.shift = shift; b.mean = mean; b.invstd = invstd; b.gamma = gamma;
+        b.m1 = w.m1; b.m2 = w.m2; b.dh = dh; b.ldh = ldh; b.lddh = lddh; b.slope = slope; b.training = training;
+        run_tile<1>(b, R, C, s);
     }
     DC_CHECK_LAUNCH("dc_bn_act_pool_backward");
     return DC_OK;
