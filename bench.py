@@ -77,6 +77,26 @@ def apply_roofline(graph, grad, div, C, iters=200):
         t = e0.elapsed_time(e1) / iters * 1e-3
         fam[name] = dict(us=round(t * 1e6, 2), bytes=nbytes, GBs=round(nbytes / t / 1e9, 1),
                          frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4))
+    # the hand-written fp32-MFMA weight-gradient GEMM (csrc/gemm_tn.hip) at the layer-2 v_mlp shape
+    R, M, N = 2 * n, 256, 256
+    A, Bm = torch.randn(R, M, device=dev), torch.randn(R, N, device=dev)
+    Cout = torch.empty(M, N, device=dev)
+    nb = lib.raw("dc_gemm_tn_workspace_bytes")(R, M, N)
+    ws = torch.empty((nb + 3) // 4, device=dev)
+    fn = lambda: lib.call("dc_gemm_tn", A, M, Bm, N, R, M, N, Cout, N, 0, ws, ws.numel() * 4)
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(50):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    tg = e0.elapsed_time(e1) / 50 * 1e-3
+    mfma = dict(kernel=f"gemm_tn_kernel<2,2> + reduce (dW = dY^T X, {R}x{M}x{N}, fp32 v_mfma_f32_32x32x2)",
+                us=round(tg * 1e6, 1), achieved=round(2.0 * R * M * N / tg / 1e12, 1), peak=157.3, unit="TFLOP/s",
+                frac=round(2.0 * R * M * N / tg / 1e12 / 157.3, 3))
     head = fam["div_curl_norm"]
     traffic = None      # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc)
     try:
@@ -88,7 +108,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
         pass
     return dict(bound="hbm", achieved=head["GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=head["frac"],
                 traffic=traffic, kernel="divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)", channels=C,
-                bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam)
+                bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam, mfma=mfma)
 
 
 def cpu_baseline(args):
