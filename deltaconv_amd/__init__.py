@@ -7,7 +7,7 @@ All graph / operator work runs in libdeltaconv_hip.so (hand-written HIP for gfx9
 include/deltaconv_hip.h).  There is no CPU fallback; the CPU restatement in oracle/ is test
 infrastructure.
 """
-from . import geometry, nn, models   # noqa: F401
+from . import geometry, nn, models, transforms   # noqa: F401
 from .data import Batch              # noqa: F401
 
 __version__ = (0, 1, 0)

@@ -23,4 +23,4 @@ Third-party semantics that the reference leaves un-pinned and that this oracle D
   * SpMM summation order: ascending slot of the k-list.
   * estimate_basis sign: whatever LAPACK returns here; compared up to sign downstream.
 """
-from . import geometry, nn, models, loss  # noqa: F401
+from . import geometry, nn, models, loss, fps  # noqa: F401

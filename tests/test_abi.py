@@ -46,3 +46,18 @@ def test_no_cpu_fallback():
         dc.geometry.build_tangent_basis(torch.randn(4, 3))
     with pytest.raises(RuntimeError):
         dc.geometry.knn_graph(torch.randn(64, 3), 8)
+
+
+def test_host_library_exports():
+    """libdeltaconv_host.so (geodesic FPS, include/deltaconv_host.h)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "deltaconv_amd", "csrc_host")], check=True)
+    from deltaconv_amd.geometry.fps import HOST_LIB_PATH
+    lib = ctypes.CDLL(HOST_LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "deltaconv_host.h")).read()
+    import re
+    names = set(re.findall(r"\b(dc_\w+)\s*\(", hdr))
+    assert names == {"dc_host_version", "dc_geodesic_fps"}
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.dc_host_version() >= 100
+    assert lib.dc_geodesic_fps(None, 0, 0, 0, None) == -1
