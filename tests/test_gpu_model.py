@@ -192,3 +192,22 @@ def test_gauge_invariance_of_parameter_grads():
         F.l1_loss(out, target).backward()
         outs.append(torch.cat([p.grad.flatten() for p in conv.parameters() if p.grad is not None]).clone())
     assert torch.allclose(outs[0], outs[1], atol=1e-4)
+
+
+def test_operator_cache_opt_in():
+    """Section 8(f)-3: operators are geometry-only, so a static batch can keep them across eval passes;
+    the cache is keyed on the position tensor (identity + version) and is off by default."""
+    b = synthetic_batch(2, 256, seed=42).to(DEV)
+    model = _model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).eval()
+    base = model.deltanet_base
+    with torch.no_grad():
+        ref = model(b)
+        assert not hasattr(b, "_dc_ops")
+        base.cache_operators = True
+        o1 = model(b)
+        g1 = b._dc_ops[1][0]
+        o2 = model(b)
+        assert b._dc_ops[1][0] is g1 and torch.equal(o1, ref) and torch.equal(o2, ref)
+        b.pos.mul_(1.1)                       # geometry changed in place -> rebuilt
+        model(b)
+        assert b._dc_ops[1][0] is not g1
