@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--no-tuned-gemm", action="store_true", help="library default GEMM heuristics")
     ap.add_argument("--fresh-tuning", action="store_true", help="ignore shipped GEMM tuning results (tools/tune_gemm.sh)")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
     return ap.parse_args()
 
 
@@ -153,7 +155,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
@@ -168,7 +176,7 @@ def main():
             enable_tuned_gemms()
     torch.manual_seed(1)
     model = dc.models.DeltaNetClassification(3, 40, num_neighbors=args.k).to(dev).train()
-    ddp = FlatGradDataParallel(model)
+    ddp = FlatGradDataParallel(model, always_reduce=args.force_dist)
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)  # train_modelnet.py:67
     data = synthetic_batch(args.batch, args.points, seed=100 + rank).to(dev)
 
@@ -183,19 +191,19 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     assert torch.isfinite(loss).item(), "loss is not finite"
@@ -217,7 +225,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

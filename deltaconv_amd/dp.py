@@ -18,14 +18,15 @@ import torch.distributed as dist
 class FlatGradDataParallel:
     """Wraps a module: ``zero_grad()`` -> forward/backward as usual -> ``reduce_gradients()``."""
 
-    def __init__(self, module, process_group=None, broadcast=True):
+    def __init__(self, module, process_group=None, broadcast=True, always_reduce=False):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.flat = None
         self.views = None
-        if broadcast and self.world > 1:           # identical initial weights and BN buffers
+        self.always_reduce = always_reduce      # exercise the collective path on a single rank (tests)
+        if broadcast and (self.world > 1 or (always_reduce and dist.is_initialized())):   # identical weights / buffers
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=self.group)
 
@@ -51,7 +52,7 @@ class FlatGradDataParallel:
         """Average gradients over ranks: one all-reduce of the flat buffer (no-op on 1 rank).
         Parameters that received no gradient (e.g. VectorNonLin.bias under BatchNorm, reference
         nn/nonlin.py:74-77) are skipped -- identically on every rank, since the model is replicated."""
-        if self.world == 1:
+        if self.world == 1 and not (self.always_reduce and dist.is_initialized()):
             return None
         live = [p for p in self.params if p.grad is not None]
         views = self._ensure_flat(live)

@@ -1,0 +1,29 @@
+"""bench.py through the driver's launcher (`python -m torch.distributed.run ... bench.py --gpus N`) on the
+one GPU of the test box, with --force-dist: RCCL process group, barrier, flat gradient all-reduce and the
+JSON contract are all exercised (with a single rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_under_torchrun_single_rank():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+           "--warmup", "2", "--no-cpu-baseline", "--force-dist"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
