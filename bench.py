@@ -166,7 +166,7 @@ def main():
     assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
     import deltaconv_amd as dc
-    import oracle  # loss definition only (experiments/utils.py:7-24 restated); the model is the HIP product
+    from deltaconv_amd.utils import calc_loss
     from deltaconv_amd.data import synthetic_batch
     from deltaconv_amd.dp import FlatGradDataParallel
 
@@ -182,7 +182,7 @@ def main():
 
     def step():
         ddp.zero_grad()
-        loss = oracle.loss.calc_loss(ddp(data), data.y)
+        loss = calc_loss(ddp(data), data.y)
         loss.backward()
         ddp.reduce_gradients()
         opt.step()

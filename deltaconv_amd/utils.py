@@ -1,0 +1,41 @@
+"""Training-step glue of the reference's experiment scripts (experiments/utils.py:7-51): the
+label-smoothed cross entropy and the ShapeNet part-IoU metric.  Product code (runs on whatever device
+the logits live on); the oracle keeps its own restatement for the CPU side of the parity tests."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def calc_loss(pred, true, smoothing=True):
+    """experiments/utils.py:7-24: cross entropy with label smoothing eps = 0.2 (classification) or
+    plain mean cross entropy (segmentation, smoothing=False)."""
+    true = true.contiguous().view(-1)
+    if not smoothing:
+        return F.cross_entropy(pred, true, reduction='mean')
+    eps, n_class = 0.2, pred.size(1)
+    logp = F.log_softmax(pred, dim=1)
+    # sum_c q_c * logp_c with q = (1-eps) on the label and eps/(n_class-1) elsewhere
+    picked = logp.gather(1, true.view(-1, 1)).squeeze(1)
+    rest = logp.sum(dim=1) - picked
+    return -((1 - eps) * picked + eps / (n_class - 1) * rest).mean()
+
+
+def calc_shape_IoU(pred_np, seg_np, label, class_choice):
+    """experiments/utils.py:27-51: mean part IoU per ShapeNet shape (an empty union counts as 1)."""
+    seg_num = [4, 2, 2, 4, 4, 3, 3, 2, 4, 2, 6, 2, 3, 3, 3, 3]
+    index_start = [0, 4, 6, 8, 12, 16, 19, 22, 24, 28, 30, 36, 38, 41, 44, 47]
+    label = np.asarray(label).squeeze()
+    ious = []
+    for s in range(seg_np.shape[0]):
+        if not class_choice:
+            cat = int(label[s]) if label.ndim else int(label)
+            parts = range(index_start[cat], index_start[cat] + seg_num[cat])
+        else:
+            parts = range(seg_num[int(label[0]) if label.ndim else int(label)])
+        per_part = []
+        for part in parts:
+            p, g = pred_np[s] == part, seg_np[s] == part
+            union = np.sum(np.logical_or(p, g))
+            per_part.append(1.0 if union == 0 else np.sum(np.logical_and(p, g)) / float(union))
+        ious.append(np.mean(per_part))
+    return ious
