@@ -112,4 +112,4 @@ def test_reduced_batch_vs_oracle(name):
         lo = ref(b)
         ld = model(b.to(DEV))
     # no-normals: SVD-sign gauge + ill-defined x-axis -> looser
-    assert rel_err(ld, lo) < (5e-2 if not normals else 2e-2)
+    assert rel_err(ld, lo) < (5e-3 if not normals else 1e-3)

@@ -64,7 +64,7 @@ for name, (kind, kw, normals) in {
     logits = model(data)
     loss = calc_loss(logits, data.y, smoothing=(kind != "seg"))
     loss.backward()
-    tol = 2e-2 if normals else 5e-2
+    tol = 1e-3 if normals else 5e-3
     rec(name, "logits vs reference f64", rel_err(logits, g["logits_f64"]), tol)
     rec(name, "logits vs reference f32", rel_err(logits, g["logits_f32"]), tol)
     rec(name, "reference f32 vs its own f64", rel_err(g["logits_f32"], g["logits_f64"]), float("nan"), "(context)")
