@@ -39,6 +39,19 @@ int dc_option(int key);
 static inline int dc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Wave-level helpers -------------------------------------------------------------------------
+// Stream-ordered zero fill as a kernel (not hipMemsetAsync: a memset node inside a captured HIP graph
+// is a different code path from a kernel node; every entry point enqueues kernels only).
+namespace {
+__global__ void dc_zero_words_kernel(unsigned* __restrict__ p, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+}  // namespace
+static inline void dc_zero_words(void* p, long n_words, hipStream_t s) {
+    if (n_words <= 0) return;
+    hipLaunchKernelGGL(dc_zero_words_kernel, dim3(dc_cdiv(n_words, 256)), dim3(256), 0, s, static_cast<unsigned*>(p), n_words);
+}
+
 __device__ __forceinline__ double dc_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

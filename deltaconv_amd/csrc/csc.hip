@@ -102,10 +102,7 @@ DC_EXPORT int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t
     }
     int* cnt = static_cast<int*>(workspace);
     const long ne = (long)num_points * k;
-    if (hipMemsetAsync(cnt, 0, (size_t)num_points * 4, s) != hipSuccess) {
-        dc_set_error("dc_csc_build: memset failed");
-        return DC_ERR_LAUNCH;
-    }
+    dc_zero_words(cnt, num_points, s);
     hipLaunchKernelGGL(csc_count_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, cnt);
     hipLaunchKernelGGL(csc_scan_kernel, dim3(num_clouds), dim3(TPB), 0, s, cloud_ptr, k, num_clouds, cnt, tptr);
     int* unordered = cnt + num_points;

@@ -113,10 +113,7 @@ DC_EXPORT int dc_mls_assemble(const float* pos, const float* normal, const float
     unsigned* inf_bits = reinterpret_cast<unsigned*>(ws + align_up((size_t)num_clouds * 8, 256));
     double* coef = reinterpret_cast<double*>(ws + align_up((size_t)num_clouds * 8, 256) +
                                              align_up((size_t)num_clouds * 4, 256));
-    if (hipMemsetAsync(inf_bits, 0, (size_t)num_clouds * 4, s) != hipSuccess) {
-        dc_set_error("dc_mls_assemble: memset failed");
-        return DC_ERR_LAUNCH;
-    }
+    dc_zero_words(inf_bits, num_clouds, s);
     hipLaunchKernelGGL(mls_avgdist_kernel, dim3(num_clouds), dim3(AVG_THREADS), 0, s, pos, nbr, cloud_ptr, k, avg);
     hipLaunchKernelGGL(mls_fit_kernel, dim3(dc_cdiv(max_cloud_size, 128), num_clouds), dim3(128), 0, s, pos, normal,
                        x_basis, y_basis, nbr, cloud_ptr, k, (double)kernel_width, (double)regularizer, avg, G, coef,

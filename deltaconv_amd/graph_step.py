@@ -1,43 +1,72 @@
-"""Forward + loss + backward of one training step captured once in a HIP graph and replayed.
+"""One training step (forward + loss + backward, optionally the optimizer update) captured once in a
+HIP graph and replayed with a single host call.
 
 Why: at 32 clouds per GPU a step is ~230 kernel launches of ~17 us each -- the Python / autograd /
-ctypes enqueue time (4.3 ms) has caught up with the GPU time (4.0 ms), see tools/cpu_overhead.py.
-Every entry point of the C ABI is capture-safe by construction (stream-ordered, no allocation, no
-sync; workspaces come from torch's allocator, which serves captures from a private pool), so the whole
-step replays with one host call.  Shapes are static (equal-size clouds, fixed batch): a new batch is
-copied into the captured input tensors.  The gradient all-reduce and optimizer.step() stay outside
-the graph (RCCL, learning-rate schedules)."""
+ctypes enqueue time (4.3 ms) has caught up with the GPU time (see tools/cpu_overhead.py).  Every entry
+point of the C ABI is capture-safe by construction (stream-ordered kernels only: no allocation, no
+sync, no memset/memcpy nodes; workspaces come from torch's allocator, which serves captures from a
+private pool), so the whole step replays from one `hipGraphLaunch`.  Shapes are static (equal-size
+clouds, fixed batch): a new batch is copied into the captured input tensors.
+
+Semantics kept per replay: kNN / MLS operators are rebuilt from the current `pos`, BatchNorm running
+statistics and `num_batches_tracked` advance, Dropout draws a fresh mask (torch's graph-safe Philox
+offsets), gradients land in the same `.grad` tensors every time (do NOT call zero_grad(set_to_none)
+between replays -- the captured backward overwrites them).  The gradient all-reduce (RCCL) stays
+outside the graph; the optimizer update is captured only when `optimizer` is given (single-rank case,
+constant hyper-parameters: a learning-rate change needs `recapture()`).
+
+ROCm note (measured on ROCm 7.2 / MI355X, tools/graph_bisect*.py history in DESIGN.md): with the
+runtime's AQL-packet capture (`DEBUG_CLR_GRAPH_PACKET_CAPTURE`, default on) a replay that follows a
+handful of small eager launches reads stale kernel arguments (wrong results, or a memory fault when
+the graph holds memset nodes).  The flag must be 0 before the HIP runtime initialises;
+`deltaconv_amd/__init__.py` sets that default at import and this class refuses to run without it."""
+import os
+
 import torch
+
+_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, sample_batch, warmup=3):
-        """sample_batch: a deltaconv_amd.Batch on the GPU whose tensors become the static inputs."""
-        self.model, self.loss_fn = model, loss_fn
+    def __init__(self, model, loss_fn, sample_batch, optimizer=None, warmup=3):
+        """sample_batch: a deltaconv_amd.Batch on the GPU whose tensors become the static inputs.
+        optimizer: captured into the graph when given (its first `warmup` steps are real updates, so
+        lazily created state such as momentum buffers exists before the capture)."""
+        if os.environ.get(_FLAG, "1") != "0":
+            raise RuntimeError(f"GraphedTrainStep needs {_FLAG}=0 in the environment before the HIP runtime "
+                               "starts (import deltaconv_amd before the first torch.cuda call, or export it)")
+        self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.static = sample_batch
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.warmup = warmup
+        self.recapture()
+
+    def recapture(self):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up outside the capture (allocator, tuning)
-            for _ in range(warmup):
+            for _ in range(self.warmup):
                 self._zero()
-                self._fwd_bwd()
+                self._step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss, self.out = self._fwd_bwd()
+            self.loss, self.out = self._step()
         torch.cuda.synchronize()
+        self.grads = [(p, p.grad) for p in self.params if p.grad is not None]   # rewritten by every replay
 
     def _zero(self):
         for p in self.params:
             p.grad = None
 
-    def _fwd_bwd(self):
+    def _step(self):
         out = self.model(self.static)
         loss = self.loss_fn(out, self.static.y)
         loss.backward()
+        if self.optimizer is not None:
+            self.optimizer.step()
         return loss.detach(), out.detach()
 
     def load(self, batch):
@@ -48,10 +77,13 @@ class GraphedTrainStep:
         for name in ("pos", "norm", "x", "y", "category"):
             dst, src = getattr(s, name, None), getattr(batch, name, None)
             if dst is not None:
+                assert src is not None and src.shape == dst.shape, f"batch.{name}: static shape {tuple(dst.shape)}"
                 dst.copy_(src, non_blocking=True)
 
     def __call__(self, batch=None):
         if batch is not None:
             self.load(batch)
         self.graph.replay()
+        for p, g in self.grads:       # a gradient reducer may have re-pointed .grad at its own buffer
+            p.grad = g
         return self.loss

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before HIP starts (deltaconv_amd/graph_step.py)
+
 import numpy as np
 import pytest
 import torch

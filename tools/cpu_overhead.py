@@ -1,12 +1,15 @@
 """How close is the step to being host-bound?  Time to ENQUEUE 20 steps vs time until the GPU finishes them."""
-import os, sys, time, torch
+import os, sys, time
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import deltaconv_amd as dc
 from deltaconv_amd.utils import calc_loss
 from deltaconv_amd.data import synthetic_batch
 from deltaconv_amd.dp import FlatGradDataParallel
 from deltaconv_amd.tuning import enable_tuned_gemms
-enable_tuned_gemms()
+if os.environ.get('DC_TUNED', '1') == '1':
+    enable_tuned_gemms()
 dev = "cuda"
 torch.manual_seed(1)
 model = dc.models.DeltaNetClassification(3, 40).to(dev).train()
@@ -25,9 +28,9 @@ t2 = time.perf_counter()
 print(f"enqueue {1e3*(t1-t0)/20:.3f} ms/step   total {1e3*(t2-t0)/20:.3f} ms/step   (host-bound if equal)")
 
 from deltaconv_amd.graph_step import GraphedTrainStep
-g = GraphedTrainStep(model, calc_loss, data)
+g = GraphedTrainStep(model, calc_loss, data, optimizer=opt)
 def gstep():
-    g(); ddp.reduce_gradients(); opt.step()
+    g()
 for _ in range(5): gstep()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
