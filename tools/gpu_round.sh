@@ -22,5 +22,6 @@ cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $GRAFT_REPO_ROOT
 find $OUT/prof -name "*kernel_stats*" | head -3
 python tools/prof_summary.py $OUT/prof > $OUT/kernel_summary.txt 2>&1; head -40 $OUT/kernel_summary.txt
+python tools/step_timeline.py $OUT/prof > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt
 # keep the merged-back payload small
 find $OUT/prof -name "*.csv" -size +20M -delete
