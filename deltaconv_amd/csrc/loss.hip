@@ -1,0 +1,91 @@
+// Training loss in two launches: label-smoothed / plain mean cross entropy and its gradient.
+// Replaces ~25 tiny ATen launches (log_softmax, gather, sums, mean and their backward) of
+// /root/reference/experiments/utils.py:7-24 per step; at [32 x 40] logits those are pure launch latency.
+//   ce_rows_kernel : wave = row (lanes stride the classes), writes d loss / d logits and one fp64
+//                    partial per block of 64 rows (wave butterflies + fixed-order sums: bit-reproducible)
+//   ce_final_kernel: one wave sums the block partials in a fixed order -> loss = sum / R
+// Bound: latency.  Bytes: 8 R C + 8 R.
+#include "common.h"
+#include "loss_math.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 64, WAVES = 4;
+
+// wave = row (lanes stride the classes, coalesced); each wave walks ROWS_PER_BLOCK / WAVES rows
+__global__ __launch_bounds__(64 * WAVES) void ce_rows_kernel(const float* __restrict__ x, long ldx,
+                                                             const long* __restrict__ label, long R, int C, float eps,
+                                                             float* __restrict__ dx, long lddx,
+                                                             double* __restrict__ partial) {
+    __shared__ double sm[WAVES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float inv_rows = 1.f / (float)R, q_off = dcloss::ce_q_off(C, eps), q_on = 1.f - eps;
+    double acc = 0.0;
+    for (int i = 0; i < ROWS_PER_BLOCK / WAVES; ++i) {
+        const long r = (long)blockIdx.x * ROWS_PER_BLOCK + w * (ROWS_PER_BLOCK / WAVES) + i;
+        if (r >= R) break;   // wave-uniform
+        const float* xr = x + r * ldx;
+        float m = -INFINITY;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+        m = dc_wave_max(m);
+        float se = 0.f, sx = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = xr[c];
+            se += expf(v - m);
+            sx += v;
+        }
+        se = dc_wave_sum(se);
+        sx = dc_wave_sum(sx);
+        const float lse = m + logf(se);
+        const long y = label[r];
+        const bool ok = y >= 0 && y < C;
+        const float bad = ok ? 0.f : nanf("");
+        for (int c = lane; c < C; c += 64)
+            dx[r * lddx + c] = dcloss::ce_grad(xr[c], lse, (ok && c == y) ? q_on : q_off, inv_rows) + bad;
+        acc += (double)(dcloss::ce_row_loss(ok ? xr[y] : 0.f, sx, lse, C, eps) + bad);   // lane-uniform
+    }
+    if (lane == 0) sm[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) s += sm[q];
+        partial[blockIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(64) void ce_final_kernel(const double* __restrict__ partial, int nb, long R,
+                                                      float* __restrict__ loss) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) s += partial[b];
+    s = dc_wave_sum(s);
+    if (threadIdx.x == 0) *loss = (float)(s / (double)R);
+}
+
+}  // namespace
+
+DC_EXPORT size_t dc_ce_loss_workspace_bytes(int64_t num_rows) {
+    return (size_t)dc_cdiv(num_rows > 0 ? num_rows : 1, ROWS_PER_BLOCK) * sizeof(double);
+}
+
+DC_EXPORT int dc_ce_loss(const float* logits, int64_t ld_logits, const int64_t* labels, int64_t num_rows,
+                         int32_t num_classes, float smoothing, float* loss, float* dlogits, int64_t ld_dlogits,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(logits && labels && loss && dlogits, "dc_ce_loss: null pointer");
+    DC_REQUIRE(num_rows >= 1 && num_classes >= 1, "dc_ce_loss: empty input (the mean over zero rows is undefined)");
+    DC_REQUIRE(ld_logits >= num_classes && ld_dlogits >= num_classes, "dc_ce_loss: leading dimension smaller than the row");
+    DC_REQUIRE(smoothing >= 0.f && smoothing < 1.f, "dc_ce_loss: smoothing must be in [0, 1)");
+    if (!workspace || workspace_bytes < dc_ce_loss_workspace_bytes(num_rows)) {
+        dc_set_error("dc_ce_loss: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = dc_cdiv(num_rows, ROWS_PER_BLOCK);
+    double* partial = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(ce_rows_kernel, dim3(nb), dim3(64 * WAVES), 0, s, logits, (long)ld_logits,
+                       reinterpret_cast<const long*>(labels), (long)num_rows, num_classes, smoothing, dlogits,
+                       (long)ld_dlogits, partial);
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, s, partial, nb, (long)num_rows, loss);
+    DC_CHECK_LAUNCH("dc_ce_loss");
+    return DC_OK;
+}

@@ -6,10 +6,36 @@ import torch
 import torch.nn.functional as F
 
 
+class _CELoss(torch.autograd.Function):
+    """loss and d loss / d logits from one pass (csrc/loss.hip): two launches instead of ~25."""
+
+    @staticmethod
+    def forward(ctx, pred, true, eps):
+        from ._lib import lib
+        pred = pred if (pred.dtype == torch.float32 and pred.stride(-1) == 1) else pred.contiguous().float()
+        r, c = pred.shape
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        dlogits = torch.empty(r, c, dtype=torch.float32, device=pred.device)
+        nbytes = lib.raw("dc_ce_loss_workspace_bytes")(r)
+        ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=pred.device)
+        lib.call("dc_ce_loss", pred, pred.stride(0), true, r, c, float(eps), loss, dlogits, c, ws, nbytes)
+        ctx.save_for_backward(dlogits)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None, None
+
+
 def calc_loss(pred, true, smoothing=True):
     """experiments/utils.py:7-24: cross entropy with label smoothing eps = 0.2 (classification) or
-    plain mean cross entropy (segmentation, smoothing=False)."""
+    plain mean cross entropy (segmentation, smoothing=False).  Logits on the GPU go through the fused
+    HIP kernel; the torch formula below serves host-side tensors (metrics on CPU copies, CPU tests)."""
     true = true.contiguous().view(-1)
+    if pred.is_cuda:
+        assert pred.dim() == 2 and true.numel() == pred.shape[0], "calc_loss: pred [R,C], true [R]"
+        return _CELoss.apply(pred, true.long(), 0.2 if smoothing else 0.0)
     if not smoothing:
         return F.cross_entropy(pred, true, reduction='mean')
     eps, n_class = 0.2, pred.size(1)

@@ -83,7 +83,7 @@ def main():
     torch.manual_seed(1)
     model = DeltaNetClassification(3, 40, num_neighbors=args.k, grad_regularizer=args.grad_regularizer).to(dev)
     ddp = FlatGradDataParallel(model)
-    opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4, fused=True)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, args.epochs, eta_min=0.001)
     train = make_split(args.train_batches, args.batch_size, args.num_points, 1000 * (rank + 1), dev)
     test = make_split(2, args.batch_size, args.num_points, 777000, dev)

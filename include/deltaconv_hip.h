@@ -186,6 +186,17 @@ int dc_bn_act_pool_backward(const float* dpooled, int64_t ldp, const int32_t* ar
                             int32_t with_mean, int32_t training, float* dh, int64_t lddh, float* dgamma, float* dbeta,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training loss ------------------------------------------------------------------------------
+ * Replaces experiments/utils.py:7-24 (`calc_loss`: label-smoothed cross entropy, eps = 0.2, or
+ * `F.cross_entropy(..., reduction='mean')` when smoothing = 0) together with its autograd backward:
+ *   loss    = mean_r( -sum_c q_rc * log_softmax(logits_r)_c ),  q = 1-smoothing on the label, smoothing/(C-1) elsewhere
+ *   dlogits = (softmax(logits_r) - q_r) / num_rows            (multiply by the incoming gradient of the loss)
+ * labels int64 in [0, num_classes) (a label outside poisons the loss with NaN).  Deterministic (ordered fp64 sum). */
+size_t dc_ce_loss_workspace_bytes(int64_t num_rows);
+int dc_ce_loss(const float* logits, int64_t ld_logits, const int64_t* labels, int64_t num_rows, int32_t num_classes,
+               float smoothing, float* loss, float* dlogits, int64_t ld_dlogits, void* workspace,
+               size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

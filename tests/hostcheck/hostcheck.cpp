@@ -10,6 +10,7 @@
 #include "../../deltaconv_amd/csrc/ell_math.h"
 #include "../../deltaconv_amd/csrc/nn_math.h"
 #include "../../deltaconv_amd/csrc/edge_math.h"
+#include "../../deltaconv_amd/csrc/loss_math.h"
 
 extern "C" {
 
@@ -261,5 +262,12 @@ void hc_edge(const float* y, const int* nbr, const int* tptr, const int* tedge, 
     for (long t = 0; t < (long)n * C; ++t)
         edge_bwd_point<1>(t, C, tptr, tedge, k, y, C, dzs.data(), s1.data(), C, amx.data(), amn.data(), C, scale.data(),
                           mean.data(), invstd.data(), m1.data(), m2.data(), training, dy, C);
+}
+
+// training loss: mean over rows of ce_row, gradient per row (loss.hip runs the same body per thread)
+double hc_ce_loss(const float* x, const long* label, long R, int C, float eps, float* dx) {
+    double s = 0.0;
+    for (long r = 0; r < R; ++r) s += (double)dcloss::ce_row(x + r * C, C, label[r], eps, 1.f / (float)R, dx + r * C);
+    return s / (double)R;
 }
 }

@@ -295,3 +295,37 @@ def test_bn_act_pool_fused(with_mean, train, B, N, C):
         for (n1, b1), (n2, b2) in zip(ours.named_buffers(), ref.named_buffers()):
             if b2.dtype.is_floating_point:
                 assert rel_err(b1, b2) < 2e-4, n1
+
+
+@pytest.mark.parametrize("R,C,smoothing,strided", [(32, 40, True, False), (32768, 50, False, False), (1, 2, True, False),
+                                                    (100, 15, True, True), (7, 8, False, True)])
+def test_fused_loss_matches_oracle(R, C, smoothing, strided):
+    """dc_ce_loss (value + gradient, scaled by the incoming gradient) == experiments/utils.py:7-24 as restated
+    in oracle/loss.py, incl. logits that are a column slice of a wider matrix."""
+    from deltaconv_amd.utils import calc_loss
+    torch.manual_seed(R * 31 + C)
+    wide = torch.randn(R, C + 5) * 3
+    x_cpu = (wide[:, 2:2 + C] if strided else wide[:, :C].contiguous()).clone().requires_grad_(True)
+    y = torch.randint(0, C, (R,))
+    ref = oracle.loss.calc_loss(x_cpu, y, smoothing=smoothing) * 1.7
+    ref.backward()
+    wide_d = wide.to(DEV).requires_grad_(True)
+    x = wide_d[:, 2:2 + C] if strided else wide_d[:, :C].contiguous()
+    if not strided:
+        x.retain_grad()
+    loss = calc_loss(x, y.to(DEV), smoothing=smoothing) * 1.7
+    loss.backward()
+    g = wide_d.grad[:, 2:2 + C] if strided else x.grad
+    assert abs(float(loss) - float(ref)) <= 3e-6 * max(1.0, abs(float(ref)))        # fp32 exp/log, fp64 row sum
+    assert rel_err(g.cpu(), x_cpu.grad) < 1e-5
+    # repeatability: the ordered reduction gives the same bits every time
+    again = calc_loss(x.detach(), y.to(DEV), smoothing=smoothing) * 1.7
+    assert float(again) == float(loss)
+
+
+def test_fused_loss_rejects_bad_shapes():
+    from deltaconv_amd.utils import calc_loss
+    with pytest.raises((RuntimeError, AssertionError)):
+        calc_loss(torch.zeros(0, 4, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV))
+    bad = calc_loss(torch.zeros(3, 4, device=DEV), torch.tensor([0, 9, 1], device=DEV))   # label out of range
+    assert torch.isnan(bad)

@@ -23,6 +23,8 @@ def hc():
     vp, ci, cl, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
     lib.hc_bn_act.argtypes = [vp, cl, ci, vp, vp, cf, cf, vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.hc_vn.argtypes = [vp, cl, ci, ci, vp, vp, cf, ci, vp, vp, vp, vp, vp]
+    lib.hc_ce_loss.argtypes = [vp, vp, cl, ci, cf, vp]
+    lib.hc_ce_loss.restype = ctypes.c_double
     return lib
 
 
@@ -140,3 +142,17 @@ def test_edge_mlp_without_edge_tensor(hc, slope, training):
     if slope > 0:
         assert torch.equal(arg.long(), arg_ref)
     assert rel_err(dy, gy) < 1e-4 and rel_err(dg, gg) < 1e-4 and rel_err(db, gb) < 1e-4
+
+
+@pytest.mark.parametrize("R,C,smoothing", [(32, 40, True), (257, 50, False), (1, 2, True), (5, 1, False), (64, 15, True)])
+def test_ce_loss_row_formula(hc, R, C, smoothing):
+    """csrc/loss_math.h == the oracle's restatement of experiments/utils.py:7-24, value and gradient."""
+    torch.manual_seed(R + C)
+    x = (torch.randn(R, C) * 3).requires_grad_(True)
+    y = torch.randint(0, C, (R,))
+    ref = oracle.loss.calc_loss(x, y, smoothing=smoothing)
+    ref.backward()
+    dx = torch.empty(R, C)
+    got = hc.hc_ce_loss(P(x.detach()), P(y), R, C, 0.2 if smoothing else 0.0, P(dx))
+    assert abs(got - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert rel_err(dx, x.grad) < 5e-6 or float((dx - x.grad).abs().max()) < 1e-7

@@ -14,7 +14,7 @@ dev = "cuda"
 torch.manual_seed(1)
 model = dc.models.DeltaNetClassification(3, 40).to(dev).train()
 ddp = FlatGradDataParallel(model)
-opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
 data = synthetic_batch(32, 1024, seed=100).to(dev)
 def step():
     ddp.zero_grad(); loss = calc_loss(ddp(data), data.y); loss.backward(); ddp.reduce_gradients(); opt.step()
