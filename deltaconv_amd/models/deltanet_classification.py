@@ -1,10 +1,11 @@
 """Classification head (reference: deltaconv/models/deltanet_classification.py:9-51)."""
 import torch
-from torch.nn import Sequential as Seq, Dropout, Linear
+from torch.nn import Sequential as Seq, Dropout
 
 from .deltanet_base import DeltaNetBase, _ptr_info
 from .pool import embed_and_pool
 from ..nn import MLP, fused
+from ..nn.mlp import Linear
 
 
 class DeltaNetClassification(torch.nn.Module):

@@ -1,10 +1,11 @@
 """Segmentation head (reference: deltaconv/models/deltanet_segmentation.py:9-69)."""
 import torch
-from torch.nn import Sequential as Seq, Dropout, LeakyReLU, Linear
+from torch.nn import Sequential as Seq, Dropout, LeakyReLU
 
 from .deltanet_base import DeltaNetBase, _ptr_info
-from .pool import embed_and_pool
+from .pool import embed_and_pool, broadcast_to_points
 from ..nn import MLP, fused
+from ..nn.mlp import Linear
 
 
 class DeltaNetSegmentation(torch.nn.Module):
@@ -31,7 +32,23 @@ class DeltaNetSegmentation(torch.nn.Module):
         conv_out = self.deltanet_base(data)
         batch = data.batch
         # lin_global -> global max pool -> broadcast back to the points (deltanet_segmentation.py:58-61)
-        x_max = embed_and_pool(self.lin_global, torch.cat(conv_out, dim=1), _ptr_info(data), with_mean=False)[batch]
+        info, n = _ptr_info(data), data.pos.shape[0]
+        conv_cat = torch.cat(conv_out, dim=1)
+        pooled = embed_and_pool(self.lin_global, conv_cat, info, with_mean=False)
         if self.categorical_vector:
-            x_max = torch.cat([x_max, self.lin_categorical(data.category)[batch]], dim=1)
-        return self.segmentation_head(torch.cat([x_max] + conv_out, dim=1))
+            pooled = torch.cat([pooled, self.lin_categorical(data.category)], dim=1)
+        first = self.segmentation_head[0]
+        blk = first[0] if len(first) == 1 else None
+        _, nc, mx = info
+        if (blk is not None and blk[0].bias is None and fused.slope_of(blk[2]) is not None and nc * mx == n
+                and conv_cat.is_cuda):
+            # Linear([x_max[batch] | conv]) = Linear_a(x_max)[batch] + Linear_b(conv): the per-cloud half of the
+            # first head GEMM runs on B rows instead of Nt and the [Nt, E+S] concatenation is never built
+            # (deltanet_segmentation.py:66-68; same sum, different association of the fp32 additions).
+            w, p = blk[0].weight, pooled.shape[1]
+            h = fused.linear(conv_cat, w[:, p:]).view(nc, mx, -1)
+            h = (h + fused.linear(pooled, w[:, :p]).unsqueeze(1)).view(n, -1)
+            y = fused.bn_act(h, blk[1].bn, fused.slope_of(blk[2]))
+            return self.segmentation_head[1:](y)
+        x_max = broadcast_to_points(pooled, batch, info, n)
+        return self.segmentation_head(torch.cat([x_max, conv_cat], dim=1))

@@ -38,8 +38,19 @@ def embed_and_pool(mlp, x, ptr_info, with_mean):
     if _equal(ptr_info, x.shape[0]) and slope is not None and x.is_cuda:
         for blk in blocks[:-1]:
             x = blk(x)
-        h = F.linear(x, last[0].weight, last[0].bias)
+        h = fused.linear(x, last[0].weight, last[0].bias)
         return fused.bn_act_pool(h, last[1].bn, slope, nc, mx, with_mean)
     x = mlp(x)
     mxp = global_max_pool(x, ptr_info)
     return torch.cat([mxp, global_mean_pool(x, ptr_info)], dim=1) if with_mean else mxp
+
+
+def broadcast_to_points(pooled, batch, ptr_info, n):
+    """``pooled[batch]``: one row per cloud -> one row per point (deltanet_segmentation.py:61,66).  With
+    equal-size clouds this is an expand, whose backward is a per-cloud sum (one reduction kernel); the
+    advanced-indexing form costs a sort + serialized scatter in backward (4.2 ms of a 16 ms step at
+    16 x 2048 points, profiles/r01n_c4_kernel_summary_before.txt)."""
+    _, nc, mx = ptr_info
+    if _equal(ptr_info, n) and pooled.shape[0] == nc:
+        return pooled.unsqueeze(1).expand(nc, mx, pooled.shape[1]).reshape(n, pooled.shape[1])
+    return pooled[batch]

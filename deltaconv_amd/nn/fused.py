@@ -235,9 +235,11 @@ def gemm_tn(a, b):
     hand-written fp32-MFMA split-K kernel (csrc/gemm_tn.hip); everything else to the library."""
     r, m = a.shape
     n = b.shape[1]
-    # measured window (profiles/r01i_kernels.log): the MFMA kernel wins for 16K <= M*N <= 64K outputs
-    # (e.g. 256x128: 31 vs 62 us tuned library); smaller / larger problems stay with the library
-    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m % 32 == 0 and n % 32 == 0 and 16384 <= m * n <= 65536
+    # measured window (profiles/r01i_kernels.log, r01n): the MFMA kernel wins for 16K <= M*N <= 64K outputs
+    # against the TUNED library (e.g. 256x128: 31 vs 62 us) and ties up to 256K (512x256: 91 vs 88 us); against
+    # the library's default heuristic it wins by 5-18x there (448x256: 1.5 ms).  Larger problems (the
+    # 1024x512 embedding) and smaller ones stay with the library.
+    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m % 32 == 0 and n % 32 == 0 and 16384 <= m * n <= 262144
             and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
         nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, n)
@@ -245,6 +247,34 @@ def gemm_tn(a, b):
         lib.call("dc_gemm_tn", a, a.stride(0), b, b.stride(0), r, m, n, out, n, 0, ws, ws.numel() * 4)
         return out
     return a.t() @ b
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b) on 2-D row-major x; the weight gradient dW = dY^T X goes through `gemm_tn` (own fp32
+    MFMA kernel inside its window), dX and the forward product through the library."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return F.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = gemm_tn(dy, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """F.linear with the tall-skinny weight-gradient GEMM routed to csrc/gemm_tn.hip (2-D fp32 GPU inputs)."""
+    if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
+        return _Linear.apply(x, w, b)
+    return F.linear(x, w, b)
 
 
 class _BNActPool(torch.autograd.Function):

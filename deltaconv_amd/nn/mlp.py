@@ -3,10 +3,21 @@
 library GEMM + one fused HIP BatchNorm/activation kernel instead of three ATen ops."""
 import torch
 import torch.nn.functional as F
-from torch.nn import Sequential as Seq, Linear as Lin, LeakyReLU
+from torch.nn import Sequential as Seq, LeakyReLU
 
 from .nonlin import BatchNorm1d, VectorNonLin
 from . import fused
+
+
+class Linear(torch.nn.Linear):
+    """torch.nn.Linear (same parameters, state_dict keys and repr) whose weight gradient runs through
+    `fused.linear` (own fp32-MFMA kernel for the tall-skinny dW = dY^T X)."""
+
+    def forward(self, x):
+        return fused.linear(x, self.weight, self.bias)
+
+
+Lin = Linear
 
 
 class MLPBlock(Seq):
@@ -15,7 +26,7 @@ class MLPBlock(Seq):
     def forward(self, x, residual=None):
         lin, bn, act = self[0], self[1], self[2]
         slope = fused.slope_of(act)
-        h = F.linear(x, lin.weight, lin.bias)
+        h = fused.linear(x, lin.weight, lin.bias)
         if slope is None:                       # exotic activation: BN fused, activation through torch
             out = act(fused.bn_act(h, bn.bn, 1.0))
             return out if residual is None else out + residual
@@ -26,7 +37,7 @@ class VectorBlock(Seq):
     """[Linear(no bias) -> VectorNonLin]."""
 
     def forward(self, v):
-        return self[1](F.linear(v, self[0].weight))
+        return self[1](fused.linear(v, self[0].weight))
 
     def forward_vcat(self, v_cat):
         """Same as forward(I_J(v_cat)) without materialising I_J: with W = [W1 | W2],
@@ -38,7 +49,7 @@ class VectorBlock(Seq):
         if not isinstance(self[1].nonlin, torch.nn.ReLU):
             from ..geometry.operators import I_J
             return self.forward(I_J(v_cat))
-        pq = F.linear(v_cat, torch.cat([w[:, :k], w[:, k:]], dim=0))     # [2N, 2*co]
+        pq = fused.linear(v_cat, torch.cat([w[:, :k], w[:, k:]], dim=0))     # [2N, 2*co]
         return self[1](pq, combine=True)
 
 
