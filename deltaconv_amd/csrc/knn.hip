@@ -10,6 +10,8 @@
 // sorted top-K list in registers (fully unrolled insertion); the P lists are then merged
 // through LDS with K rounds of a lexicographic (distance, index) min over the P-lane group.
 // Compute-bound (N^2 distance evaluations per cloud), not HBM-bound: 12 B/point in, 4k B out.
+// Two kernels: the wave-per-query selection kernel (further down, default) and this sorted-insertion
+// kernel (k > 40, clouds > 4096 points, or lanes_per_query = 1 | 8).
 #include "common.h"
 #include <math.h>
 
@@ -168,6 +170,180 @@ int dispatch_k(const float* pos, const int* cloud_ptr, int num_clouds, int max_c
     return launch_knn<64, P>(pos, cloud_ptr, num_clouds, max_cloud, k, nbr, stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wave-per-query selection kernel (default for k <= 40, clouds <= 4096 points).
+//
+// One wave owns a query.  Lane l keeps the NPL distances to candidates l, l+64, l+128, ... in
+// registers (positions staged once per block in LDS as SoA, read conflict-free).  Instead of
+// maintaining a sorted list (data-dependent insertions diverge in SIMD) the wave bounds the k-th
+// distance: the k-th smallest of the 64 per-lane minima is >= the true k-th distance, and only
+// ~1.2 k candidates lie below it (measured: 23 +- 3 of 1024 for k = 20).  Those are compacted into
+// LDS with ballot prefix sums and rank-sorted by (distance bits, index) -- exact, deterministic.
+// If more than 64 candidates pass (massive ties: duplicated points) the wave falls back to an exact
+// bit-by-bit radix select of the k-th distance on its registers and takes ties in index order.
+// VALU-bound: ~45 instructions per candidate-lane-group instead of ~57 per candidate.
+constexpr int WQ_WAVES = 4;
+constexpr int WQ_QPB = 32;   // queries per block (8 per wave)
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int lane_prefix(unsigned long long mask) {   // set bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(64 * WQ_WAVES) void knn_wave_kernel(const float* __restrict__ pos,
+                                                                 const int* __restrict__ cloud_ptr, int k,
+                                                                 int* __restrict__ nbr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NC = NPL * 64;
+    float* tx = reinterpret_cast<float*>(smem);
+    float* ty = tx + NC;
+    float* tz = ty + NC;
+    unsigned* scratch = reinterpret_cast<unsigned*>(tz + NC);       // per wave: 64 keys + 64 ids + 64 minima + tau
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned* key_u = scratch + wave * 200;
+    unsigned* key_i = key_u + 64;
+    unsigned* mins = key_i + 64;
+    unsigned* tau_slot = mins + 64;
+
+    const int cloud = blockIdx.y;
+    const int begin = cloud_ptr[cloud];
+    const int n = cloud_ptr[cloud + 1] - begin;
+    const int q0 = blockIdx.x * WQ_QPB;
+    if (q0 >= n) return;   // block-uniform
+    for (int c = threadIdx.x; c < NC; c += 64 * WQ_WAVES) {
+        float x = INFINITY, y = 0.f, z = 0.f;   // padding: distance +inf
+        if (c < n) {
+            const float* p = pos + 3 * (size_t)(begin + c);
+            x = p[0]; y = p[1]; z = p[2];
+        }
+        tx[c] = x; ty[c] = y; tz[c] = z;
+    }
+    __syncthreads();
+
+    for (int t = wave; t < WQ_QPB; t += WQ_WAVES) {
+        const int q = q0 + t;
+        if (q >= n) break;   // wave-uniform
+        const float px = tx[q], py = ty[q], pz = tz[q];
+        unsigned u[NPL];
+        unsigned mn = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int c = j * 64 + lane;
+            const float dx = __fsub_rn(px, tx[c]);
+            const float dy = __fsub_rn(py, ty[c]);
+            const float dz = __fsub_rn(pz, tz[c]);
+            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            u[j] = __float_as_uint(d2);          // d2 >= +0: the bit pattern orders like the value
+            mn = min(mn, u[j]);
+        }
+        // ---- upper bound of the k-th distance: k-th smallest of the lane minima
+        wave_lds_sync();                          // previous query's readers are done with the scratch
+        mins[lane] = mn;
+        wave_lds_sync();
+        int c_lt = 0, c_le = 0;
+#pragma unroll 16
+        for (int l = 0; l < 64; ++l) {
+            const unsigned m = mins[l];
+            c_lt += m < mn;
+            c_le += m <= mn;
+        }
+        if (c_lt < k && k <= c_le) *tau_slot = mn;   // every qualifying lane holds the same value
+        wave_lds_sync();
+        const unsigned tau = *tau_slot;
+        // ---- compact candidates <= tau (in index order)
+        int base = 0;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const bool hit = u[j] <= tau;
+            const unsigned long long mask = __ballot(hit);
+            const int slot = base + lane_prefix(mask);
+            if (hit && slot < 64) {
+                key_u[slot] = u[j];
+                key_i[slot] = (unsigned)(j * 64 + lane);
+            }
+            base += __popcll(mask);
+        }
+        int m = base;
+        if (m > 64) {
+            // ---- exact k-th distance by radix select on the registers, then < first, ties by index
+            unsigned prefix = 0;
+            for (int bit = 30; bit >= 0; --bit) {
+                const unsigned trial = prefix | (1u << bit);
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) c += u[j] < trial;
+                c = wave_sum_i(c);
+                if (c < k) prefix = trial;     // fewer than k below `trial`: the k-th is >= trial
+            }
+            wave_lds_sync();
+            base = 0;
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const bool hit = u[j] < prefix;
+                const unsigned long long mask = __ballot(hit);
+                const int slot = base + lane_prefix(mask);
+                if (hit) {                      // fewer than k <= 64 of these
+                    key_u[slot] = u[j];
+                    key_i[slot] = (unsigned)(j * 64 + lane);
+                }
+                base += __popcll(mask);
+            }
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const bool hit = u[j] == prefix;
+                const unsigned long long mask = __ballot(hit);
+                const int slot = base + lane_prefix(mask);
+                if (hit && slot < k) {
+                    key_u[slot] = u[j];
+                    key_i[slot] = (unsigned)(j * 64 + lane);
+                }
+                base += __popcll(mask);
+            }
+            m = min(base, k);
+        }
+        wave_lds_sync();
+        // ---- rank sort of the m <= 64 survivors by (distance bits, index)
+        const unsigned mu = lane < m ? key_u[lane] : 0xffffffffu;
+        const unsigned mi = lane < m ? key_i[lane] : 0xffffffffu;
+        int rank = 0;
+        for (int l = 0; l < m; ++l) {
+            const unsigned ou = key_u[l], oi = key_i[l];
+            rank += (ou < mu) || (ou == mu && oi < mi);
+        }
+        if (lane < m && rank < k) nbr[(size_t)(begin + q) * k + rank] = begin + (int)mi;
+    }
+}
+
+template <int NPL>
+int launch_knn_wave(const float* pos, const int* cloud_ptr, int num_clouds, int max_cloud, int k, int* nbr,
+                    hipStream_t stream) {
+    const size_t lds = (size_t)3 * NPL * 64 * sizeof(float) + WQ_WAVES * 200 * sizeof(unsigned);
+    dim3 grid(dc_cdiv(max_cloud, WQ_QPB), num_clouds);
+    hipLaunchKernelGGL((knn_wave_kernel<NPL>), grid, dim3(64 * WQ_WAVES), lds, stream, pos, cloud_ptr, k, nbr);
+    DC_CHECK_LAUNCH("dc_knn");
+    return DC_OK;
+}
+
+int dispatch_wave(const float* pos, const int* cloud_ptr, int num_clouds, int max_cloud, int k, int* nbr,
+                  hipStream_t stream) {
+    if (max_cloud <= 256) return launch_knn_wave<4>(pos, cloud_ptr, num_clouds, max_cloud, k, nbr, stream);
+    if (max_cloud <= 512) return launch_knn_wave<8>(pos, cloud_ptr, num_clouds, max_cloud, k, nbr, stream);
+    if (max_cloud <= 1024) return launch_knn_wave<16>(pos, cloud_ptr, num_clouds, max_cloud, k, nbr, stream);
+    if (max_cloud <= 2048) return launch_knn_wave<32>(pos, cloud_ptr, num_clouds, max_cloud, k, nbr, stream);
+    return launch_knn_wave<64>(pos, cloud_ptr, num_clouds, max_cloud, k, nbr, stream);
+}
+
 }  // namespace
 
 DC_EXPORT int dc_knn(const float* pos, const int32_t* cloud_ptr, int32_t num_clouds, int32_t max_cloud_size,
@@ -175,10 +351,15 @@ DC_EXPORT int dc_knn(const float* pos, const int32_t* cloud_ptr, int32_t num_clo
     DC_REQUIRE(pos && cloud_ptr && nbr, "dc_knn: null pointer");
     DC_REQUIRE(k >= 1 && k <= 64, "dc_knn: k=%d outside [1,64]", k);
     DC_REQUIRE(num_clouds >= 0 && max_cloud_size >= 0, "dc_knn: negative size");
-    DC_REQUIRE(lanes_per_query == 0 || lanes_per_query == 1 || lanes_per_query == 8,
-               "dc_knn: lanes_per_query must be 0 (auto), 1 or 8");
+    DC_REQUIRE(lanes_per_query == 0 || lanes_per_query == 1 || lanes_per_query == 8 || lanes_per_query == 64,
+               "dc_knn: lanes_per_query must be 0 (auto), 1, 8 or 64");
+    DC_REQUIRE(lanes_per_query != 64 || max_cloud_size <= 4096, "dc_knn: the wave-per-query kernel holds <= 4096 points per cloud");
     if (num_clouds == 0 || max_cloud_size == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // auto: wave-per-query selection when a cloud fits the registers of one wave and the bound on the
+    // k-th distance is tight (k <= 40); the sorted-insertion kernel otherwise
+    if (lanes_per_query == 64 || (lanes_per_query == 0 && k <= 40 && max_cloud_size <= 4096))
+        return dispatch_wave(pos, cloud_ptr, num_clouds, max_cloud_size, k, nbr, s);
     if (lanes_per_query == 1) return dispatch_k<1>(pos, cloud_ptr, num_clouds, max_cloud_size, k, nbr, s);
     return dispatch_k<8>(pos, cloud_ptr, num_clouds, max_cloud_size, k, nbr, s);
 }

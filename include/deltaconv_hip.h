@@ -41,7 +41,8 @@ int dc_set_option(int32_t key, int32_t value);
 /* knn_graph(pos, k, batch, loop=True, flow='target_to_source')  (torch_cluster via
  * torch_geometric) -- deltaconv/models/deltanet_base.py:52,63.
  * Order: fp32 ((dx*dx+dy*dy)+dz*dz) ascending, ties by lower index, self included; global ids.
- * Every cloud needs >= k points; k <= 64.  lanes_per_query: 0 = auto, 1 or 8. */
+ * Every cloud needs >= k points; k <= 64.  lanes_per_query: 0 = auto, 64 = wave-per-query selection
+ * kernel (clouds <= 4096 points), 1 or 8 = sorted-insertion kernel. */
 int dc_knn(const float* pos, const int32_t* cloud_ptr, int32_t num_clouds, int32_t max_cloud_size, int32_t k,
            int32_t lanes_per_query, int32_t* nbr, void* stream);
 

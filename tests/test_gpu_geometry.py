@@ -30,7 +30,7 @@ def batch_of(g):
 
 # ---------------------------------------------------------------------------------- kNN
 @pytest.mark.parametrize("name", GEOM)
-@pytest.mark.parametrize("lanes", [1, 8])
+@pytest.mark.parametrize("lanes", [0, 1, 8, 64])
 def test_knn_golden_bit_exact(name, lanes):
     from deltaconv_amd.geometry import Graph
     g = load_golden(name)
@@ -44,12 +44,30 @@ def test_knn_vs_oracle(B, N, k, kw):
     from deltaconv_amd.geometry import Graph
     b = synthetic_batch(B, N, seed=31, **kw)
     ref = geo.knn(b.pos, k, geo.cloud_ptr(b.batch))
-    for lanes in (1, 8):
+    for lanes in (0, 1, 8) + ((64,) if N <= 4096 else ()):     # 64 = wave-per-query selection kernel
         gr = Graph.knn(b.pos.to(DEV), k, b.batch.to(DEV), lanes_per_query=lanes)
         got = gr.nbr.cpu().long()
         bad = (got != ref).any(1).nonzero().flatten()
         assert bad.numel() == 0, f"lanes={lanes}: {bad.numel()} rows differ, first {bad[:3].tolist()}: " \
                                  f"{got[bad[:1]].tolist()} vs {ref[bad[:1]].tolist()}"
+
+
+@pytest.mark.parametrize("N,k,dups", [(1024, 20, 200), (700, 30, 700), (4096, 10, 300), (130, 40, 100)])
+def test_knn_massive_ties(N, k, dups):
+    """`dups` points coincide (and a second clump shares one distance to them): far more than 64 candidates
+    tie at the k-th distance, which sends the wave kernel down its exact radix-select path; ties must come
+    out in index order like the oracle's stable sort."""
+    from deltaconv_amd.geometry import Graph
+    g = torch.Generator().manual_seed(5)
+    pos = torch.randn(2 * N, 3, generator=g)
+    for c in range(2):
+        idx = torch.randperm(N, generator=g)[:dups] + c * N
+        pos[idx] = pos[idx[0]].clone()
+    batch = torch.arange(2).repeat_interleave(N)
+    ref = geo.knn(pos, k, geo.cloud_ptr(batch))
+    for lanes in (0, 8, 64):
+        got = Graph.knn(pos.to(DEV), k, batch.to(DEV), lanes_per_query=lanes).nbr.cpu().long()
+        assert torch.equal(got, ref), f"lanes={lanes}"
 
 
 def test_knn_ragged_and_api():

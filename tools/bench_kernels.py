@@ -61,7 +61,7 @@ def main():
     info = dc.models.deltanet_base._ptr_info(b)
     n, k = b.pos.shape[0], a.k
     E = n * k
-    for lanes in (1, 8):
+    for lanes in (1, 8, 64):
         rec(f"knn lanes={lanes}", timeit(lambda: Graph.knn(b.pos, k, ptr_info=info, lanes_per_query=lanes), 20, 3),
             12 * n + 4 * E)
     graph = Graph.knn(b.pos, k, ptr_info=info)
