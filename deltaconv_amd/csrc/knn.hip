@@ -209,12 +209,10 @@ __global__ __launch_bounds__(64 * WQ_WAVES) void knn_wave_kernel(const float* __
     float* tx = reinterpret_cast<float*>(smem);
     float* ty = tx + NC;
     float* tz = ty + NC;
-    unsigned* scratch = reinterpret_cast<unsigned*>(tz + NC);       // per wave: 64 keys + 64 ids + 64 minima + tau
+    unsigned* scratch = reinterpret_cast<unsigned*>(tz + NC);       // per wave: 64 keys + 64 ids
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned* key_u = scratch + wave * 200;
+    unsigned* key_u = scratch + wave * 128;
     unsigned* key_i = key_u + 64;
-    unsigned* mins = key_i + 64;
-    unsigned* tau_slot = mins + 64;
 
     const int cloud = blockIdx.y;
     const int begin = cloud_ptr[cloud];
@@ -247,20 +245,14 @@ __global__ __launch_bounds__(64 * WQ_WAVES) void knn_wave_kernel(const float* __
             u[j] = __float_as_uint(d2);          // d2 >= +0: the bit pattern orders like the value
             mn = min(mn, u[j]);
         }
-        // ---- upper bound of the k-th distance: k-th smallest of the lane minima
-        wave_lds_sync();                          // previous query's readers are done with the scratch
-        mins[lane] = mn;
-        wave_lds_sync();
-        int c_lt = 0, c_le = 0;
-#pragma unroll 16
-        for (int l = 0; l < 64; ++l) {
-            const unsigned m = mins[l];
-            c_lt += m < mn;
-            c_le += m <= mn;
+        // ---- upper bound of the k-th distance: k-th smallest of the 64 lane minima, by a bitwise
+        // select whose counting is one v_cmp + scalar popcount per bit (no LDS, no cross-lane traffic)
+        unsigned tau = 0;
+        for (int bit = 30; bit >= 0; --bit) {
+            const unsigned trial = tau | (1u << bit);
+            if (__popcll(__ballot(mn < trial)) < k) tau = trial;
         }
-        if (c_lt < k && k <= c_le) *tau_slot = mn;   // every qualifying lane holds the same value
-        wave_lds_sync();
-        const unsigned tau = *tau_slot;
+        wave_lds_sync();                          // previous query's readers are done with the scratch
         // ---- compact candidates <= tau (in index order)
         int base = 0;
 #pragma unroll
@@ -328,7 +320,7 @@ __global__ __launch_bounds__(64 * WQ_WAVES) void knn_wave_kernel(const float* __
 template <int NPL>
 int launch_knn_wave(const float* pos, const int* cloud_ptr, int num_clouds, int max_cloud, int k, int* nbr,
                     hipStream_t stream) {
-    const size_t lds = (size_t)3 * NPL * 64 * sizeof(float) + WQ_WAVES * 200 * sizeof(unsigned);
+    const size_t lds = (size_t)3 * NPL * 64 * sizeof(float) + WQ_WAVES * 128 * sizeof(unsigned);
     dim3 grid(dc_cdiv(max_cloud, WQ_QPB), num_clouds);
     hipLaunchKernelGGL((knn_wave_kernel<NPL>), grid, dim3(64 * WQ_WAVES), lds, stream, pos, cloud_ptr, k, nbr);
     DC_CHECK_LAUNCH("dc_knn");
