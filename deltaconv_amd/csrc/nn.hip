@@ -103,6 +103,7 @@ __global__ __launch_bounds__(TPB) void tile_kernel(long R, int C, int rpc, BODY 
 template <int V>
 struct BnActBody {
     const float *h, *scale, *shift, *res; float* y; long ldh, ldr, ldy; float slope;
+    float* y2; long ldy2;   // optional second destination (the layer output also lands in the concat buffer)
     float sc[V], sh[V];
     __device__ void init(int c0) {
 #pragma unroll
@@ -119,6 +120,7 @@ struct BnActBody {
             for (int j = 0; j < V; ++j) o.v[j] += rr.v[j];
         }
         stv<V>(y + r * ldy + c0, o);
+        if (y2) stv<V>(y2 + r * ldy2 + c0, o);
     }
 };
 
@@ -374,20 +376,36 @@ DC_EXPORT int dc_bn_eval_coeffs(const float* gamma, const float* beta, const flo
 }
 
 // y = leaky_slope(scale*h + shift) (+ residual).  slope = 1 -> identity, 0 -> ReLU.
-DC_EXPORT int dc_bn_act(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift,
-                        float slope, const float* residual, int64_t ldr, float* y, int64_t ldy, void* stream) {
+static int bn_act_impl(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift,
+                       float slope, const float* residual, int64_t ldr, float* y, int64_t ldy, float* y2, int64_t ldy2,
+                       void* stream) {
     DC_REQUIRE(h && scale && shift && y, "dc_bn_act: null pointer");
-    DC_REQUIRE(R >= 0 && C >= 1 && ldh >= C && ldy >= C && (!residual || ldr >= C), "dc_bn_act: bad size");
+    DC_REQUIRE(R >= 0 && C >= 1 && ldh >= C && ldy >= C && (!residual || ldr >= C) && (!y2 || ldy2 >= C),
+               "dc_bn_act: bad size");
     if (R == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool v4 = C % 4 == 0 && ldh % 4 == 0 && ldy % 4 == 0 && al16(h) && al16(y) &&
-                    (!residual || (ldr % 4 == 0 && al16(residual)));
+                    (!residual || (ldr % 4 == 0 && al16(residual))) && (!y2 || (ldy2 % 4 == 0 && al16(y2)));
     if (v4)
-        run_tile<4>(BnActBody<4>{h, scale, shift, residual, y, (long)ldh, (long)ldr, (long)ldy, slope}, R, C, s);
+        run_tile<4>(BnActBody<4>{h, scale, shift, residual, y, (long)ldh, (long)ldr, (long)ldy, slope, y2, (long)ldy2},
+                    R, C, s);
     else
-        run_tile<1>(BnActBody<1>{h, scale, shift, residual, y, (long)ldh, (long)ldr, (long)ldy, slope}, R, C, s);
+        run_tile<1>(BnActBody<1>{h, scale, shift, residual, y, (long)ldh, (long)ldr, (long)ldy, slope, y2, (long)ldy2},
+                    R, C, s);
     DC_CHECK_LAUNCH("dc_bn_act");
     return DC_OK;
+}
+
+DC_EXPORT int dc_bn_act(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift,
+                        float slope, const float* residual, int64_t ldr, float* y, int64_t ldy, void* stream) {
+    return bn_act_impl(h, R, C, ldh, scale, shift, slope, residual, ldr, y, ldy, nullptr, 0, stream);
+}
+
+// Same, writing the result to two destinations (y2 may be NULL).
+DC_EXPORT int dc_bn_act2(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift,
+                         float slope, const float* residual, int64_t ldr, float* y, int64_t ldy, float* y2,
+                         int64_t ldy2, void* stream) {
+    return bn_act_impl(h, R, C, ldh, scale, shift, slope, residual, ldr, y, ldy, y2, ldy2, stream);
 }
 
 // Backward of y = leaky(scale*h + shift): dh (through the batch statistics when training != 0),

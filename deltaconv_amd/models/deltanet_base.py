@@ -2,6 +2,7 @@
 import torch
 
 from ..nn import DeltaConv
+from ..nn.layer import offer_cat
 from ..geometry.graph import Graph
 from ..geometry.grad_div_mls import build_grad_div, build_tangent_basis, estimate_basis
 
@@ -81,7 +82,24 @@ class DeltaNetBase(torch.nn.Module):
         x = data.x if hasattr(data, 'x') and data.x is not None else data.pos   # deltanet_base.py:76
         v = grad @ x                                                             # deltanet_base.py:78
         out = []
-        for conv in self.convs:
-            x, v = conv(x, v, grad, div, graph)
-            out.append(x)
+        # every layer output is written straight into its column block of one [Nt, sum(c_l)] buffer (the
+        # heads concatenate them: deltanet_classification.py:42, deltanet_segmentation.py:58) when all layers
+        # run as fused nodes; otherwise plain tensors
+        widths = [c.out_channels for c in self.convs]
+        fusable = all(c.fuse_layer and c._fusable() is not None and w % 4 == 0 for c, w in zip(self.convs, widths))
+        blocks = None
+        if fusable and x.is_cuda:
+            xall = torch.empty(x.shape[0], sum(widths), dtype=torch.float32, device=x.device)
+            blocks = [(xall, sum(widths[:i])) for i in range(len(widths))]
+            offer_cat(xall, widths)
+        for i, conv in enumerate(self.convs):
+            nxt = self.convs[i + 1] if i + 1 < len(self.convs) else None
+            if blocks is not None:
+                xo, v = conv(x, v, grad, div, graph, next_layer=nxt, out_block=blocks[i])
+                x = conv._chained_x
+                conv._chained_x = None
+                out.append(xo)
+            else:
+                x, v = conv(x, v, grad, div, graph, next_layer=nxt)
+                out.append(x)
         return out

@@ -6,6 +6,7 @@ from .deltanet_base import DeltaNetBase, _ptr_info
 from .pool import embed_and_pool
 from ..nn import MLP, fused
 from ..nn.mlp import Linear
+from ..nn.layer import cat_outputs
 
 
 class DeltaNetClassification(torch.nn.Module):
@@ -26,5 +27,5 @@ class DeltaNetClassification(torch.nn.Module):
     def _forward(self, data):
         conv_out = self.deltanet_base(data)
         # lin_embedding -> [global max | global mean] (deltanet_classification.py:42-49), pooling fused in
-        x = embed_and_pool(self.lin_embedding, torch.cat(conv_out, dim=1), _ptr_info(data), with_mean=True)
+        x = embed_and_pool(self.lin_embedding, cat_outputs(conv_out), _ptr_info(data), with_mean=True)
         return self.classification_head(x)

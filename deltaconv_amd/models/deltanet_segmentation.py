@@ -6,6 +6,7 @@ from .deltanet_base import DeltaNetBase, _ptr_info
 from .pool import embed_and_pool, broadcast_to_points
 from ..nn import MLP, fused
 from ..nn.mlp import Linear
+from ..nn.layer import cat_outputs
 
 
 class DeltaNetSegmentation(torch.nn.Module):
@@ -33,7 +34,7 @@ class DeltaNetSegmentation(torch.nn.Module):
         batch = data.batch
         # lin_global -> global max pool -> broadcast back to the points (deltanet_segmentation.py:58-61)
         info, n = _ptr_info(data), data.pos.shape[0]
-        conv_cat = torch.cat(conv_out, dim=1)
+        conv_cat = cat_outputs(conv_out)
         pooled = embed_and_pool(self.lin_global, conv_cat, info, with_mean=False)
         if self.categorical_vector:
             pooled = torch.cat([pooled, self.lin_categorical(data.category)], dim=1)

@@ -28,6 +28,7 @@ class DeltaConv(torch.nn.Module):
         self.v_mlp = VectorMLP([in_channels * 4 + out_channels * 2] + [out_channels] * depth) if vector else None
 
     fuse_layer = True   # one autograd node per layer (nn/layer.py) when the layer qualifies
+    _chained_x = None
 
     def _fusable(self):
         """depth-1 MLPs with BatchNorm, piecewise-linear activations, ReLU vector non-linearity, no bias."""
@@ -46,20 +47,33 @@ class DeltaConv(torch.nn.Module):
                 return None
         return sm, ss
 
-    def forward(self, x, v, grad, div, edge_index):
+    def forward(self, x, v, grad, div, edge_index, next_layer=None, out_block=None):
+        """next_layer (optional, beyond the reference signature): the DeltaConv that consumes this layer's
+        outputs next; x' and v' are then produced directly inside its operand buffers (no copies).
+        out_block (optional): (buffer [n, W], column offset) of a concatenation buffer; when the layer runs as
+        one fused node x' is ALSO written into that column block, which is returned as x."""
         graph = as_graph(edge_index, grad.graph)
         slopes = self._fusable() if self.fuse_layer else None
         if slopes is None:
             return self.forward_composed(x, v, grad, div, graph)
         bm, bs = self.s_mlp_max[0], self.s_mlp[0]
         bv = self.v_mlp[0] if self.v_mlp is not None else None
+        chain = None
+        if (isinstance(next_layer, DeltaConv) and next_layer.fuse_layer and next_layer.in_channels == self.out_channels
+                and next_layer._fusable() is not None and self.out_channels % 4 == 0):
+            co = self.out_channels
+            chain = (4 * co, 2 * co + next_layer.out_channels
+                     if (bv is not None and next_layer.v_mlp is not None and next_layer.out_channels % 4 == 0) else None)
         cfg = LayerCfg(graph, grad, div, bm[1].bn, bs[1].bn, bv[1].batchnorm.bn if bv is not None else None,
-                       self.centralized, slopes[0], slopes[1], bv is not None)
+                       self.centralized, slopes[0], slopes[1], bv is not None, chain, out_block)
         vb = bv[1].batchnorm.bn if bv is not None else None
-        x_new, v_new = DeltaConvLayerFn.apply(
+        x_new, v_new, x_dup = DeltaConvLayerFn.apply(
             x, v, bm[0].weight, bm[1].bn.weight, bm[1].bn.bias, bs[0].weight, bs[1].bn.weight, bs[1].bn.bias,
             bv[0].weight if bv is not None else None, vb.weight if vb is not None else None,
             vb.bias if vb is not None else None, cfg)
+        if out_block is not None:
+            self._chained_x = x_new          # what the next layer consumes (lives in its operand buffer)
+            return x_dup, (v_new if bv is not None else v)
         return x_new, (v_new if bv is not None else v)
 
     def forward_composed(self, x, v, grad, div, edge_index):

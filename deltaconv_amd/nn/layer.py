@@ -35,12 +35,38 @@ def _rows(t):
 
 
 class LayerCfg:
-    """Non-tensor state of one call: graph, operators, BatchNorm modules, flags."""
+    """Non-tensor state of one call: graph, operators, BatchNorm modules, flags.
+    chain = (width of the next layer's s_mlp operand, width of its v_mlp operand or None): the layer then
+    writes x' / v' straight into the left columns of those operands (allocated here, adopted by the next
+    layer through `_CHAIN`), so the next layer's `[x | ...]` / `[v | ...]` buffers need no copy."""
 
-    def __init__(self, graph, grad, div, bn_m, bn_s, bn_v, centralized, slope_m, slope_s, vector):
+    def __init__(self, graph, grad, div, bn_m, bn_s, bn_v, centralized, slope_m, slope_s, vector, chain=None,
+                 dup=None):
         self.graph, self.grad, self.div = graph, grad, div
         self.bn_m, self.bn_s, self.bn_v = bn_m, bn_s, bn_v
         self.centralized, self.slope_m, self.slope_s, self.vector = centralized, slope_m, slope_s, vector
+        self.chain = chain
+        self.dup = dup     # (buffer [n, sum co], column offset): x' is written into that column block as well
+
+
+# operand buffers handed from one layer to the next: data_ptr of the view -> buffer.  The consumer pops its
+# entry; entries that are never consumed (the next layer was not called) are dropped by the size cap.
+_CHAIN = {}
+
+
+def _offer(view, buf):
+    if len(_CHAIN) >= 16:
+        _CHAIN.clear()
+    _CHAIN[view.data_ptr()] = buf
+
+
+def _adopt(t, rows, cols, width):
+    """The chain buffer [rows, width] whose left `cols` columns ARE `t`, or None."""
+    buf = _CHAIN.pop(t.data_ptr(), None)
+    if (buf is not None and tuple(buf.shape) == (rows, width) and tuple(t.shape) == (rows, cols)
+            and t.stride(0) == width and t.stride(1) == 1 and t.dtype == _F32 and buf.data_ptr() == t.data_ptr()):
+        return buf
+    return None
 
 
 def _bn_mode(bn):
@@ -78,7 +104,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
     def forward(ctx, x, v, Wm, gm, bm, Ws, gs, bs, Wv, gv, bv, cfg):
         g = cfg.graph
         n, k = g.n, g.k
-        x, v = _c(x), _c(v)
+        (x, ldx), (v, ldv) = _rows(x), _rows(v)
         dev = x.device
         ci, co = x.shape[1], Wm.shape[0]
         f32 = dict(dtype=_F32, device=dev)
@@ -113,26 +139,45 @@ class DeltaConvLayerFn(torch.autograd.Function):
             max_saved = (hm, arg)
 
         # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)
-        x_cat = torch.empty(n, 4 * ci, **f32)
-        x_cat[:, :ci].copy_(x)
-        call("dc_apply_div_curl_norm", D, g.nbr, n, k, v, ci, ci, x_cat[:, ci:], 4 * ci)
+        x_cat = _adopt(x, n, ci, 4 * ci)
+        if x_cat is None:
+            x_cat = torch.empty(n, 4 * ci, **f32)
+            x_cat[:, :ci].copy_(x)
+        call("dc_apply_div_curl_norm", D, g.nbr, n, k, v, ci, ldv, x_cat[:, ci:], 4 * ci)
         hs = x_cat @ Ws.t()
         coef_s, use_s = _bn_coeffs(hs, n, co, co, cfg.bn_s, gs, bs, dev)
-        x_new = torch.empty(n, co, **f32)
-        call("dc_bn_act", hs, n, co, co, coef_s[2], coef_s[3], cfg.slope_s, x_max, co, x_new, co)
+        if cfg.chain is not None:
+            xbuf = torch.empty(n, cfg.chain[0], **f32)
+            x_new = xbuf[:, :co]
+            _offer(x_new, xbuf)
+        else:
+            x_new = torch.empty(n, co, **f32)
+        ldxn = x_new.stride(0)
+        # the block view is created HERE (inside the node, like the chain views): an outside view object
+        # must not be returned as an output of an autograd Function
+        x_dup = cfg.dup[0][:, cfg.dup[1]:cfg.dup[1] + co] if cfg.dup is not None else None
+        call("dc_bn_act2", hs, n, co, co, coef_s[2], coef_s[3], cfg.slope_s, x_max, co, x_new, ldxn, x_dup,
+             x_dup.stride(0) if x_dup is not None else 0)
 
         # ---- vector stream: [v | hodge v | grad x'] and its 90-degree rotation -> v_mlp (deltaconv.py:64-68)
         if cfg.vector:
             K = 2 * ci + co
-            v_cat = torch.empty(2 * n, K, **f32)
-            v_cat[:, :ci].copy_(v)
+            v_cat = _adopt(v, 2 * n, ci, K)
+            if v_cat is None:
+                v_cat = torch.empty(2 * n, K, **f32)
+                v_cat[:, :ci].copy_(v)
             call("dc_apply_hodge", G, g.nbr, n, k, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
-            call("dc_apply_grad", G, g.nbr, n, k, x_new, co, co, v_cat[:, 2 * ci:], K)
+            call("dc_apply_grad", G, g.nbr, n, k, x_new, co, ldxn, v_cat[:, 2 * ci:], K)
             Wst = torch.cat([Wv[:, :K], Wv[:, K:]], dim=0)            # [2co, K]: the I_J fold (mlp.VectorBlock)
             PQ = v_cat @ Wst.t()                                      # [2n, 2co] = [P | Q]
             coef_v, use_v = _bn_coeffs(PQ, n, co, 2 * co, cfg.bn_v, gv, bv, dev, vn_combine=1)
-            v_new = torch.empty(2 * n, co, **f32)
-            call("dc_vn_apply", PQ, n, co, 2 * co, 1, coef_v[2], coef_v[3], v_new, co)
+            if cfg.chain is not None and cfg.chain[1] is not None:
+                vbuf = torch.empty(2 * n, cfg.chain[1], **f32)
+                v_new = vbuf[:, :co]
+                _offer(v_new, vbuf)
+            else:
+                v_new = torch.empty(2 * n, co, **f32)
+            call("dc_vn_apply", PQ, n, co, 2 * co, 1, coef_v[2], coef_v[3], v_new, v_new.stride(0))
         else:
             v_cat = PQ = coef_v = Wst = None
             use_v = False
@@ -142,10 +187,10 @@ class DeltaConvLayerFn(torch.autograd.Function):
         ctx.flags = (use_m, use_s, use_v, ci, co)
         ctx.max_saved = max_saved
         ctx.save_for_backward(x, v, Wm, gm, Ws, gs, Wst, gv, coef_m, x_cat, hs, coef_s, v_cat, PQ, coef_v)
-        return x_new, v_new
+        return x_new, v_new, x_dup
 
     @staticmethod
-    def backward(ctx, dx_new, dv_new):
+    def backward(ctx, dx_new, dv_new, dx_dup):
         cfg = ctx.cfg
         x, v, Wm, gm, Ws, gs, Wst, gv, coef_m, x_cat, hs, coef_s, v_cat, PQ, coef_v = ctx.saved_tensors
         use_m, use_s, use_v, ci, co = ctx.flags
@@ -158,7 +203,13 @@ class DeltaConvLayerFn(torch.autograd.Function):
         need_x, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         dWv = dgv = dbv = None
 
-        dxn = _c(dx_new) if dx_new is not None else torch.zeros(n, co, **f32)
+        # d x' arrives from the next layer (dx_new) and / or from the concatenated embedding input (dx_dup)
+        if dx_new is not None and dx_dup is not None:
+            (dxn, lddx), private = _rows(dx_new + dx_dup), True
+        elif dx_new is not None or dx_dup is not None:
+            (dxn, lddx), private = _rows(dx_new if dx_new is not None else dx_dup), False
+        else:
+            dxn, lddx, private = torch.zeros(n, co, **f32), co, True
         dv_cat = None
         if cfg.vector and dv_new is not None:
             K = 2 * ci + co
@@ -172,15 +223,15 @@ class DeltaConvLayerFn(torch.autograd.Function):
             dWv = torch.cat([dWst[:co], dWst[co:]], dim=1)            # back to the [co, 2K] layout of v_mlp
             dv_cat = dPQ @ Wst                                        # [2n, K]
             # grad^T of the `grad @ x'` block accumulates into d x'
-            if dx_new is not None:
-                dxn = dxn.clone() if dxn.data_ptr() == dx_new.data_ptr() else dxn
-            call("dc_apply_grad_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, dxn, co, 1)
+            if not private:                    # accumulated into below: never touch autograd's buffer
+                dxn, lddx = (dxn.clone() if dxn.is_contiguous() else dxn.contiguous()), co
+            call("dc_apply_grad_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, dxn, lddx, 1)
 
         # ---- s_mlp block (residual: d x_max = d x')
         dhs = torch.empty_like(hs)
         dgs, dbs = torch.empty(co, **f32), torch.empty(co, **f32)
         ws, nb = fused._ws(n, co, dev)
-        call("dc_bn_act_backward", dxn, co, hs, co, n, co, coef_s[2], coef_s[3], coef_s[0], coef_s[1], gs, cfg.slope_s,
+        call("dc_bn_act_backward", dxn, lddx, hs, co, n, co, coef_s[2], coef_s[3], coef_s[0], coef_s[1], gs, cfg.slope_s,
              int(use_s), dhs, co, dgs, dbs, ws, nb)
         dWs = fused.gemm_tn(dhs, x_cat)
         d_xcat = dhs @ Ws                                             # [n, 4ci] = d[x | div | curl | norm]
@@ -191,11 +242,11 @@ class DeltaConvLayerFn(torch.autograd.Function):
         if need_v:
             if dv_cat is not None:          # accumulate on top of d v from the v_mlp operand, in place
                 dv = dv_cat[:, :ci]
-                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, ci,
+                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0),
                      dv, 2 * ci + co, 1)
             else:
                 dv = torch.empty(2 * n, ci, **f32)
-                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, ci,
+                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0),
                      dv, ci, 0)
 
         # ---- max-aggregation branch (d x_max = d x')
@@ -204,14 +255,14 @@ class DeltaConvLayerFn(torch.autograd.Function):
         if cfg.centralized:
             y0, stat, args = ctx.max_saved
             dzs, dy0 = torch.empty(n, co, **f32), torch.empty(n, co, **f32)
-            call("dc_edge_max_backward", dxn, co, y0, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
+            call("dc_edge_max_backward", dxn, lddx, y0, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
                  stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slope_m, int(use_m), dzs, dy0, co, dgm, dbm,
                  ws, nb)
             dpre = dy0
         else:
             hm, arg = ctx.max_saved
             dym = torch.empty(n, co, **f32)
-            call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, co, dym, co, 0)
+            call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, lddx, dym, co, 0)
             dpre = torch.empty_like(hm)
             call("dc_bn_act_backward", dym, co, hm, co, n, co, coef_m[2], coef_m[3], coef_m[0], coef_m[1], gm,
                  cfg.slope_m, int(use_m), dpre, co, dgm, dbm, ws, nb)
@@ -220,3 +271,45 @@ class DeltaConvLayerFn(torch.autograd.Function):
         nz = lambda t, ref: t if ref is not None else None
         return (dx, dv, dWm, nz(dgm, gm), nz(dbm, gm), dWs, nz(dgs, gs), nz(dbs, gs), dWv, nz(dgv, gv), nz(dbv, gv),
                 None)
+
+
+# ---- concatenation of the layer outputs without a copy ---------------------------------------------
+_CATBUF = {}   # data_ptr of the first block -> (buffer [n, sum co], [(data_ptr, width), ...])
+
+
+def offer_cat(buf, widths):
+    if len(_CATBUF) >= 8:
+        _CATBUF.clear()
+    offs = [sum(widths[:i]) for i in range(len(widths))]
+    _CATBUF[buf.data_ptr()] = (buf, [(buf.data_ptr() + 4 * o, w) for o, w in zip(offs, widths)])
+
+
+class _ViewCat(torch.autograd.Function):
+    """cat(xs, dim=1) when xs are the consecutive column blocks of one buffer: returns the buffer."""
+
+    @staticmethod
+    def forward(ctx, holder, *xs):
+        buf = holder[0]
+        ctx.widths = [x.shape[1] for x in xs]
+        return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset(),
+                                                                       buf.shape, buf.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, off:off + w])
+            off += w
+        return (None, *outs)
+
+
+def cat_outputs(xs):
+    """torch.cat(xs, dim=1) (deltanet_classification.py:42, deltanet_segmentation.py:58) -- free when the
+    backbone already wrote every layer output into its column block of one buffer (`LayerCfg.dup`)."""
+    hit = _CATBUF.pop(xs[0].data_ptr(), None) if len(xs) else None
+    if hit is not None:
+        buf, blocks = hit
+        if len(blocks) == len(xs) and all(x.data_ptr() == p and x.shape[1] == w and x.stride(0) == buf.shape[1]
+                                          for x, (p, w) in zip(xs, blocks)):
+            return _ViewCat.apply((buf,), *xs)
+    return torch.cat(xs, dim=1)

@@ -127,6 +127,10 @@ int dc_bn_eval_coeffs(const float* gamma, const float* beta, const float* runnin
 /* y = leaky_slope(scale*h + shift) (+ residual);  slope 1 = identity, 0 = ReLU */
 int dc_bn_act(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift, float slope,
               const float* residual, int64_t ldr, float* y, int64_t ldy, void* stream);
+/* dc_bn_act with a second destination y2 (may be NULL): a layer output that is also a column block of the
+ * concatenated embedding input (`torch.cat(conv_out, dim=1)`, models/deltanet_classification.py:42) */
+int dc_bn_act2(const float* h, int64_t R, int32_t C, int64_t ldh, const float* scale, const float* shift, float slope,
+               const float* residual, int64_t ldr, float* y, int64_t ldy, float* y2, int64_t ldy2, void* stream);
 /* backward of dc_bn_act (through the batch statistics when training != 0); dgamma/dbeta may be NULL */
 int dc_bn_act_backward(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
                        const float* scale, const float* shift, const float* mean, const float* invstd,
