@@ -43,10 +43,23 @@ struct BnBwdF {  // dz, dz*xhat
         }
     }
 };
-// vector block: "row" = point i; input rows 2i, 2i+1 of pq (combine: [P | Q] with 2*co columns)
+// vector block: "row" = point i; input rows 2i, 2i+1 of pq.  combine 1: [P | Q] blocked (2*co columns);
+// combine 2: P and Q interleaved (column 2c = P_c, 2c+1 = Q_c) -- what `v_cat @ W.view(2co, K)^T` produces
+// from the reference's [co, 2K] weight without re-stacking it.
 template <int V>
 __device__ __forceinline__ void vn_load_y(const float* in, long ld, long i, int c0, int co, int combine, FV<V>& yu,
                                           FV<V>& yv) {
+    if (combine == 2) {
+        const float* ru = in + (2 * i) * ld + 2 * c0;
+        const float* rv = in + (2 * i + 1) * ld + 2 * c0;
+        const FV<V> u0 = ldv<V>(ru), u1 = ldv<V>(ru + V), v0 = ldv<V>(rv), v1 = ldv<V>(rv + V);
+        float eu[2 * V], ev[2 * V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) { eu[j] = u0.v[j]; eu[V + j] = u1.v[j]; ev[j] = v0.v[j]; ev[V + j] = v1.v[j]; }
+#pragma unroll
+        for (int j = 0; j < V; ++j) vn_combine(eu[2 * j], eu[2 * j + 1], ev[2 * j], ev[2 * j + 1], yu.v[j], yv.v[j]);
+        return;
+    }
     const FV<V> pu = ldv<V>(in + (2 * i) * ld + c0), pv = ldv<V>(in + (2 * i + 1) * ld + c0);
     if (combine) {
         const FV<V> qu = ldv<V>(in + (2 * i) * ld + co + c0), qv = ldv<V>(in + (2 * i + 1) * ld + co + c0);
@@ -191,6 +204,21 @@ struct VnBwdBody {
             vn_bwd_dy(yu.v[j], yv.v[j], du.v[j], dv.v[j], sc[j], sh[j], mu[j], is[j], gi[j], a1[j], a2[j], training,
                       gu.v[j], gv.v[j]);
         // d[P|Q]: row u = [dy_u | dy_v], row v = [dy_v | -dy_u]   (transpose of vn_combine)
+        if (combine == 2) {                      // interleaved pairs (dP_c, dQ_c)
+            float eu[2 * V], ev[2 * V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                eu[2 * j] = gu.v[j]; eu[2 * j + 1] = gv.v[j];
+                ev[2 * j] = gv.v[j]; ev[2 * j + 1] = -gu.v[j];
+            }
+            FV<V> a, b, c, d;
+#pragma unroll
+            for (int j = 0; j < V; ++j) { a.v[j] = eu[j]; b.v[j] = eu[V + j]; c.v[j] = ev[j]; d.v[j] = ev[V + j]; }
+            float* ru = din + (2 * i) * lddi + 2 * c0;
+            float* rv = din + (2 * i + 1) * lddi + 2 * c0;
+            stv<V>(ru, a); stv<V>(ru + V, b); stv<V>(rv, c); stv<V>(rv + V, d);
+            return;
+        }
         stv<V>(din + (2 * i) * lddi + c0, gu);
         stv<V>(din + (2 * i + 1) * lddi + c0, gv);
         if (combine) {

@@ -168,16 +168,16 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 v_cat[:, :ci].copy_(v)
             call("dc_apply_hodge", G, g.nbr, n, k, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
             call("dc_apply_grad", G, g.nbr, n, k, x_new, co, ldxn, v_cat[:, 2 * ci:], K)
-            Wst = torch.cat([Wv[:, :K], Wv[:, K:]], dim=0)            # [2co, K]: the I_J fold (mlp.VectorBlock)
-            PQ = v_cat @ Wst.t()                                      # [2n, 2co] = [P | Q]
-            coef_v, use_v = _bn_coeffs(PQ, n, co, 2 * co, cfg.bn_v, gv, bv, dev, vn_combine=1)
+            Wst = Wv.view(2 * co, K)                                 # rows (c, half): the I_J fold, a free view
+            PQ = v_cat @ Wst.t()                                      # [2n, 2co], columns interleaved (P_c, Q_c)
+            coef_v, use_v = _bn_coeffs(PQ, n, co, 2 * co, cfg.bn_v, gv, bv, dev, vn_combine=2)
             if cfg.chain is not None and cfg.chain[1] is not None:
                 vbuf = torch.empty(2 * n, cfg.chain[1], **f32)
                 v_new = vbuf[:, :co]
                 _offer(v_new, vbuf)
             else:
                 v_new = torch.empty(2 * n, co, **f32)
-            call("dc_vn_apply", PQ, n, co, 2 * co, 1, coef_v[2], coef_v[3], v_new, v_new.stride(0))
+            call("dc_vn_apply", PQ, n, co, 2 * co, 2, coef_v[2], coef_v[3], v_new, v_new.stride(0))
         else:
             v_cat = PQ = coef_v = Wst = None
             use_v = False
@@ -217,10 +217,9 @@ class DeltaConvLayerFn(torch.autograd.Function):
             dPQ = torch.empty_like(PQ)
             dgv, dbv = torch.empty(co, **f32), torch.empty(co, **f32)
             ws, nb = fused._ws(n, co, dev)
-            call("dc_vn_backward", dvn, lddvn, PQ, 2 * co, 1, n, co, coef_v[2], coef_v[3], coef_v[0], coef_v[1], gv,
+            call("dc_vn_backward", dvn, lddvn, PQ, 2 * co, 2, n, co, coef_v[2], coef_v[3], coef_v[0], coef_v[1], gv,
                  int(use_v), dPQ, 2 * co, dgv, dbv, ws, nb)
-            dWst = fused.gemm_tn(dPQ, v_cat)                                    # [2co, K]
-            dWv = torch.cat([dWst[:co], dWst[co:]], dim=1)            # back to the [co, 2K] layout of v_mlp
+            dWv = fused.gemm_tn(dPQ, v_cat).view(co, 2 * K)           # [2co, K] rows (c, half) = the [co, 2K] layout
             dv_cat = dPQ @ Wst                                        # [2n, K]
             # grad^T of the `grad @ x'` block accumulates into d x'
             if not private:                    # accumulated into below: never touch autograd's buffer
@@ -267,7 +266,10 @@ class DeltaConvLayerFn(torch.autograd.Function):
             call("dc_bn_act_backward", dym, co, hm, co, n, co, coef_m[2], coef_m[3], coef_m[0], coef_m[1], gm,
                  cfg.slope_m, int(use_m), dpre, co, dgm, dbm, ws, nb)
         dWm = fused.gemm_tn(dpre, x)
-        dx = torch.addmm(d_xcat[:, :ci], dpre, Wm) if need_x else None
+        dx = None
+        if need_x:                            # d x = d_xcat[:, :ci] + dpre Wm, accumulated in place (GEMM with ldc = 4 ci)
+            dx = d_xcat[:, :ci]
+            dx.addmm_(dpre, Wm)
         nz = lambda t, ref: t if ref is not None else None
         return (dx, dv, dWm, nz(dgm, gm), nz(dbm, gm), dWs, nz(dgs, gs), nz(dbs, gs), dWv, nz(dgv, gv), nz(dbv, gv),
                 None)

@@ -41,16 +41,16 @@ class VectorBlock(Seq):
 
     def forward_vcat(self, v_cat):
         """Same as forward(I_J(v_cat)) without materialising I_J: with W = [W1 | W2],
-        W I_J(a) = (W1 a_u - W2 a_v, W1 a_v + W2 a_u); one GEMM a [W1^T | W2^T] -> [P | Q] and the
-        combination happens inside the fused non-linearity kernel."""
+        W I_J(a) = (W1 a_u - W2 a_v, W1 a_v + W2 a_u); one GEMM with the weight viewed as [2co, K] (rows
+        (c, half), no copy) -> interleaved (P_c, Q_c) columns, combined inside the fused non-linearity kernel."""
         w = self[0].weight
         k = v_cat.shape[1]
         assert w.shape[1] == 2 * k, "first vector block expects I_J(v_cat) (2x the channels of v_cat)"
         if not isinstance(self[1].nonlin, torch.nn.ReLU):
             from ..geometry.operators import I_J
             return self.forward(I_J(v_cat))
-        pq = fused.linear(v_cat, torch.cat([w[:, :k], w[:, k:]], dim=0))     # [2N, 2*co]
-        return self[1](pq, combine=True)
+        pq = fused.linear(v_cat, w.view(2 * w.shape[0], k))    # [2N, 2*co], columns interleaved (P_c, Q_c)
+        return self[1](pq, combine=2)
 
 
 def MLP(channels, bias=False, nonlin=LeakyReLU(negative_slope=0.2)):

@@ -44,8 +44,8 @@ class VectorNonLin(torch.nn.Module):
         if self.batchnorm is not None:
             self.batchnorm.reset_parameters()
 
-    def forward(self, x: Tensor, combine: bool = False) -> Tensor:
-        """x: [2N,C]; with combine=True x is [2N,2C] = [P | Q] (see fused.py / mlp.VectorBlock)."""
+    def forward(self, x: Tensor, combine: int = 0) -> Tensor:
+        """x: [2N,C]; combine=1: x is [2N,2C] = [P | Q]; combine=2: P/Q interleaved (fused.py / mlp.VectorBlock)."""
         if isinstance(self.nonlin, torch.nn.ReLU):
             return fused.vector_nonlin(x, combine, self)
         # any other non-linearity: same formula through torch ops on the GPU

@@ -138,7 +138,9 @@ int dc_bn_act_backward(const float* dy, int64_t lddy, const float* h, int64_t ld
                        float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 /* vector block.  in: combine != 0 -> [2n, 2co] = [P | Q], the Linear applied to v_cat (NOT to
  * I_J(v_cat)) with the weight halves stacked, y_u = P_u - Q_v, y_v = P_v + Q_u
- * (deltaconv/geometry/operators.py:9-21 folded into the epilogue); combine == 0 -> [2n, co] = y. */
+ * (deltaconv/geometry/operators.py:9-21 folded into the epilogue); combine == 0 -> [2n, co] = y;
+ * combine == 2 -> P and Q interleaved (column 2c = P_c, 2c+1 = Q_c), i.e. v_cat @ W.view(2co, K)^T for the
+ * reference's [co, 2K] weight of the first VectorMLP layer, no re-stacking of W. */
 int dc_vn_stats(const float* in, int64_t n, int32_t co, int64_t ld, int32_t combine, const float* gamma,
                 const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* mean,
                 float* invstd, float* scale, float* shift, void* workspace, size_t workspace_bytes, void* stream);

@@ -329,3 +329,38 @@ def test_fused_loss_rejects_bad_shapes():
         calc_loss(torch.zeros(0, 4, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV))
     bad = calc_loss(torch.zeros(3, 4, device=DEV), torch.tensor([0, 9, 1], device=DEV))   # label out of range
     assert torch.isnan(bad)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("n,co", [(300, 8), (257, 5)])
+def test_vector_nonlin_combine_layouts(mode, n, co):
+    """[P | Q] blocked (combine=1) and (P_c, Q_c) interleaved (combine=2) inputs give the same result and
+    input gradient as the plain layout (combine=0) applied to y = (P_u - Q_v, P_v + Q_u)."""
+    from deltaconv_amd.nn import fused
+    torch.manual_seed(n + co + mode)
+    vn = oracle.nn.VectorNonLin(co, batchnorm=oracle.nn.BatchNorm1d(co))
+    import deltaconv_amd as dc
+    ours = dc.nn.VectorNonLin(co, batchnorm=dc.nn.BatchNorm1d(co)).to(DEV).train()
+    ours.load_state_dict(vn.state_dict())
+    P, Q = torch.randn(2 * n, co, device=DEV), torch.randn(2 * n, co, device=DEV)
+    y = torch.empty(2 * n, co, device=DEV)
+    y[0::2] = P[0::2] - Q[1::2]
+    y[1::2] = P[1::2] + Q[0::2]
+    y.requires_grad_(True)
+    pq = (torch.cat([P, Q], 1) if mode == 1 else torch.stack([P, Q], 2).reshape(2 * n, 2 * co)).requires_grad_(True)
+    w = torch.randn(2 * n, co, device=DEV)
+    out0 = fused.vector_nonlin(y, 0, ours)
+    (out0 * w).sum().backward()
+    ours2 = dc.nn.VectorNonLin(co, batchnorm=dc.nn.BatchNorm1d(co)).to(DEV).train()
+    ours2.load_state_dict(vn.state_dict())
+    out = fused.vector_nonlin(pq, mode, ours2)
+    (out * w).sum().backward()
+    assert rel_err(out, out0) < 1e-6
+    g = pq.grad.view(2 * n, 2, co) if mode == 1 else pq.grad.view(2 * n, co, 2).transpose(1, 2)
+    dP, dQ = g[:, 0], g[:, 1]
+    # y_u = P_u - Q_v, y_v = P_v + Q_u  =>  dP = dy, dQ_u = dy_v, dQ_v = -dy_u
+    assert rel_err(dP, y.grad) < 1e-5
+    dq_ref = torch.empty_like(y.grad)
+    dq_ref[0::2] = y.grad[1::2]
+    dq_ref[1::2] = -y.grad[0::2]
+    assert rel_err(dQ, dq_ref) < 1e-5
