@@ -175,6 +175,41 @@ DC_HD void knn_max_fwd(long i, int c0, const int* ids, int k, const float* h, lo
     for (int q = 0; q < V; ++q) arg[i * lda + c0 + q] = slot[q];
 }
 
+// Same with the BatchNorm + activation of the producing MLP block folded in:
+//   out[i,c] = max_s y[nbr[i,s], c],  y = act(scale_c * h + shift_c)   (nn/mlp.py:9 + nn/deltaconv.py:54)
+// y is evaluated per candidate (2 flops on top of a 16-byte gather), so values, ties and the first-maximal-slot
+// rule are exactly those of materialising y first -- minus one [Nt,C] write and read.
+template <int V>
+DC_HD void knn_max_affine_fwd(long i, int c0, const int* ids, int k, const float* h, long ldh, const float* scale,
+                              const float* shift, float slope, float* out, long ldo, unsigned char* arg, long lda) {
+    float sc[V], sh[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { sc[q] = scale[c0 + q]; sh[q] = shift[c0 + q]; }
+    Vec<V> best = vload<V>(h + (long)ids[0] * ldh + c0);
+    unsigned char slot[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        const float z = fmaf(sc[q], best.v[q], sh[q]);
+        best.v[q] = z > 0.f ? z : slope * z;
+        slot[q] = 0;
+    }
+#pragma unroll 4
+    for (int s = 1; s < k; ++s) {
+        const Vec<V> hv = vload<V>(h + (long)ids[s] * ldh + c0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float z = fmaf(sc[q], hv.v[q], sh[q]);
+            const float y = z > 0.f ? z : slope * z;
+            const bool up = y > best.v[q];
+            best.v[q] = up ? y : best.v[q];
+            slot[q] = up ? (unsigned char)s : slot[q];
+        }
+    }
+    vstore<V>(out + i * ldo + c0, best);
+#pragma unroll
+    for (int q = 0; q < V; ++q) arg[i * lda + c0 + q] = slot[q];
+}
+
 // ---- transposed applies (backward of the above; the operators carry no gradient) ---------------
 // A column of the transposed operator = the in-edges of point j, ascending edge id.  Each op is an
 // accumulator: init(), step(i, s, g, c0) once per in-edge (i = source point, s = its slot,

@@ -132,10 +132,8 @@ class DeltaConvLayerFn(torch.autograd.Function):
         else:
             hm = x @ Wm.t()
             coef_m, use_m = _bn_coeffs(hm, n, co, co, cfg.bn_m, gm, bm, dev)
-            ym = torch.empty(n, co, **f32)
-            call("dc_bn_act", hm, n, co, co, coef_m[2], coef_m[3], cfg.slope_m, None, co, ym, co)
-            arg = torch.empty(n, co, dtype=torch.uint8, device=dev)
-            call("dc_knn_max", g.nbr, n, k, ym, co, co, x_max, co, arg)
+            arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
+            call("dc_knn_max_affine", g.nbr, n, k, hm, co, co, coef_m[2], coef_m[3], cfg.slope_m, x_max, co, arg)
             max_saved = (hm, arg)
 
         # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)

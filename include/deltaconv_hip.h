@@ -106,6 +106,12 @@ int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, const int32_t
 /* out[i,c] = max_s h[nbr[i,s],c]; arg[Nt,C] = first maximal slot (k <= 255) */
 int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float* out,
                int64_t ldo, uint8_t* arg, void* stream);
+/* out[i,c] = max_s leaky_slope(scale_c * h[nbr[i,s],c] + shift_c): the BatchNorm + activation of s_mlp_max
+ * (nn/mlp.py:9) folded into the max-aggregation gather (nn/deltaconv.py:54); same values, ties and slots
+ * as dc_bn_act followed by dc_knn_max.  Backward: dc_knn_max_backward then dc_bn_act_backward. */
+int dc_knn_max_affine(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh,
+                      const float* scale, const float* shift, float slope, float* out, int64_t ldo, uint8_t* arg,
+                      void* stream);
 int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const uint8_t* arg,
                         const float* dout, int32_t C, int64_t ldo, float* dh, int64_t ldh, int32_t accumulate,
                         void* stream);

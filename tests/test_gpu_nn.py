@@ -364,3 +364,27 @@ def test_vector_nonlin_combine_layouts(mode, n, co):
     dq_ref[0::2] = y.grad[1::2]
     dq_ref[1::2] = -y.grad[0::2]
     assert rel_err(dQ, dq_ref) < 1e-5
+
+
+@pytest.mark.parametrize("n_clouds,N,k,C,slope", [(2, 300, 20, 64, 0.2), (1, 257, 10, 5, 0.2), (2, 128, 30, 128, 0.0)])
+def test_knn_max_affine_equals_bn_act_then_max(n_clouds, N, k, C, slope):
+    """dc_knn_max_affine (BatchNorm scale/shift + LeakyReLU evaluated inside the gather) == dc_bn_act followed by
+    dc_knn_max, bit for bit: values AND first-maximal slots (negative, zero and tiny scales included)."""
+    from deltaconv_amd._lib import lib
+    from deltaconv_amd.geometry import Graph
+    from deltaconv_amd.data import synthetic_batch
+    b = synthetic_batch(n_clouds, N, seed=77).to(DEV)
+    g = Graph.knn(b.pos, k, b.batch)
+    n = b.pos.shape[0]
+    torch.manual_seed(C)
+    h = torch.randn(n, C, device=DEV).round(decimals=1)              # plenty of exact ties
+    scale = torch.randn(C, device=DEV)
+    scale[0], scale[1 % C], scale[2 % C] = 0.0, -0.7, 1e-9            # constant column, min instead of max, rounding ties
+    shift = torch.randn(C, device=DEV)
+    y = torch.empty_like(h)
+    lib.call("dc_bn_act", h, n, C, C, scale, shift, slope, None, C, y, C)
+    o1, a1 = torch.empty_like(h), torch.empty(n, C, dtype=torch.uint8, device=DEV)
+    lib.call("dc_knn_max", g.nbr, n, k, y, C, C, o1, C, a1)
+    o2, a2 = torch.empty_like(h), torch.empty(n, C, dtype=torch.uint8, device=DEV)
+    lib.call("dc_knn_max_affine", g.nbr, n, k, h, C, C, scale, shift, slope, o2, C, a2)
+    assert torch.equal(o1, o2) and torch.equal(a1, a2)
