@@ -257,7 +257,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N=1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out))
     if use_dist:
