@@ -8,7 +8,6 @@ category, num_graphs`` and ``.to(device)``.
 smooth closed surface r = 1 + 0.25 sin(3 theta) cos(2 phi) with analytic normals, then the
 reference's NormalizeScale semantics (transforms/normalize_scale.py:13-19).
 """
-import math
 import torch
 
 

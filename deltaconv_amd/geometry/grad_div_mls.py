@@ -9,7 +9,7 @@ import torch
 
 from .._lib import lib, require_gpu
 from .. import _ops
-from .graph import Graph, as_graph, _ptr_from_batch
+from .graph import Graph, _ptr_from_batch
 
 EPS = 1e-5
 

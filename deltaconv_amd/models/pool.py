@@ -28,7 +28,6 @@ def embed_and_pool(mlp, x, ptr_info, with_mean):
     """``pool(mlp(x))`` for the embedding MLP in front of the global pooling.  With equal-size clouds
     and a single [Linear -> BatchNorm -> piecewise-linear] block the BatchNorm/activation is fused with
     the pooling (the [Nt, E] activation is never written); otherwise the plain composition."""
-    import torch.nn.functional as F
     from ..nn import fused
     from ..nn.mlp import MLPBlock
     _, nc, mx = ptr_info

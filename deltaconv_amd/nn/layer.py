@@ -9,7 +9,13 @@ owns its buffers:
   leading dimensions) -- no ``torch.cat``;
 * in the backward pass every transposed apply accumulates in place (``accumulate=1``) into the
   gradient buffer of the tensor it belongs to -- no autograd ``add`` kernels, no zero fills;
-* the residual ``x_max + s_mlp(...)`` is folded into the BatchNorm/LeakyReLU kernel.
+* the residual ``x_max + s_mlp(...)`` is folded into the BatchNorm/LeakyReLU kernel, the BatchNorm +
+  activation of ``s_mlp_max`` into the max-aggregation gather;
+* consecutive layers chain their buffers: x' / v' are produced inside the NEXT layer's operand buffers and
+  x' is written a second time into its column block of the concatenated embedding input (``LayerCfg.chain``,
+  ``LayerCfg.dup``) -- no copies between layers, no ``torch.cat`` of the layer outputs;
+* the I_J fold of the first VectorMLP layer uses the reference's [co, 2K] weight as a [2co, K] view (GEMM
+  output = interleaved (P_c, Q_c) columns), so neither the weight nor its gradient is re-stacked.
 
 Dense GEMMs are library calls (tuned, see deltaconv_amd/tuning).  Used when every MLP of the layer
 has depth 1 and standard activations (all reference models except the depth-2 segmentation net,

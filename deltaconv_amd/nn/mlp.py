@@ -2,7 +2,6 @@
 (hence the same state_dict keys: ``0.0.weight``, ``0.1.bn.weight`` ...); each inner block runs as
 library GEMM + one fused HIP BatchNorm/activation kernel instead of three ATen ops."""
 import torch
-import torch.nn.functional as F
 from torch.nn import Sequential as Seq, LeakyReLU
 
 from .nonlin import BatchNorm1d, VectorNonLin
