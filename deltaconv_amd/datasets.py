@@ -1,0 +1,160 @@
+"""Data side of the ModelNet experiment without torch_geometric:
+an OFF mesh reader, a ``Data`` attribute bag the transforms operate on, ``Compose``, a collate into
+``deltaconv_amd.Batch`` and an in-memory ``ModelNet`` dataset with the constructor and on-disk layout
+of the reference's ``experiments/datasets/modelnet.py:11-114`` (``root/raw/<category>/<train|test>/*.off``
+-> ``root/processed/{training,test}.pt`` after ``pre_transform``).
+
+Host-side, one-off work (the hot path starts at the collated batch).  Nothing is downloaded: there is
+no network in this environment, the raw folder has to exist.
+"""
+import copy
+import glob
+import os
+import os.path as osp
+
+import torch
+
+from .data import Batch
+
+
+class Data:
+    """Attribute bag (``pos``, ``face`` [3,F], ``norm``, ``x``, ``y``, ``category`` ...): what the transforms
+    in ``deltaconv_amd.transforms`` read and write."""
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    def keys(self):
+        return [k for k, v in self.__dict__.items() if v is not None]
+
+    def clone(self):
+        out = Data()
+        for k, v in self.__dict__.items():
+            setattr(out, k, v.clone() if torch.is_tensor(v) else copy.deepcopy(v))
+        return out
+
+    def __repr__(self):
+        f = lambda v: list(v.shape) if torch.is_tensor(v) else v
+        return "Data(" + ", ".join(f"{k}={f(getattr(self, k))}" for k in self.keys()) + ")"
+
+
+class Compose:
+    def __init__(self, transforms):
+        self.transforms = list(transforms)
+
+    def __call__(self, data):
+        for t in self.transforms:
+            data = t(data)
+        return data
+
+    def __repr__(self):
+        return "Compose([" + ", ".join(repr(t) for t in self.transforms) + "])"
+
+
+def parse_off(text):
+    """OFF text -> Data(pos [V,3] float32, face [3,F] int64).  Accepts the ModelNet files whose counts are
+    glued to the magic word (``OFF490 518 0``); polygons with more than three corners are fanned."""
+    tok = text.split()
+    if not tok or not tok[0].startswith("OFF"):
+        raise ValueError("not an OFF file")
+    head = tok[0][3:]
+    tok = ([head] if head else []) + tok[1:]
+    nv, nf = int(tok[0]), int(tok[1])
+    p = 3                                              # skip the edge count
+    pos = torch.tensor([float(t) for t in tok[p:p + 3 * nv]], dtype=torch.float32).view(nv, 3)
+    p += 3 * nv
+    tri = []
+    for _ in range(nf):
+        c = int(tok[p])
+        idx = [int(t) for t in tok[p + 1:p + 1 + c]]
+        p += 1 + c
+        for j in range(1, c - 1):
+            tri.append((idx[0], idx[j], idx[j + 1]))
+    face = torch.tensor(tri, dtype=torch.long).t().contiguous() if tri else torch.empty(3, 0, dtype=torch.long)
+    if face.numel() and (int(face.min()) < 0 or int(face.max()) >= nv):
+        raise ValueError("OFF face index out of range")
+    return Data(pos=pos, face=face)
+
+
+def read_off(path):
+    with open(path, "r") as fh:
+        return parse_off(fh.read())
+
+
+def collate(data_list):
+    """List of per-shape ``Data`` -> one ``Batch`` (pos / norm / x concatenated, ``batch`` vector, labels
+    stacked per cloud or concatenated per point, ``category`` stacked)."""
+    cat = lambda name: (torch.cat([getattr(d, name) for d in data_list])
+                        if all(getattr(d, name, None) is not None for d in data_list) else None)
+    pos = cat("pos")
+    batch = torch.cat([torch.full((d.pos.shape[0],), i, dtype=torch.long) for i, d in enumerate(data_list)])
+    norm = cat("norm")
+    if norm is None:
+        norm = cat("normal")
+    ys = [getattr(d, "y", None) for d in data_list]
+    y = None
+    if all(v is not None for v in ys):
+        ys = [v if torch.is_tensor(v) else torch.tensor([v]) for v in ys]
+        y = torch.cat([v.reshape(-1) for v in ys])
+    cats = [getattr(d, "category", None) for d in data_list]
+    category = torch.stack([c.reshape(-1) for c in cats]) if all(c is not None for c in cats) else None
+    return Batch(pos, batch, norm, cat("x"), y, category, len(data_list))
+
+
+class DataLoader(torch.utils.data.DataLoader):
+    """``torch.utils.data.DataLoader`` that collates ``Data`` objects into ``deltaconv_amd.Batch``."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, **kw):
+        kw.setdefault("collate_fn", collate)
+        super().__init__(dataset, batch_size=batch_size, shuffle=shuffle, **kw)
+
+
+class ModelNet(torch.utils.data.Dataset):
+    """ModelNet10/40 from OFF files (experiments/datasets/modelnet.py:11-114): same arguments, same folder
+    layout, labels = index of the category in sorted order; ``pre_transform`` runs once and its result is
+    cached under ``root/processed``, ``transform`` runs on a copy at every access."""
+
+    def __init__(self, root, n_per_class=None, name='10', train=True, transform=None, pre_transform=None,
+                 pre_filter=None):
+        assert name in ['10', '40']
+        self.root, self.name, self.n_per_class = root, name, n_per_class
+        self.transform, self.pre_transform, self.pre_filter = transform, pre_transform, pre_filter
+        self.raw_dir, self.processed_dir = osp.join(root, "raw"), osp.join(root, "processed")
+        paths = [osp.join(self.processed_dir, f) for f in ("training.pt", "test.pt")]
+        if not all(osp.exists(p) for p in paths):
+            if not osp.isdir(self.raw_dir):
+                raise FileNotFoundError(f"{self.raw_dir} not found: unpack ModelNet{name}.zip there "
+                                        "(<category>/<train|test>/*.off); nothing is downloaded")
+            os.makedirs(self.processed_dir, exist_ok=True)
+            torch.save(self.process_set("train"), paths[0])
+            torch.save(self.process_set("test"), paths[1])
+        blob = torch.load(paths[0] if train else paths[1], weights_only=False)
+        self.categories, self.items = blob["categories"], [Data(**d) for d in blob["items"]]
+
+    def process_set(self, split):
+        categories = sorted(d for d in os.listdir(self.raw_dir) if osp.isdir(osp.join(self.raw_dir, d)))
+        items = []
+        for target, category in enumerate(categories):
+            paths = sorted(glob.glob(osp.join(self.raw_dir, category, split, f"{category}_*.off")))
+            for i, path in enumerate(paths):
+                if self.n_per_class is not None and i > self.n_per_class:     # modelnet.py:99 keeps n+1 shapes
+                    continue
+                data = read_off(path)
+                data.y = torch.tensor([target])
+                items.append(data)
+        if self.pre_filter is not None:
+            items = [d for d in items if self.pre_filter(d)]
+        if self.pre_transform is not None:
+            items = [self.pre_transform(d) for d in items]
+        return {"categories": categories, "items": [dict(d.__dict__) for d in items]}
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        data = self.items[i].clone()
+        return data if self.transform is None else self.transform(data)
+
+    def __repr__(self):
+        return '{}{}({})'.format(self.__class__.__name__, self.name, len(self))

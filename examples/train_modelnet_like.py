@@ -1,10 +1,13 @@
 """Training loop with the semantics of the reference's experiments/train_modelnet.py (:20-142): SGD(lr 0.1,
 momentum 0.9, wd 1e-4) + cosine annealing to 1e-3, label-smoothed cross entropy, train / evaluate per
 epoch, state_dict checkpoints with the reference's key names -- on the MI355X path, data-parallel over
-the GPUs of one node.  No dataset ships with this repo (the reference downloads ModelNet40), so the
-clouds are synthetic; swap `make_split` for a real loader that yields `deltaconv_amd.Batch` objects.
+the GPUs of one node.  No dataset ships with this repo (the reference downloads ModelNet40), so by default
+the clouds are synthetic; with `--data <ModelNet40 root>` (raw/<category>/<train|test>/*.off) the reference's
+pipeline runs instead: NormalizeScale -> SamplePoints -> GeodesicFPS once, RandomScale + RandomTranslateGlobal
+per access (train_modelnet.py:29-49), through `deltaconv_amd.datasets`.
 
     python examples/train_modelnet_like.py --epochs 3
+    python examples/train_modelnet_like.py --data /data/ModelNet40 --epochs 50
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_modelnet_like.py
 """
 import argparse
@@ -72,6 +75,8 @@ def main():
     ap.add_argument("--grad_regularizer", type=float, default=0.001)
     ap.add_argument("--train_batches", type=int, default=8)
     ap.add_argument("--logdir", default="runs/modelnet_like")
+    ap.add_argument("--data", default=None, help="ModelNet40 root with raw/<category>/<train|test>/*.off")
+    ap.add_argument("--sampling_margin", type=int, default=8)
     args = ap.parse_args()
 
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
@@ -85,8 +90,27 @@ def main():
     ddp = FlatGradDataParallel(model)
     opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4, fused=True)
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, args.epochs, eta_min=0.001)
-    train = make_split(args.train_batches, args.batch_size, args.num_points, 1000 * (rank + 1), dev)
-    test = make_split(2, args.batch_size, args.num_points, 777000, dev)
+    if args.data is None:
+        train = make_split(args.train_batches, args.batch_size, args.num_points, 1000 * (rank + 1), dev)
+        test = make_split(2, args.batch_size, args.num_points, 777000, dev)
+    else:
+        import deltaconv_amd.transforms as T
+        from deltaconv_amd.datasets import Compose, DataLoader, ModelNet
+        pre = Compose((T.NormalizeScale(), T.SamplePoints(args.num_points * args.sampling_margin, include_normals=True),
+                       T.GeodesicFPS(args.num_points)))
+        aug = Compose((T.RandomScale((4 / 5, 5 / 4)), T.RandomTranslateGlobal(0.1)))
+        tr = ModelNet(args.data, None, "40", True, transform=aug, pre_transform=pre)
+        te = ModelNet(args.data, None, "40", False, pre_transform=pre)
+        sampler = torch.utils.data.distributed.DistributedSampler(tr) if world > 1 else None
+        on_dev = lambda loader: (b.to(dev) for b in loader)      # each rank collates and uploads its own shard
+        train_loader = DataLoader(tr, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler, drop_last=True)
+        test_loader = DataLoader(te, batch_size=args.batch_size, shuffle=False, drop_last=False)
+        args.train_batches = len(train_loader)
+
+        class _OnDevice:
+            def __init__(self, loader): self.loader = loader
+            def __iter__(self): return on_dev(self.loader)
+        train, test = _OnDevice(train_loader), _OnDevice(test_loader)
     os.makedirs(args.logdir, exist_ok=True)
     for epoch in range(args.epochs):
         t0 = time.perf_counter()

@@ -1,0 +1,100 @@
+"""Data side without torch_geometric (deltaconv_amd/datasets.py): OFF reader, collate, ModelNet layout and
+caching (reference: experiments/datasets/modelnet.py:11-114, experiments/train_modelnet.py:29-49)."""
+import os
+
+import pytest
+import torch
+
+import deltaconv_amd.transforms as T
+from deltaconv_amd.datasets import Compose, Data, DataLoader, ModelNet, collate, parse_off, read_off
+
+CUBE = """OFF
+8 6 0
+0 0 0
+1 0 0
+1 1 0
+0 1 0
+0 0 1
+1 0 1
+1 1 1
+0 1 1
+4 0 1 2 3
+4 4 5 6 7
+4 0 1 5 4
+4 2 3 7 6
+4 1 2 6 5
+4 0 3 7 4
+"""
+TETRA_GLUED = "OFF4 4 0\n0 0 0\n1 0 0\n0 1 0\n0 0 1\n3 0 1 2\n3 0 1 3\n3 0 2 3\n3 1 2 3\n"
+
+
+def test_parse_off_quads_and_glued_header():
+    cube = parse_off(CUBE)
+    assert cube.pos.shape == (8, 3) and cube.face.shape == (3, 12) and cube.face.dtype == torch.long   # 6 quads -> 12 triangles
+    area = torch.linalg.cross(cube.pos[cube.face[1]] - cube.pos[cube.face[0]],
+                              cube.pos[cube.face[2]] - cube.pos[cube.face[0]], dim=1).norm(dim=1).sum() / 2
+    assert abs(float(area) - 6.0) < 1e-6
+    tet = parse_off(TETRA_GLUED)
+    assert tet.pos.shape == (4, 3) and tet.face.shape == (3, 4)
+    with pytest.raises(ValueError):
+        parse_off("PLY\n1 2 3")
+    with pytest.raises(ValueError):
+        parse_off("OFF\n3 1 0\n0 0 0\n1 0 0\n0 1 0\n3 0 1 7\n")
+
+
+def _make_tree(root):
+    for cat, text in (("bowl", CUBE), ("airplane", TETRA_GLUED)):
+        for split, n in (("train", 3), ("test", 2)):
+            d = os.path.join(root, "raw", cat, split)
+            os.makedirs(d)
+            for i in range(n):
+                with open(os.path.join(d, f"{cat}_{i:04d}.off"), "w") as fh:
+                    fh.write(text)
+            with open(os.path.join(d, "README.txt"), "w") as fh:      # ignored: not <category>_*.off
+                fh.write("x")
+
+
+def test_modelnet_layout_pretransform_cache_and_loader(tmp_path):
+    root = str(tmp_path / "ModelNet40")
+    with pytest.raises(FileNotFoundError):
+        ModelNet(root, None, "40", True)
+    _make_tree(root)
+    torch.manual_seed(0)
+    pre = Compose((T.NormalizeScale(), T.SamplePoints(64, include_normals=True), T.GeodesicFPS(32)))
+    train = ModelNet(root, None, "40", True, transform=Compose((T.RandomScale((4 / 5, 5 / 4)),
+                                                               T.RandomTranslateGlobal(0.1))), pre_transform=pre)
+    test = ModelNet(root, None, "40", False, pre_transform=pre)
+    assert len(train) == 6 and len(test) == 4 and repr(train) == "ModelNet40(6)"
+    assert train.categories == ["airplane", "bowl"]                    # labels follow the sorted category names
+    assert [int(train.items[i].y) for i in range(6)] == [0, 0, 0, 1, 1, 1]
+    d = train[4]
+    assert d.pos.shape == (32, 3) and d.norm.shape == (32, 3) and d.face is None
+    assert torch.allclose(d.norm.norm(dim=1), torch.ones(32), atol=1e-5)
+    assert not torch.equal(train[4].pos, train[4].pos)                 # the per-access transform is random ...
+    assert torch.equal(test[1].pos, test[1].pos)                       # ... the cached pre-transform is not
+    # processed/ is the cache: the raw files are not needed again
+    import shutil
+    shutil.rmtree(os.path.join(root, "raw"))
+    again = ModelNet(root, None, "40", False)
+    assert len(again) == 4 and torch.equal(again[1].pos, test[1].pos)
+    # loader -> Batch objects the models consume
+    loader = DataLoader(train, batch_size=4, shuffle=False, drop_last=True)
+    batches = list(loader)
+    assert len(batches) == 1
+    b = batches[0]
+    assert b.pos.shape == (128, 3) and b.norm.shape == (128, 3) and b.num_graphs == 4
+    assert b.y.tolist() == [0, 0, 0, 1] and b.batch.tolist() == sum([[i] * 32 for i in range(4)], [])
+    assert b.ptr.tolist() == [0, 32, 64, 96, 128]
+
+
+def test_n_per_class_and_collate_variants(tmp_path):
+    root = str(tmp_path / "ModelNet10")
+    _make_tree(root)
+    ds = ModelNet(root, 0, "10", True)                                 # reference quirk: i > n is skipped -> n+1 kept
+    assert len(ds) == 2
+    a = Data(pos=torch.zeros(3, 3), x=torch.ones(3, 2), y=torch.tensor([0, 1, 2]), category=torch.tensor([1., 0.]))
+    b = Data(pos=torch.ones(2, 3), x=torch.zeros(2, 2), y=torch.tensor([3, 4]), category=torch.tensor([0., 1.]))
+    out = collate([a, b])
+    assert out.norm is None and out.x.shape == (5, 2) and out.y.tolist() == [0, 1, 2, 3, 4]
+    assert out.category.shape == (2, 2) and out.batch.tolist() == [0, 0, 0, 1, 1]
+    assert "pos=[3, 3]" in repr(a)
