@@ -14,7 +14,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before HIP starts (deltaconv_amd/graph_step.py)
+os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"   # before HIP starts (deltaconv_amd/graph_step.py)
 
 import torch
 import torch.distributed as dist
@@ -194,16 +194,17 @@ def main():
         counter[0] += 1
         return batches[counter[0] % len(batches)]
 
-    if args.no_graph:
-        def step():
-            b = next_batch()
-            ddp.zero_grad()
-            loss = calc_loss(ddp(b), b.y)
-            loss.backward()
-            ddp.reduce_gradients()
-            opt.step()
-            return loss
-    else:
+    def eager_step():
+        b = next_batch()
+        ddp.zero_grad()
+        loss = calc_loss(ddp(b), b.y)
+        loss.backward()
+        ddp.reduce_gradients()
+        opt.step()
+        return loss
+
+    step, launch = eager_step, "eager launches"
+    if not args.no_graph:
         # forward + loss + backward (+ SGD update when there is no all-reduce in between) replayed from
         # one captured HIP graph; same kernels, same work per step, one host call.
         from deltaconv_amd.graph_step import GraphedTrainStep
@@ -213,14 +214,19 @@ def main():
             calc_loss(ddp(static), static.y).backward()
             ddp.reduce_gradients()
             opt.step()
-        gstep = GraphedTrainStep(model, calc_loss, static, optimizer=None if use_dist else opt)
+        try:
+            gstep = GraphedTrainStep(model, calc_loss, static, optimizer=None if use_dist else opt)
 
-        def step():
-            loss = gstep(next_batch())
-            if use_dist:
-                ddp.reduce_gradients()
-                opt.step()
-            return loss
+            def step():
+                loss = gstep(next_batch())
+                if use_dist:
+                    ddp.reduce_gradients()
+                    opt.step()
+                return loss
+            launch = "HIP-graph replay"
+        except Exception as e:                               # keep measuring (eagerly) and say so in the output
+            print(f"[bench] HIP-graph capture failed, falling back to eager launches: {e!r}", file=sys.stderr)
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -253,7 +259,7 @@ def main():
             "data": "synthetic (seeded smooth closed surfaces with analytic normals, random-init weights)",
             "config": {"workload": f"ModelNet40 classification, {args.points} points, k={args.k}, "
                                    f"batch={args.batch} per GPU, fwd+bwd+SGD step, train-mode BN/Dropout, "
-                                   + ("eager launches" if args.no_graph else "HIP-graph replay"),
+                                   + launch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": roof,
         }
