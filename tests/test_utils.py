@@ -26,3 +26,18 @@ def test_shape_iou():
     # category 0 owns parts 0..3: IoUs = 1/3, 1/2, 1, 1/2
     assert abs(calc_shape_IoU(pred, seg, np.array([0]), None)[0] - np.mean([1 / 3, 1 / 2, 1.0, 1 / 2])) < 1e-12
     assert calc_shape_IoU(np.array([[4, 4]]), np.array([[4, 4]]), np.array([1]), None)[0] == 1.0   # part 5 empty -> 1
+
+
+def test_graphed_step_refuses_to_run_with_packet_capture_on(monkeypatch):
+    """GraphedTrainStep checks the ROCm runtime flag before touching the GPU (deltaconv_amd/graph_step.py)."""
+    import pytest
+    from deltaconv_amd.graph_step import GraphedTrainStep
+    monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")
+    with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
+        GraphedTrainStep(None, None, None)
+
+
+def test_package_import_defaults_the_runtime_flag():
+    import os
+    import deltaconv_amd  # noqa: F401
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
