@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tuned-gemm", action="store_true", help="library default GEMM heuristics")
     ap.add_argument("--fresh-tuning", action="store_true", help="ignore shipped GEMM tuning results (tools/tune_gemm.sh)")
+    ap.add_argument("--save-tuning", default=None, metavar="CSV",
+                    help="write the TunableOp results of this run (shipped + newly tuned shapes) to CSV")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every kernel from Python each step instead of replaying the captured HIP graph")
@@ -247,6 +249,13 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     assert torch.isfinite(loss).item(), "loss is not finite"
+    if args.save_tuning and rank == 0:
+        import torch.cuda.tunable as tn                      # same text format as TunableOp's own results file
+        with open(args.save_tuning, "w") as fh:
+            for key, val in tn.get_validators():
+                fh.write(f"Validator,{key},{val}\n")
+            for op, params, solution, ms in tn.get_results():
+                fh.write(f"{op},{params},{solution},{ms}\n")
 
     if rank == 0:
         graph, grad, div = model.deltanet_base.build_operators(data)
