@@ -1,8 +1,8 @@
-"""Data side of the ModelNet experiment without torch_geometric:
+"""Data side of the ModelNet / ShapeNet experiments without torch_geometric:
 an OFF mesh reader, a ``Data`` attribute bag the transforms operate on, ``Compose``, a collate into
-``deltaconv_amd.Batch`` and an in-memory ``ModelNet`` dataset with the constructor and on-disk layout
-of the reference's ``experiments/datasets/modelnet.py:11-114`` (``root/raw/<category>/<train|test>/*.off``
--> ``root/processed/{training,test}.pt`` after ``pre_transform``).
+``deltaconv_amd.Batch`` and in-memory ``ModelNet`` / ``ShapeNet`` datasets with the constructors and on-disk
+layouts of the reference's ``experiments/datasets/modelnet.py:11-114`` (``root/raw/<category>/<train|test>/*.off``
+-> ``root/processed/{training,test}.pt`` after ``pre_transform``) and ``shapenet.py:13-200``.
 
 Host-side, one-off work (the hot path starts at the collated batch).  Nothing is downloaded: there is
 no network in this environment, the raw folder has to exist.
@@ -158,3 +158,109 @@ class ModelNet(torch.utils.data.Dataset):
 
     def __repr__(self):
         return '{}{}({})'.format(self.__class__.__name__, self.name, len(self))
+
+
+def read_txt_array(path):
+    """Whitespace-separated numeric table -> float32 tensor [rows, cols]."""
+    with open(path, "r") as fh:
+        rows = [[float(t) for t in line.split()] for line in fh if line.strip()]
+    return torch.tensor(rows, dtype=torch.float32)
+
+
+class ShapeNet(torch.utils.data.Dataset):
+    """ShapeNet part-segmentation benchmark (experiments/datasets/shapenet.py:13-200; used by
+    train_shapenet.py:43-44): ``root/raw/<synset>/*.txt`` rows ``x y z nx ny nz part`` and
+    ``root/raw/train_test_split/shuffled_{train,val,test}_file_list.json``.  Items carry ``pos``, ``norm``,
+    per-point ``y`` (0..49) and the one-hot ``category`` [1,16] indexed within the SELECTED categories, as the
+    reference builds it; ``y_mask[c]`` marks the part labels of category c.  Processed splits are cached as
+    ``root/processed/<cats>_{train,val,test,trainval}.pt``."""
+
+    _names = ['Airplane', 'Bag', 'Cap', 'Car', 'Chair', 'Earphone', 'Guitar', 'Knife', 'Lamp', 'Laptop', 'Motorbike',
+              'Mug', 'Pistol', 'Rocket', 'Skateboard', 'Table']
+    _synsets = ['02691156', '02773838', '02954340', '02958343', '03001627', '03261776', '03467517', '03624134',
+                '03636649', '03642806', '03790512', '03797390', '03948459', '04099429', '04225987', '04379243']
+    _parts = [4, 2, 2, 4, 4, 3, 3, 2, 4, 2, 6, 2, 3, 3, 3, 3]          # part labels per category, consecutive from 0
+    category_ids = dict(zip(_names, _synsets))
+    seg_classes = None            # filled in below the class body (a class-level comprehension cannot see _parts)
+    splits = ['train', 'val', 'test', 'trainval']
+
+    def __init__(self, root, categories=None, n_per_class=None, include_normals=True, split='trainval', transform=None,
+                 pre_transform=None, pre_filter=None):
+        if categories is None:
+            categories = list(self.category_ids.keys())
+        if isinstance(categories, str):
+            categories = [categories]
+        assert all(c in self.category_ids for c in categories)
+        if split not in self.splits:
+            raise ValueError(f'Split {split} found, but expected either train, val, trainval or test')
+        self.root, self.categories, self.n_per_class = root, categories, n_per_class
+        self.transform, self.pre_transform, self.pre_filter = transform, pre_transform, pre_filter
+        self.include_normals = include_normals
+        self.raw_dir, self.processed_dir = osp.join(root, "raw"), osp.join(root, "processed")
+        tag = '_'.join(c[:3].lower() for c in categories)
+        paths = {s: osp.join(self.processed_dir, f"{tag}_{s}.pt") for s in self.splits}
+        if not all(osp.exists(p) for p in paths.values()):
+            if not osp.isdir(osp.join(self.raw_dir, "train_test_split")):
+                raise FileNotFoundError(f"{self.raw_dir}/train_test_split not found: unpack "
+                                        "shapenetcore_partanno_segmentation_benchmark_v0_normal there; nothing is downloaded")
+            os.makedirs(self.processed_dir, exist_ok=True)
+            self._process(paths)
+        self.items = [Data(**d) for d in torch.load(paths[split], weights_only=False)]
+        if not include_normals:
+            for d in self.items:
+                d.norm = None
+        self.y_mask = torch.zeros((len(self.seg_classes), 50), dtype=torch.bool)
+        for i, labels in enumerate(self.seg_classes.values()):
+            self.y_mask[i, labels] = 1
+
+    @property
+    def num_classes(self):
+        return self.y_mask.size(-1)
+
+    def _process_filenames(self, filenames):
+        ids = [self.category_ids[c] for c in self.categories]
+        cat_idx = {s: i for i, s in enumerate(ids)}
+        left = [self.n_per_class] * len(ids) if self.n_per_class is not None else None
+        out = []
+        for name in filenames:
+            syn = name.split(osp.sep)[0]
+            if syn not in cat_idx:
+                continue
+            if left is not None:
+                if left[cat_idx[syn]] <= 0:
+                    continue
+                left[cat_idx[syn]] -= 1
+            tab = read_txt_array(osp.join(self.raw_dir, name))
+            onehot = torch.zeros(1, 16)
+            onehot[0, cat_idx[syn]] = 1
+            data = Data(pos=tab[:, :3].contiguous(), norm=tab[:, 3:6].contiguous(), y=tab[:, -1].long(), category=onehot)
+            if self.pre_filter is not None and not self.pre_filter(data):
+                continue
+            out.append(data if self.pre_transform is None else self.pre_transform(data))
+        return out
+
+    def _process(self, paths):
+        import json
+        trainval = []
+        for split in ('train', 'val', 'test'):
+            with open(osp.join(self.raw_dir, 'train_test_split', f'shuffled_{split}_file_list.json')) as fh:
+                names = [osp.sep.join(n.split('/')[1:]) + '.txt' for n in json.load(fh)]   # drop the leading folder
+            items = self._process_filenames(names)
+            if split != 'test':
+                trainval += items
+            torch.save([dict(d.__dict__) for d in items], paths[split])
+        torch.save([dict(d.__dict__) for d in trainval], paths['trainval'])
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        data = self.items[i].clone()
+        return data if self.transform is None else self.transform(data)
+
+    def __repr__(self):
+        return '{}({}, categories={})'.format(self.__class__.__name__, len(self), self.categories)
+
+
+ShapeNet.seg_classes = {n: list(range(sum(ShapeNet._parts[:i]), sum(ShapeNet._parts[:i + 1])))
+                        for i, n in enumerate(ShapeNet._names)}

@@ -98,3 +98,45 @@ def test_n_per_class_and_collate_variants(tmp_path):
     assert out.norm is None and out.x.shape == (5, 2) and out.y.tolist() == [0, 1, 2, 3, 4]
     assert out.category.shape == (2, 2) and out.batch.tolist() == [0, 0, 0, 1, 1]
     assert "pos=[3, 3]" in repr(a)
+
+
+def test_shapenet_part_layout(tmp_path):
+    import json
+    from deltaconv_amd.datasets import ShapeNet
+    from deltaconv_amd.utils import calc_shape_IoU
+    root = str(tmp_path / "ShapeNet")
+    with pytest.raises(FileNotFoundError):
+        ShapeNet(root)
+    g = torch.Generator().manual_seed(3)
+    files = {"train": [("02691156", "a1"), ("03001627", "c1"), ("02691156", "a2")],
+             "val": [("03001627", "c2")], "test": [("02691156", "a3"), ("04379243", "t1")]}
+    os.makedirs(os.path.join(root, "raw", "train_test_split"))
+    for split, lst in files.items():
+        with open(os.path.join(root, "raw", "train_test_split", f"shuffled_{split}_file_list.json"), "w") as fh:
+            json.dump([f"shape_data/{syn}/{name}" for syn, name in lst], fh)
+        for syn, name in lst:
+            os.makedirs(os.path.join(root, "raw", syn), exist_ok=True)
+            lo = {"02691156": 0, "03001627": 12, "04379243": 47}[syn]
+            n = 20
+            tab = torch.cat([torch.randn(n, 3, generator=g), torch.nn.functional.normalize(torch.randn(n, 3, generator=g)),
+                             torch.randint(lo, lo + 3, (n, 1), generator=g).float()], 1)
+            with open(os.path.join(root, "raw", syn, name + ".txt"), "w") as fh:
+                for row in tab.tolist():
+                    fh.write(" ".join(f"{v:.6f}" for v in row) + "\n")
+    tv = ShapeNet(root, split="trainval")
+    te = ShapeNet(root, split="test")
+    assert len(tv) == 4 and len(te) == 2 and tv.num_classes == 50 and tv.y_mask.shape == (16, 50)
+    assert tv.y_mask[4].nonzero().flatten().tolist() == [12, 13, 14, 15]         # Chair
+    d = te[1]                                                                     # the table
+    assert d.pos.shape == (20, 3) and d.norm.shape == (20, 3) and d.y.dtype == torch.long
+    assert d.category.shape == (1, 16) and int(d.category.argmax()) == 15 and 47 <= int(d.y.min())
+    only = ShapeNet(root, categories="Chair", split="trainval")                   # one-hot index WITHIN the selection
+    assert len(only) == 2 and int(only[0].category.argmax()) == 0
+    assert len(ShapeNet(root, categories=["Airplane", "Chair"], n_per_class=1, split="train")) == 2
+    with pytest.raises(ValueError):
+        ShapeNet(root, split="training")
+    b = next(iter(DataLoader(tv, batch_size=2)))
+    assert b.pos.shape == (40, 3) and b.y.shape == (40,) and b.category.shape == (2, 16)
+    # the seg tables agree with the IoU metric's tables (experiments/utils.py:27-51)
+    ious = calc_shape_IoU(d.y.numpy()[None], d.y.numpy()[None], [15], None)
+    assert ious == [1.0]
