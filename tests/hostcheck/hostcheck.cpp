@@ -122,6 +122,16 @@ void hc_knn_max(int V, const int* nbr, int n, int k, const float* h, int C, long
         }
 }
 
+void hc_knn_max_affine(int V, const int* nbr, int n, int k, const float* h, int C, long ldh, const float* scale,
+                       const float* shift, float slope, float* out, long ldo, unsigned char* arg) {
+    using namespace dcell;
+    for (long i = 0; i < n; ++i)
+        for (int c0 = 0; c0 < C; c0 += V) {
+            if (V == 4) knn_max_affine_fwd<4>(i, c0, nbr + i * k, k, h, ldh, scale, shift, slope, out, ldo, arg, C);
+            else knn_max_affine_fwd<1>(i, c0, nbr + i * k, k, h, ldh, scale, shift, slope, out, ldo, arg, C);
+        }
+}
+
 void hc_knn_max_bwd(int V, const int* tptr, const int* tedge, int n, int k, const unsigned char* arg,
                     const float* dout, int C, long ldo, float* dh, long ldh, int acc) {
     using namespace dcell;

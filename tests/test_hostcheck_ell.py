@@ -25,6 +25,7 @@ def hc():
     lib.hc_ell_T.argtypes = [ci, ci, vp, vp, vp, ci, ci, vp, ci, cl, vp, cl, ci, vp, cl]
     lib.hc_knn_max.argtypes = [ci, vp, ci, ci, vp, ci, cl, vp, cl, vp]
     lib.hc_knn_max_bwd.argtypes = [ci, vp, vp, ci, ci, vp, vp, ci, cl, vp, cl, ci]
+    lib.hc_knn_max_affine.argtypes = [ci, vp, ci, ci, vp, ci, cl, vp, vp, ctypes.c_float, vp, cl, vp]
     return lib
 
 
@@ -154,3 +155,23 @@ def test_forward_and_transposed(hc, graph, C, pad):
     dh = buf(n, C, ld)
     hc.hc_knn_max_bwd(V, P(tptr), P(tedge), n, k, P(arg), P(dyb), C, ld, P(dh), ld, 0)
     assert rel_err(dh[:, :C], dh_ref) < 1e-6
+
+    # the same with BatchNorm scale/shift + LeakyReLU folded into the gather (dc_knn_max_affine): dyadic values
+    # make every fmaf exact, so values AND first-maximal slots must equal "transform, then max"
+    gq = torch.Generator().manual_seed(11)
+    hq = torch.randint(-16, 17, (n, C), generator=gq) / 8.0
+    sc = torch.randint(-8, 9, (C,), generator=gq) / 4.0
+    sc[0] = 0.0                                                            # constant column: slot 0 wins
+    sh = torch.randint(-8, 9, (C,), generator=gq) / 8.0
+    z = sc * hq + sh
+    yq = torch.where(z > 0, z, 0.25 * z)
+    yg = yq[graph["nbr"]]                                                  # [n,k,C]
+    mx = yg.max(dim=1).values
+    eq = yg == mx[:, None, :]
+    first = (eq.float().cumsum(1) == 1) & eq
+    slot = (first.float() * torch.arange(k).view(1, k, 1)).sum(1).long()
+    hb2 = torch.zeros(n, ld); hb2[:, :C] = hq
+    out2 = buf(n, C, ld)
+    arg2 = torch.zeros(n, C, dtype=torch.uint8)
+    hc.hc_knn_max_affine(V, P(nbr32), n, k, P(hb2), C, ld, P(sc.contiguous()), P(sh.contiguous()), 0.25, P(out2), ld, P(arg2))
+    assert torch.equal(out2[:, :C], mx) and torch.equal(arg2.long(), slot)
