@@ -264,3 +264,197 @@ class ShapeNet(torch.utils.data.Dataset):
 
 ShapeNet.seg_classes = {n: list(range(sum(ShapeNet._parts[:i]), sum(ShapeNet._parts[:i + 1])))
                         for i, n in enumerate(ShapeNet._names)}
+
+
+# ---- ShapeSeg (human-body part segmentation, meshes from Adobe / FAUST / MIT / SCAPE, SHREC for testing) ----
+def read_ply(path):
+    """PLY (ascii or binary_little_endian) -> Data(pos [V,3] float32, face [3,F] int64).  Reads the x/y/z
+    properties of the vertex element and the index list of the face element; polygons are fanned."""
+    import struct
+    with open(path, "rb") as fh:
+        raw = fh.read()
+    end = raw.index(b"end_header")
+    end = raw.index(b"\n", end) + 1
+    header = raw[:end].decode("ascii", "replace").splitlines()
+    if not header or header[0].strip() != "ply":
+        raise ValueError("not a PLY file")
+    fmt, elements, cur = None, [], None
+    for line in header[1:]:
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "format":
+            fmt = t[1]
+        elif t[0] == "element":
+            cur = {"name": t[1], "count": int(t[2]), "props": []}
+            elements.append(cur)
+        elif t[0] == "property" and cur is not None:
+            cur["props"].append(t[1:])          # [type, name] or ['list', count_type, item_type, name]
+    if fmt not in ("ascii", "binary_little_endian"):
+        raise ValueError(f"unsupported PLY format {fmt}")
+    codes = {"char": "b", "uchar": "B", "short": "h", "ushort": "H", "int": "i", "uint": "I", "float": "f", "double": "d",
+             "int8": "b", "uint8": "B", "int16": "h", "uint16": "H", "int32": "i", "uint32": "I", "float32": "f",
+             "float64": "d"}
+    pos, tri = None, []
+    if fmt == "ascii":
+        tok = raw[end:].split()
+        p = 0
+        for el in elements:
+            rows = []
+            for _ in range(el["count"]):
+                row = {}
+                for pr in el["props"]:
+                    if pr[0] == "list":
+                        c = int(tok[p]); p += 1
+                        row[pr[3]] = [int(float(v)) for v in tok[p:p + c]]; p += c
+                    else:
+                        row[pr[1]] = float(tok[p]); p += 1
+                rows.append(row)
+            if el["name"] == "vertex":
+                pos = torch.tensor([[r["x"], r["y"], r["z"]] for r in rows], dtype=torch.float32)
+            elif el["name"] == "face":
+                for r in rows:
+                    idx = next(v for v in r.values() if isinstance(v, list))
+                    tri += [(idx[0], idx[j], idx[j + 1]) for j in range(1, len(idx) - 1)]
+    else:
+        p = end
+        for el in elements:
+            rows = []
+            for _ in range(el["count"]):
+                row = {}
+                for pr in el["props"]:
+                    if pr[0] == "list":
+                        ct, it = "<" + codes[pr[1]], codes[pr[2]]
+                        (c,) = struct.unpack_from(ct, raw, p); p += struct.calcsize(ct)
+                        row[pr[3]] = list(struct.unpack_from(f"<{c}{it}", raw, p)); p += struct.calcsize(f"<{c}{it}")
+                    else:
+                        f = "<" + codes[pr[0]]
+                        (row[pr[1]],) = struct.unpack_from(f, raw, p); p += struct.calcsize(f)
+                rows.append(row)
+            if el["name"] == "vertex":
+                pos = torch.tensor([[r["x"], r["y"], r["z"]] for r in rows], dtype=torch.float32)
+            elif el["name"] == "face":
+                for r in rows:
+                    idx = next(v for v in r.values() if isinstance(v, list))
+                    tri += [(idx[0], idx[j], idx[j + 1]) for j in range(1, len(idx) - 1)]
+    if pos is None:
+        raise ValueError("PLY without a vertex element")
+    face = torch.tensor(tri, dtype=torch.long).t().contiguous() if tri else torch.empty(3, 0, dtype=torch.long)
+    return Data(pos=pos, face=face)
+
+
+def read_obj(path):
+    """Wavefront OBJ -> Data(pos, face [3,F]): ``v x y z`` and ``f a b c`` records (``a/b/c`` corner syntax and
+    negative indices accepted, polygons fanned).  Stands for the openmesh reader of shape_seg.py:193-199."""
+    pos, tri = [], []
+    with open(path, "r") as fh:
+        for line in fh:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                pos.append([float(v) for v in t[1:4]])
+            elif t[0] == "f":
+                idx = [int(c.split("/")[0]) for c in t[1:]]
+                idx = [i - 1 if i > 0 else len(pos) + i for i in idx]
+                tri += [(idx[0], idx[j], idx[j + 1]) for j in range(1, len(idx) - 1)]
+    face = torch.tensor(tri, dtype=torch.long).t().contiguous() if tri else torch.empty(3, 0, dtype=torch.long)
+    return Data(pos=torch.tensor(pos, dtype=torch.float32).view(-1, 3), face=face)
+
+
+def edge_to_vertex_labels(face, labels, n_nodes):
+    """Per-edge labels (MeshCNN ``.eseg``, 1-based; edges numbered in order of first appearance while walking the
+    faces, corners (0,1), (1,2), (0,2)) -> per-vertex labels, 0-based (shape_seg.py:173-191): every edge writes
+    its label to both end points, first all first end points, then all second end points, later edges
+    overwriting earlier ones."""
+    seen, order = set(), []
+    for f in face.t().tolist():
+        for a, b in ((f[0], f[1]), (f[1], f[2]), (f[0], f[2])):
+            e = (a, b) if a < b else (b, a)
+            if e not in seen:
+                seen.add(e)
+                order.append(e)
+    res = [0] * n_nodes
+    lab = labels.tolist()
+    for end in (0, 1):
+        for e, l in zip(order, lab):
+            res[e[end]] = int(l)
+    return torch.tensor(res, dtype=torch.long) - 1
+
+
+class ShapeSeg(torch.utils.data.Dataset):
+    """Human-body segmentation set of Maron et al. in the MeshCNN remeshing (experiments/datasets/shape_seg.py:
+    13-171; used by train_shapeseg.py:44,53): training = Adobe (41 ``.ply`` + ``segs/<i>.pt``), FAUST (100
+    ``tr_reg_%03d.ply``, one shared ``faust_seg.pt``), MIT (``.obj`` + per-edge ``.eseg``), SCAPE (71 ``.ply``,
+    shared ``scape_seg.pt``); test = SHREC (18 ``.ply`` + ``segs/<i>.pt``).  Expects the archive unpacked as
+    ``root/raw/ShapeSeg/<SET>/raw/{meshes,segs}`` (nested ``<set>.zip`` files are extracted when still
+    present).  Items: ``pos``, ``face``, per-vertex ``y``; cached as ``root/processed/{training,test}.pt``."""
+
+    def __init__(self, root, train=True, transform=None, pre_transform=None, pre_filter=None):
+        self.root, self.transform, self.pre_transform, self.pre_filter = root, transform, pre_transform, pre_filter
+        self.raw_dir, self.processed_dir = osp.join(root, "raw"), osp.join(root, "processed")
+        paths = [osp.join(self.processed_dir, f) for f in ("training.pt", "test.pt")]
+        if not all(osp.exists(p) for p in paths):
+            base = osp.join(self.raw_dir, "ShapeSeg")
+            if not osp.isdir(base):
+                big = osp.join(self.raw_dir, "shapeseg.zip")
+                if not osp.exists(big):
+                    raise FileNotFoundError(f"{base} (or {big}) not found; nothing is downloaded")
+                import zipfile
+                with zipfile.ZipFile(big) as z:
+                    z.extractall(self.raw_dir)
+            os.makedirs(self.processed_dir, exist_ok=True)
+            train_items, test_items = self._process(base)
+            torch.save([dict(d.__dict__) for d in train_items], paths[0])
+            torch.save([dict(d.__dict__) for d in test_items], paths[1])
+        self.items = [Data(**d) for d in torch.load(paths[0] if train else paths[1], weights_only=False)]
+
+    def _finish(self, data, out):
+        if self.pre_filter is not None and not self.pre_filter(data):
+            return
+        out.append(data if self.pre_transform is None else self.pre_transform(data))
+
+    @staticmethod
+    def _set_dir(base, name):
+        d = osp.join(base, name, "raw")
+        z = osp.join(d, name.lower() + ".zip")
+        if osp.exists(z) and not osp.isdir(osp.join(d, "meshes")):
+            import zipfile
+            with zipfile.ZipFile(z) as zf:
+                zf.extractall(d)
+        return d
+
+    def _numbered(self, base, name, pattern, shared_seg, out):
+        d = self._set_dir(base, name)
+        shared = torch.load(osp.join(d, "segs", shared_seg), weights_only=False) if shared_seg else None
+        i = 0
+        while osp.exists(osp.join(d, "meshes", pattern.format(i))):
+            data = read_ply(osp.join(d, "meshes", pattern.format(i)))
+            data.y = shared if shared is not None else torch.load(osp.join(d, "segs", f"{i}.pt"), weights_only=False)
+            self._finish(data, out)
+            i += 1
+
+    def _process(self, base):
+        train, test = [], []
+        self._numbered(base, "Adobe", "{}.ply", None, train)
+        self._numbered(base, "FAUST", "tr_reg_{0:03d}.ply", "faust_seg.pt", train)
+        d = self._set_dir(base, "MIT")
+        for fn in os.listdir(osp.join(d, "meshes")):          # directory order, as the reference (shape_seg.py:125)
+            data = read_obj(osp.join(d, "meshes", fn))
+            with open(osp.join(d, "segs", fn.replace(".obj", ".eseg"))) as fh:
+                segs = torch.tensor([int(float(t)) for t in fh.read().split()], dtype=torch.long)
+            data.y = edge_to_vertex_labels(data.face, segs, data.pos.shape[0])
+            self._finish(data, train)
+        self._numbered(base, "SCAPE", "{}.ply", "scape_seg.pt", train)
+        self._numbered(base, "SHREC", "{}.ply", None, test)
+        return train, test
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        data = self.items[i].clone()
+        return data if self.transform is None else self.transform(data)
+
+    def __repr__(self):
+        return '{}({})'.format(self.__class__.__name__, len(self))

@@ -140,3 +140,93 @@ def test_shapenet_part_layout(tmp_path):
     # the seg tables agree with the IoU metric's tables (experiments/utils.py:27-51)
     ious = calc_shape_IoU(d.y.numpy()[None], d.y.numpy()[None], [15], None)
     assert ious == [1.0]
+
+
+def _write_ply(path, pos, faces, binary):
+    import struct
+    head = ["ply", "format " + ("binary_little_endian 1.0" if binary else "ascii 1.0"), "comment test",
+            f"element vertex {len(pos)}", "property float x", "property float y", "property float z",
+            "property uchar red", f"element face {len(faces)}", "property list uchar int vertex_indices", "end_header"]
+    with open(path, "wb") as fh:
+        fh.write(("\n".join(head) + "\n").encode())
+        if binary:
+            for p in pos:
+                fh.write(struct.pack("<fffB", *p, 7))
+            for f in faces:
+                fh.write(struct.pack(f"<B{len(f)}i", len(f), *f))
+        else:
+            for p in pos:
+                fh.write((" ".join(f"{v:.6f}" for v in p) + " 7\n").encode())
+            for f in faces:
+                fh.write((f"{len(f)} " + " ".join(map(str, f)) + "\n").encode())
+
+
+def test_ply_obj_readers_and_edge_labels(tmp_path):
+    from deltaconv_amd.datasets import edge_to_vertex_labels, read_obj, read_ply
+    pos = [(0., 0., 0.), (1., 0., 0.), (1., 1., 0.), (0., 1., 0.), (0.5, 0.5, 1.)]
+    faces = [(0, 1, 2, 3), (0, 1, 4), (1, 2, 4)]                      # one quad -> fanned
+    for binary in (False, True):
+        p = str(tmp_path / f"m{int(binary)}.ply")
+        _write_ply(p, pos, faces, binary)
+        d = read_ply(p)
+        assert d.pos.shape == (5, 3) and torch.allclose(d.pos, torch.tensor(pos))
+        assert d.face.t().tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 4], [1, 2, 4]]
+    with open(tmp_path / "bad.ply", "w") as fh:
+        fh.write("plx\nend_header\n")
+    with pytest.raises(ValueError):
+        read_ply(str(tmp_path / "bad.ply"))
+    obj = tmp_path / "m.obj"
+    obj.write_text("# c\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1 4/4/1\nf -4 -3 -1\n")
+    o = read_obj(str(obj))
+    assert o.pos.shape == (4, 3) and o.face.t().tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 3]]
+    # per-edge -> per-vertex labels, against the vectorised formulation of shape_seg.py:173-191
+    face = torch.tensor([[0, 1, 2], [0, 2, 3], [0, 1, 4], [1, 2, 4]]).t()
+    seen, edges = set(), []
+    for f in face.t():
+        for e in (f[:2], f[1:], f[::2]):
+            key = tuple(sorted(e.tolist()))
+            if key not in seen:
+                seen.add(key)
+                edges.append(key)
+    labels = torch.arange(1, len(edges) + 1)
+    ei = torch.tensor(edges)
+    ref = torch.zeros(5, dtype=torch.long)
+    ref[ei[:, 0]] = labels
+    ref[ei[:, 1]] = labels
+    assert torch.equal(edge_to_vertex_labels(face, labels, 5), ref - 1)
+
+
+def test_shapeseg_layout(tmp_path):
+    from deltaconv_amd.datasets import ShapeSeg
+    root = str(tmp_path / "ShapeSeg")
+    with pytest.raises(FileNotFoundError):
+        ShapeSeg(root)
+    pos = [(0., 0., 0.), (1., 0., 0.), (1., 1., 0.), (0., 1., 0.)]
+    faces = [(0, 1, 2), (0, 2, 3)]
+    base = os.path.join(root, "raw", "ShapeSeg")
+    counts = {"Adobe": 2, "FAUST": 3, "SCAPE": 1, "SHREC": 2}
+    for name, n in counts.items():
+        for sub in ("meshes", "segs"):
+            os.makedirs(os.path.join(base, name, "raw", sub))
+        for i in range(n):
+            fn = f"tr_reg_{i:03d}.ply" if name == "FAUST" else f"{i}.ply"
+            _write_ply(os.path.join(base, name, "raw", "meshes", fn), pos, faces, binary=(i % 2 == 0))
+            if name in ("Adobe", "SHREC"):
+                torch.save(torch.tensor([i, 1, 2, 3]), os.path.join(base, name, "raw", "segs", f"{i}.pt"))
+    torch.save(torch.tensor([7, 7, 7, 7]), os.path.join(base, "FAUST", "raw", "segs", "faust_seg.pt"))
+    torch.save(torch.tensor([5, 5, 5, 5]), os.path.join(base, "SCAPE", "raw", "segs", "scape_seg.pt"))
+    for sub in ("meshes", "segs"):
+        os.makedirs(os.path.join(base, "MIT", "raw", sub))
+    with open(os.path.join(base, "MIT", "raw", "meshes", "crane_0.obj"), "w") as fh:
+        fh.write("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3\nf 1 3 4\n")
+    with open(os.path.join(base, "MIT", "raw", "segs", "crane_0.eseg"), "w") as fh:
+        fh.write("1\n2\n3\n4\n5\n")                                   # 5 unique edges
+    tr = ShapeSeg(root, True, pre_transform=T.NormalizeScale())
+    te = ShapeSeg(root, False)
+    assert len(tr) == 2 + 3 + 1 + 1 and len(te) == 2 and repr(te) == "ShapeSeg(2)"
+    assert tr[0].y.tolist() == [0, 1, 2, 3] and tr[2].y.tolist() == [7, 7, 7, 7]      # Adobe first, then FAUST
+    mit = tr[5]
+    assert mit.pos.shape == (4, 3) and mit.y.shape == (4,) and int(mit.y.min()) >= 0
+    assert float(tr[0].pos.norm(dim=1).max()) < 1.0                                   # pre_transform applied
+    b = collate([tr[0], tr[1]])
+    assert b.pos.shape == (8, 3) and b.y.shape == (8,)
