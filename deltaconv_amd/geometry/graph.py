@@ -13,14 +13,34 @@ import torch
 from .._lib import lib, require_gpu
 
 
+class PtrInfo(tuple):
+    """(ptr int32 [B+1] on device, num_clouds, max_cloud_size) + ``min_cloud`` (smallest cloud, for the
+    k <= cloud size check of the kNN graph)."""
+    min_cloud = None
+
+    def __new__(cls, ptr, num_clouds, max_cloud, min_cloud=None):
+        self = super().__new__(cls, (ptr, num_clouds, max_cloud))
+        self.min_cloud = min_cloud
+        return self
+
+
 def _ptr_from_batch(batch, n, device):
-    """(ptr int32 [B+1] on device, num_clouds, max_cloud_size).  One host sync when batch is given."""
+    """PtrInfo of a sorted ``batch`` vector.  One host sync when batch is given."""
     if batch is None:
-        return torch.tensor([0, n], dtype=torch.int32, device=device), 1, n
+        return PtrInfo(torch.tensor([0, n], dtype=torch.int32, device=device), 1, n, n)
     counts = torch.bincount(batch)
     ptr = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=device)
     ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return ptr, int(counts.numel()), int(counts.max())
+    mx_mn = torch.stack([counts.max(), counts.min()]).tolist()       # one sync for both
+    return PtrInfo(ptr, int(counts.numel()), int(mx_mn[0]), int(mx_mn[1]))
+
+
+def _min_cloud(ptr_info):
+    mn = getattr(ptr_info, "min_cloud", None)
+    if mn is None:
+        ptr = ptr_info[0]
+        mn = int((ptr[1:] - ptr[:-1]).min())
+    return mn
 
 
 class Graph:
@@ -38,7 +58,13 @@ class Graph:
         require_gpu()
         pos = pos.contiguous().float()
         n = pos.shape[0]
-        ptr, nc, mx = ptr_info if ptr_info is not None else _ptr_from_batch(batch, n, pos.device)
+        info = ptr_info if ptr_info is not None else _ptr_from_batch(batch, n, pos.device)
+        ptr, nc, mx = info
+        # a cloud with fewer than k points has no k-nearest-neighbour list (the reference's fixed-k reshape,
+        # grad_div_mls.py:24-25,85, fails there too); the kernels index neighbours without bounds checks
+        mn = _min_cloud(info)
+        if mn < k:
+            raise ValueError(f"knn graph: every cloud needs at least k = {k} points, the smallest has {mn}")
         nbr = torch.empty(n, k, dtype=torch.int32, device=pos.device)
         lib.call("dc_knn", pos, ptr, nc, mx, k, lanes_per_query, nbr)
         return Graph(nbr, ptr, nc, mx)

@@ -9,14 +9,15 @@ from ..geometry.grad_div_mls import build_grad_div, build_tangent_basis, estimat
 
 def _ptr_info(data):
     """(ptr, num_clouds, max_cloud) without a device sync when the batch carries it (data.Batch)."""
-    from ..geometry.graph import _ptr_from_batch
+    from ..geometry.graph import _ptr_from_batch, PtrInfo
     info = getattr(data, "_ptr_info", None)
     if info is not None and info[0].device == data.pos.device:
         return info
     if hasattr(data, "ptr") and getattr(data, "num_graphs", None) is not None and not callable(data.ptr):
         ptr = data.ptr.to(device=data.pos.device, dtype=torch.int32)
         sizes = (ptr[1:] - ptr[:-1])
-        info = (ptr, int(data.num_graphs), int(sizes.max()))
+        mx_mn = torch.stack([sizes.max(), sizes.min()]).tolist()
+        info = PtrInfo(ptr, int(data.num_graphs), int(mx_mn[0]), int(mx_mn[1]))
     else:
         info = _ptr_from_batch(data.batch, data.pos.shape[0], data.pos.device)
     try:

@@ -47,6 +47,14 @@ class defer_counters:
         return False
 
 
+def check_bn_rows(bn, rows):
+    """torch.nn.functional.batch_norm refuses a train-mode batch with one value per channel (the reference
+    hits this at B = 1 in its head: deltaconv/nn/nonlin.py:29-30, SURVEY.md section 8(d) C1 caveat); same here."""
+    if bn.training and int(rows) <= 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, "
+                         f"{bn.num_features}, {int(rows)}]")
+
+
 def slope_of(act):
     """negative slope of a piecewise-linear activation module, or None if it is something else."""
     if isinstance(act, torch.nn.LeakyReLU):
@@ -98,6 +106,7 @@ class _BNAct(torch.autograd.Function):
 def bn_act(h, bn, slope, residual=None):
     """bn: torch.nn.BatchNorm1d holding the parameters / running statistics."""
     require_gpu()
+    check_bn_rows(bn, h.shape[0])
     use_batch = bn.training or bn.running_mean is None
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     rm, rv = (bn.running_mean, bn.running_var) if (bn.training and bn.track_running_stats) or not use_batch else (None, None)
@@ -158,6 +167,7 @@ def vector_nonlin(inp, combine, vn):
     if vn.batchnorm is None:
         return _VectorNonLin.apply(inp, combine, None, vn.bias, None, None, 0, 0.0, 0.0)
     bn = vn.batchnorm.bn
+    check_bn_rows(bn, inp.shape[0] // 2)
     use_batch = bn.training or bn.running_mean is None
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     track = bn.training and bn.track_running_stats
@@ -320,6 +330,7 @@ class _BNActPool(torch.autograd.Function):
 
 def bn_act_pool(h, bn, slope, num_clouds, n_per, with_mean):
     require_gpu()
+    check_bn_rows(bn, h.shape[0])
     use_batch = bn.training or bn.running_mean is None
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     track = bn.training and bn.track_running_stats

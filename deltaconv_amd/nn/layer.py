@@ -90,6 +90,7 @@ def _bn_mode(bn):
 
 def _bn_coeffs(h, rows, c, ld, bn, gamma, beta, dev, vn_combine=None):
     """Batch (or running) statistics of h -> coef[4,c] = mean, invstd, scale, shift."""
+    fused.check_bn_rows(bn, rows)
     use_batch, mom, rm, rv = _bn_mode(bn)
     coef = torch.empty(4, c, dtype=_F32, device=dev)
     if use_batch:

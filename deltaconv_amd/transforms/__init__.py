@@ -136,7 +136,7 @@ class RandomRotate(_Transform):
             m = [[c, s, 0], [-s, c, 0], [0, 0, 1]]
         m = torch.tensor(m, dtype=torch.float32)
         data.pos = data.pos @ m.to(data.pos.dtype).to(data.pos.device)
-        if hasattr(data, 'norm'):
+        if getattr(data, 'norm', None) is not None:
             data.norm = data.norm @ m.to(data.norm.dtype).to(data.norm.device)
         return data
 

@@ -65,3 +65,35 @@ def calc_shape_IoU(pred_np, seg_np, label, class_choice):
             per_part.append(1.0 if union == 0 else np.sum(np.logical_and(p, g)) / float(union))
         ious.append(np.mean(per_part))
     return ious
+
+
+# ---- run bookkeeping of the experiment scripts ------------------------------------------------------------
+def experiment_details(args, experiment_name):
+    """The text experiments/train_modelnet.py:205-209 writes to <logdir>/settings.txt (and prints)."""
+    text = experiment_name + '\n--\nSettings:\n--\n'
+    for arg in vars(args):
+        text += '{}: {}\n'.format(arg, getattr(args, arg))
+    return text
+
+
+def write_settings(args, logdir, experiment_name):
+    """<logdir>/settings.txt + <logdir>/checkpoints/ exactly as the reference lays a run out
+    (train_modelnet.py:197-211); returns the checkpoint directory."""
+    import os
+    ckpt = os.path.join(logdir, 'checkpoints')
+    os.makedirs(ckpt, exist_ok=True)
+    with open(os.path.join(logdir, 'settings.txt'), 'w') as f:
+        f.write(experiment_details(args, experiment_name))
+    return ckpt
+
+
+def save_checkpoint(model, path):
+    """torch.save(model.state_dict(), path): the reference's checkpoint format (train_modelnet.py:80,82) --
+    plain tensors under the reference's parameter names, so either code base loads the other's files."""
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, path)
+
+
+def load_checkpoint(model, path, strict=True):
+    """model.load_state_dict(torch.load(path)) (train_modelnet.py:84), strict by default."""
+    sd = torch.load(path, map_location='cpu', weights_only=True)
+    return model.load_state_dict(sd, strict=strict)

@@ -107,8 +107,17 @@ def test_model_step_golden(name):
     assert names == [str(s) for s in g["gnames"]]
     gn = g["gnorm_f64"].numpy()
     assert np.max(np.abs(np.array(norms) - gn) / (gn + 1e-3 * gn.max())) < 5 * tol
+    # signed probe dot products (a sign / permutation error in a weight gradient changes these, not the norms)
+    gd = g["gdot_f64"].numpy()
+    assert np.max(np.abs(np.array(dots) - gd) / (gn + 1e-3 * gn.max())) < 5 * tol
+    # and two weight gradients element by element (first edge MLP, first vector MLP)
+    params = dict(model.named_parameters())
+    for pkey in ("deltanet_base.convs.0.s_mlp_max.0.0.weight", "deltanet_base.convs.1.v_mlp.0.0.weight"):
+        for tag in ("f64", "f32"):
+            assert rel_err(params[pkey].grad, g[f"g_{pkey}_{tag}"]) < 5 * tol, (pkey, tag)
     key = ("lin_global" if kind == "seg" else "lin_embedding") + ".0.1.bn.running_mean"
     assert rel_err(dict(model.named_buffers())[key], g["rm_embed_f64"]) < tol
+    assert rel_err(dict(model.named_buffers())[key.replace("running_mean", "running_var")], g["rv_embed_f64"]) < tol
 
 
 @pytest.mark.parametrize("B,N,k", [(2, 512, 20), (8, 1024, 20)])
@@ -281,3 +290,106 @@ def test_graphed_training_matches_eager():
     sd1, sd2 = m1.state_dict(), m2.state_dict()
     for key in sd1:
         assert torch.equal(sd1[key], sd2[key]), key
+
+
+# ---- C1 (ModelNet40, 1024 points, k = 20, batch 1: BASELINE.json configs[0]) ----------------------------
+def _oracle_pair(kind, kw, k, seed=1):
+    """(oracle model fp32, deltaconv_amd model on the GPU) with identical weights."""
+    torch.manual_seed(seed)
+    ocls = oracle.models.DeltaNetSegmentation if kind == "seg" else oracle.models.DeltaNetClassification
+    ref = ocls(num_neighbors=k, **kw)
+    import deltaconv_amd as dc
+    cls = dc.models.DeltaNetSegmentation if kind == "seg" else dc.models.DeltaNetClassification
+    model = cls(num_neighbors=k, **kw)
+    model.load_state_dict(ref.state_dict())
+    return ref, model.to(DEV)
+
+
+def _randomize_bn(ref):
+    """Non-trivial running statistics / affine parameters, so an eval-mode pass really tests them."""
+    gen = torch.Generator().manual_seed(123)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=gen))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=gen))
+                m.weight.copy_(0.5 + torch.rand(m.weight.shape, generator=gen))
+                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=gen))
+
+
+def test_c1_eval_forward_b1():
+    """C1 (i): eval-mode forward of ONE cloud of 1024 points, k = 20, logits vs the oracle."""
+    b = synthetic_batch(1, 1024, seed=80)
+    ref, model = _oracle_pair("cls", dict(in_channels=3, num_classes=40), 20)
+    _randomize_bn(ref)
+    model.load_state_dict(ref.state_dict())
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        lo = ref(b)
+        ld = model(b.to(DEV))
+    assert ld.shape == (1, 40)
+    assert rel_err(ld, lo) < 1e-3
+
+
+def test_c1_train_b1_raises_like_reference():
+    """C1 caveat: the reference cannot run a train-mode step at B = 1 -- the head's
+    BatchNorm sees one row and torch raises ValueError (nn/nonlin.py:29-30 -> F.batch_norm).  Same here."""
+    b = synthetic_batch(1, 1024, seed=81).to(DEV)
+    _, model = _oracle_pair("cls", dict(in_channels=3, num_classes=40), 20)
+    model.train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        model(b)
+
+
+def test_c1_backbone_train_b1():
+    """C1 (ii): forward + backward through DeltaNetBase + lin_embedding at B = 1 (train-mode BatchNorm over the
+    1024 rows is well defined) vs the oracle."""
+    b = synthetic_batch(1, 1024, seed=82)
+    ref, model = _oracle_pair("cls", dict(in_channels=3, num_classes=40), 20)
+    ref.train(); model.train()
+
+    def run(m, data):
+        xs = m.deltanet_base(data)
+        e = m.lin_embedding(torch.cat(list(xs), dim=1))
+        w = probe_vec(tuple(e.shape), 31).float().to(e.device)
+        (e * w).sum().backward()
+        return e
+    eo = run(ref, b)
+    ed = run(model, b.to(DEV))
+    assert rel_err(ed, eo) < 1e-3
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for (n1, p1), (n2, p2) in zip(model.named_parameters(), ref.named_parameters()):
+        assert n1 == n2
+        if p2.grad is None:
+            assert p1.grad is None, n1
+            continue
+        scale = max(float(p2.grad.abs().max()), 1e-3 * gmax)
+        assert float((p1.grad.cpu() - p2.grad).abs().max()) / scale < 2e-2, n1
+
+
+def test_c1_train_step_b2():
+    """C1 (iii): the smallest batch the reference can train on (B = 2), one full step vs the oracle (fp64 truth,
+    self-calibrated against the oracle's own fp32 run like test_model_step_vs_oracle)."""
+    test_model_step_vs_oracle(2, 1024, 20)
+
+
+@pytest.mark.parametrize("kind,kw,bkw", [
+    ("cls", dict(in_channels=3, num_classes=40), {}),
+    ("seg", dict(in_channels=3, num_classes=50, categorical_vector=True),
+     dict(per_point_labels=True, categories=16, num_classes=50)),
+    ("cls", dict(in_channels=3, num_classes=15, conv_channels=[64, 64, 64, 128], grad_regularizer=1e-2),
+     dict(normals=False, num_classes=15)),
+])
+def test_eval_mode_logits_vs_oracle(kind, kw, bkw):
+    """Whole-model eval-mode parity (running statistics, dropout off): classification, segmentation (depth-2
+    MLPs + categorical vector), and the no-normals (estimate_basis) variant."""
+    b = synthetic_batch(3, 512, seed=83, **bkw)
+    ref, model = _oracle_pair(kind, kw, 20)
+    _randomize_bn(ref)
+    model.load_state_dict(ref.state_dict())
+    ref.eval(); model.eval()
+    with torch.no_grad():
+        lo = ref(b)
+        ld = model(b.to(DEV))
+    assert ld.shape == lo.shape
+    assert rel_err(ld, lo) < (5e-3 if bkw.get("normals") is False else 1e-3)
