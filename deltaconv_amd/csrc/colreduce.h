@@ -117,6 +117,22 @@ struct BwdFin {
 struct NoFin {
     __device__ void operator()(int, double, double) const {}
 };
+// the two column sums themselves (fp64): the data-parallel SyncBN path all-reduces them across ranks
+struct SumsFin {
+    double* sums; int C;
+    __device__ void operator()(int c, double s0, double s1) const {
+        sums[c] = s0;
+        sums[C + c] = s1;
+    }
+};
+
+// coefficients from (possibly all-reduced) column sums over `count` rows; one thread per column
+// count <= 0: the row count is itself on the device, sums[2C] (all-reduced together with the sums: no host sync)
+__global__ void bn_coeffs_from_sums_kernel(const double* __restrict__ sums, long count, int C, BnFin fin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    fin.R = count > 0 ? count : (long)(sums[2 * C] + 0.5);
+    if (c < C) fin(c, sums[c], sums[C + c]);
+}
 
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
                                       float eps, int C, float* mean, float* invstd, float* scale, float* shift) {

@@ -1,0 +1,516 @@
+// Dense per-point GEMMs of the scalar / vector MLP stream on the fp32 matrix cores, LDS-staged.
+//
+//   forward          Y[M,N]  = X[M,K] W[N,K]^T          (every Linear(no bias): /root/reference/deltaconv/nn/mlp.py:9,15)
+//   input gradient   dX[M,K] (+)= dY[M,N] W[N,K]        (ATen mm in the autograd of the same lines)
+// M = points (32768..65536), N, K = features (64..1024): tall and skinny, so the row-major activations are
+// streamed once and the small weight matrix stays in L2.  (The weight gradient dW = dY^T X has the long
+// dimension as its reduction and lives in gemm_tn.hip.)
+//
+// Mapping (CDNA4): v_mfma_f32_32x32x2_f32 -- exact fp32, lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31].  A workgroup = 4 waves (2 x 2) on a BM x BN tile of the output, K walked in tiles of 32
+// through double-buffered LDS (one barrier per tile; the next tile's global loads are in flight while the
+// current one is multiplied):
+//   * an operand whose reduction index is contiguous in memory (X, dY, and W in the forward product) is staged
+//     as [rows][32 + 4 pad] and read back with ONE ds_read_b128 per four k-steps: the lane half h = l>>5 takes
+//     k = 8j + 4h + t for t = 0..3, i.e. MFMA step t pairs columns {8j + t, 8j + 4 + t} -- a fixed permutation of
+//     the reduction order, applied to both operands alike (pad 4: the 16 rows of a read group land on 16
+//     different 16-byte bank slots);
+//   * W in the input-gradient product has the reduction index as its ROW index: staged as [32][BN] and read with
+//     conflict-free ds_read_b32 at the same permuted k.
+// Global loads are 16 bytes per lane, whole 128-byte row segments per 8 lanes (full cache lines through the
+// texture path once, fragments come from LDS).  Accumulators: (BM/64) x (BN/64) tiles of 32 x 32 per wave.
+// Output: the MFMA C/D layout (lane = column, registers = rows) would be 64 dword stores per lane, each touching
+// two 128-byte row pieces -- store-issue bound.  Each wave instead transposes its tile through LDS (the operand
+// buffers are dead by then) and writes whole rows with 16-byte stores (r02a: the dword epilogue cost ~20 % of a
+// 128 x 128 x 512 workgroup's time).
+// The weight gradient dW[M,N] = dY[R,M]^T X[R,N] (both operands reduction-major, R = points) runs through the same
+// kernel with the reduction split over row slabs (grid.y) into per-slab partial tiles, summed in slab order by
+// gemm_tn_reduce_kernel (gemm_tn.hip): deterministic, no atomics.
+//
+// Fused epilogues (forward): the per-column sum / sum of squares of the tile (BatchNorm statistics of the
+// Linear output, nn/nonlin.py:24-35), or of the per-point vector norms of an interleaved (P_c, Q_c) output
+// (VectorNonLin statistics, nn/nonlin.py:63-79) are reduced in fp64 inside the workgroup and written as one
+// partial per (column, row tile); the ordered final stage of colreduce.h turns them into scale / shift.  The
+// separate statistics pass over the [M, N] output (one full read) disappears.  Deterministic: fixed order.
+//
+// Bound: MFMA (157 TFLOP/s fp32).  Per 32-deep K tile a 128 x 128 workgroup issues 64 MFMAs per wave (4096
+// cycles) against 32 KB of global loads (8 B/clk/CU) and 16 ds_read_b128 per wave.
+#include <algorithm>
+#include "common.h"
+#include "nn_math.h"
+#include "colreduce.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;         // reduction tile
+constexpr int LDK = BK + 4;    // row stride (floats) of a k-contiguous operand tile in LDS
+constexpr int NT = 256;        // threads per workgroup (4 waves, 2 x 2)
+
+enum { EPI_NONE = 0, EPI_COLSTATS = 1, EPI_VNSTATS = 2 };
+enum { B_NK = 0 /* W[N,K]: forward */, B_KN = 1 /* reduction-major: input gradient, weight gradient */ };
+enum { A_MK = 0 /* X[M,K]: reduction index contiguous */, A_KM = 1 /* dY[R,M]: reduction-major (weight gradient) */ };
+
+struct GemmP {
+    const float* A; long lda;
+    const float* B; long ldb;
+    float* C; long ldc;
+    long M; int N; long K;
+    int tiles_n, remap, accumulate;
+    long k_per_slab, slab_stride;          // split reduction: blockIdx.y = slab, C += slab * slab_stride
+    int phase;                             // experiment: delay every other resident workgroup by half a K tile
+    double* part; int chunks, stat_cols;   // statistics partials [2][stat_cols][chunks]
+};
+
+template <bool FAST>
+__device__ __forceinline__ f32x4 gload4(const float* base, long ld, long row, long nrows, long col, long ncols) {
+    if (FAST) return *reinterpret_cast<const f32x4*>(base + row * ld + col);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nrows && col < ncols) {
+        const float* p = base + row * ld + col;
+        if (col + 3 < ncols && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+            v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < ncols) v[e] = p[e];
+        }
+    }
+    return v;
+}
+
+template <int BM, int BN, int AL, int BL, bool FAST, int EPI>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+    constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;      // 32 x 32 accumulators per wave
+    constexpr int A_FL = AL == A_MK ? BM * LDK : BK * BM;
+    constexpr int B_FL = BL == B_NK ? BN * LDK : BK * BN;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 16-byte loads per thread and K tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][A_FL]
+    float* Bs = smem + 2 * A_FL;       // [2][B_FL]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const long blk = dc_xcd_block(p.remap);
+    const long kbeg = (long)blockIdx.y * p.k_per_slab;
+    const long kend = min(p.K, kbeg + p.k_per_slab);
+    const long tm = blk / p.tiles_n;
+    const int tn = (int)(blk - tm * p.tiles_n);
+    const long m0 = tm * BM;
+    const int n0 = tn * BN;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    f32x4 sa[A_IT], sb[B_IT];
+    auto load_tiles = [&](long k0) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = tid + NT * it;
+            if (AL == A_MK)
+                sa[it] = gload4<FAST>(p.A, p.lda, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
+            else
+                sa[it] = gload4<FAST>(p.A, p.lda, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int idx = tid + NT * it;
+            if (BL == B_NK)
+                sb[it] = gload4<FAST>(p.B, p.ldb, n0 + (idx >> 3), p.N, k0 + (idx & 7) * 4, kend);
+            else
+                sb[it] = gload4<FAST>(p.B, p.ldb, k0 + idx / (BN / 4), kend, n0 + (idx % (BN / 4)) * 4, p.N);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * A_FL;
+        float* b = Bs + buf * B_FL;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int idx = tid + NT * it;
+            if (AL == A_MK)
+                *reinterpret_cast<f32x4*>(a + (idx >> 3) * LDK + (idx & 7) * 4) = sa[it];
+            else
+                *reinterpret_cast<f32x4*>(a + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = sa[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int idx = tid + NT * it;
+            if (BL == B_NK)
+                *reinterpret_cast<f32x4*>(b + (idx >> 3) * LDK + (idx & 7) * 4) = sb[it];
+            else
+                *reinterpret_cast<f32x4*>(b + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = sb[it];
+        }
+    };
+    // Fragments are double-buffered in registers and the loop is software-pipelined by hand: while the 4 k-steps of
+    // fragment set j are multiplied, set j+1 is already being read from LDS; the next K tile goes global -> registers
+    // at the top of the iteration, registers -> LDS behind the third MFMA group, and the workgroup barrier sits before
+    // the LAST group, whose operands are in registers by then -- so the first fragments of the next tile are fetched
+    // under that group's MFMAs and no ds_read latency, ds_write burst or barrier skew is exposed between tiles.
+    f32x4 fa[2][TM], fb[2][TN];
+    auto read_frags = [&](int buf, int j, f32x4 (&ra)[TM], f32x4 (&rb)[TN]) {
+        const float* a = AL == A_MK ? As + buf * A_FL + (wm0 + li) * LDK + 4 * lh
+                                    : As + buf * A_FL + (4 * lh) * BM + wm0 + li;
+        const float* b = BL == B_NK ? Bs + buf * B_FL + (wn0 + li) * LDK + 4 * lh
+                                    : Bs + buf * B_FL + (4 * lh) * BN + wn0 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (AL == A_MK) {
+                ra[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + 8 * j);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ra[i][t] = a[(8 * j + t) * BM + i * 32];
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            if (BL == B_NK) {
+                rb[jn] = *reinterpret_cast<const f32x4*>(b + jn * 32 * LDK + 8 * j);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) rb[jn][t] = b[(8 * j + t) * BN + jn * 32];
+            }
+        }
+    };
+    auto mfma_group = [&](const f32x4 (&ra)[TM], const f32x4 (&rb)[TN]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][t], rb[jn][t], acc[i][jn], 0, 0, 0);
+    };
+
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+    if (p.phase && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(32);   // de-phase the two workgroups of a CU
+    load_tiles(kbeg);
+    store_tiles(0);
+    __syncthreads();
+    read_frags(0, 0, fa[0], fb[0]);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tiles(kbeg + (long)(kt + 1) * BK);
+        read_frags(cur, 1, fa[1], fb[1]);
+        mfma_group(fa[0], fb[0]);
+        read_frags(cur, 2, fa[0], fb[0]);
+        mfma_group(fa[1], fb[1]);
+        read_frags(cur, 3, fa[1], fb[1]);
+        if (more) store_tiles(cur ^ 1);
+        mfma_group(fa[0], fb[0]);
+        __syncthreads();              // tile `cur` is consumed (its last fragments are in registers), tile cur^1 is written
+        if (more) read_frags(cur ^ 1, 0, fa[0], fb[0]);
+        mfma_group(fa[1], fb[1]);
+    }
+    __syncthreads();                  // (the staging below reuses the operand buffers)
+
+    // ---- statistics epilogue (rows beyond M hold zeros and add nothing)
+    if (EPI != EPI_NONE) {
+        constexpr int SC = EPI == EPI_VNSTATS ? BN / 2 : BN;        // statistic columns of the tile
+        double* sst = reinterpret_cast<double*>(smem);               // [2 quantities][2 wave rows][SC]; tiles are dead
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (EPI == EPI_COLSTATS) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const double x = (double)acc[i][jn][q];
+                        s0 += x;
+                        s1 += x * x;
+                    }
+                } else {   // rows (2r, 2r+1) = registers (q, q+1), q even; columns (2c, 2c+1) = (P_c, Q_c) = lanes (l, l+1)
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const float pu = acc[i][jn][q], pv = acc[i][jn][q + 1];
+                        const float qu = __shfl_xor(pu, 1, 64), qv = __shfl_xor(pv, 1, 64);
+                        float yu, yv;
+                        dcnn::vn_combine(pu, qu, pv, qv, yu, yv);
+                        const double nr = (double)dcnn::vn_norm(yu, yv);
+                        s0 += nr;
+                        s1 += nr * nr;
+                    }
+                }
+            }
+            s0 += __shfl_xor(s0, 32, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            if (lh == 0) {
+                if (EPI == EPI_COLSTATS) {
+                    const int c = wn0 + jn * 32 + li;
+                    sst[(0 * 2 + (wave >> 1)) * SC + c] = s0;
+                    sst[(1 * 2 + (wave >> 1)) * SC + c] = s1;
+                } else if ((li & 1) == 0) {
+                    const int c = (wn0 + jn * 32 + li) >> 1;
+                    sst[(0 * 2 + (wave >> 1)) * SC + c] = s0;
+                    sst[(1 * 2 + (wave >> 1)) * SC + c] = s1;
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * SC; idx += NT) {
+            const int q = idx / SC, c = idx - q * SC;
+            const int gc = (EPI == EPI_VNSTATS ? n0 / 2 : n0) + c;
+            if (gc < p.stat_cols)
+                p.part[((long)q * p.stat_cols + gc) * p.chunks + tm] = sst[(q * 2 + 0) * SC + c] + sst[(q * 2 + 1) * SC + c];
+        }
+        __syncthreads();   // sst is about to be overwritten by the output staging
+    }
+
+    // ---- store: each wave transposes its WM x WN tile through LDS and writes whole rows, 16 bytes per lane.
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5).  The staging row
+    // stride is exactly WN floats: the ds_read_b128 lane groups then cover all 16 slots of a 256-byte bank row.
+    float* stg = smem + wave * (WM * WN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                stg[(i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh) * WN + jn * 32 + li] = acc[i][jn][q];
+    __syncthreads();
+    float* cbase = p.C + (long)blockIdx.y * p.slab_stride;
+    constexpr int RL = WN / 4;                         // lanes per output row
+#pragma unroll
+    for (int it = 0; it < WM * WN / 4 / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = idx / RL, c4 = (idx % RL) * 4;
+        const long row = m0 + wm0 + r;
+        const int col = n0 + wn0 + c4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * WN + c4);
+        float* dst = cbase + row * p.ldc + col;
+        if (FAST) {
+            if (p.accumulate) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+                v += o;
+            }
+            *reinterpret_cast<f32x4*>(dst) = v;
+        } else if (row < p.M) {
+            if (col + 3 < p.N && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+                if (p.accumulate) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
+                    v += o;
+                }
+                *reinterpret_cast<f32x4*>(dst) = v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < p.N) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+            }
+        }
+    }
+}
+
+struct Tile { int bm, bn; };
+
+Tile pick_tile(long M, int N, int K, int tile) {
+    switch (tile) {
+        case 1: return {128, 128};
+        case 2: return {128, 64};
+        case 3: return {64, 64};
+        case 4: return {64, 128};
+        default: break;
+    }
+    const int bn = N > 64 ? 128 : 64;
+    const long tn = (N + bn - 1) / bn;
+    // enough workgroups for 256 CUs x 2: fall back to 64-row tiles for short problems
+    const int bm = ((M + 127) / 128) * tn >= 384 ? 128 : 64;
+    return {bm, bn};
+}
+
+size_t lds_bytes(int bm, int bn, int al, int bl) {
+    const size_t a = al == A_MK ? (size_t)bm * LDK : (size_t)BK * bm, b = bl == B_NK ? (size_t)bn * LDK : (size_t)BK * bn;
+    return std::max(2 * (a + b), (size_t)bm * bn) * sizeof(float);      // operand ring | output staging
+}
+
+template <int BM, int BN, int AL, int BL, bool FAST, int EPI>
+void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
+    static bool configured = false;
+    const size_t lds = lds_bytes(BM, BN, AL, BL);
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, FAST, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, FAST, EPI>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
+                       dim3(NT), lds, s, p);
+}
+
+template <int AL, int BL, bool FAST, int EPI>
+void launch_tile(const GemmP& p, Tile t, long tiles_m, int slabs, hipStream_t s) {
+    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
+    else if (t.bm == 128) launch_one<128, 64, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
+    else if (t.bn == 128) launch_one<64, 128, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
+    else launch_one<64, 64, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
+}
+
+template <int AL, int BL, int EPI>
+void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, bool fast, hipStream_t s) {
+    if (fast) launch_tile<AL, BL, true, EPI>(p, t, tiles_m, slabs, s);
+    else launch_tile<AL, BL, false, EPI>(p, t, tiles_m, slabs, s);
+}
+
+bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+// bl: operand layout of W; epi: fused statistics; part/chunks filled by the caller for epi != 0
+int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const float* B, long ldb, long M, int N, int K,
+             float* C, long ldc, int accumulate, int tile, double* part, int stat_cols, hipStream_t s) {
+    const Tile t = pick_tile(M, N, K, tile);
+    const long tiles_m = (M + t.bm - 1) / t.bm;
+    GemmP p;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K;
+    p.tiles_n = (N + t.bn - 1) / t.bn;
+    p.remap = dc_option(DC_OPT_XCD_REMAP);
+    p.accumulate = accumulate;
+    p.k_per_slab = K; p.slab_stride = 0;
+    p.phase = dc_option(DC_OPT_GEMM_PHASE);
+    p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
+    // fast path: no guards at all (every hot shape of the reference models)
+    const bool fast = M % t.bm == 0 && N % t.bn == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+                      al16p(A) && al16p(B) && al16p(C);
+    if (bl == B_NK) {
+        if (epi == EPI_COLSTATS) launch_fast<A_MK, B_NK, EPI_COLSTATS>(p, t, tiles_m, 1, fast, s);
+        else if (epi == EPI_VNSTATS) launch_fast<A_MK, B_NK, EPI_VNSTATS>(p, t, tiles_m, 1, fast, s);
+        else launch_fast<A_MK, B_NK, EPI_NONE>(p, t, tiles_m, 1, fast, s);
+    } else {
+        launch_fast<A_MK, B_KN, EPI_NONE>(p, t, tiles_m, 1, fast, s);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dc_set_error("%s: %s", name, hipGetErrorString(e));
+        return DC_ERR_LAUNCH;
+    }
+    return DC_OK;
+}
+
+int chunks_for(long M, int N, int K, int tile) {
+    const Tile t = pick_tile(M, N, K, tile);
+    return (int)((M + t.bm - 1) / t.bm);
+}
+
+}  // namespace
+
+// ---- weight gradient through the LDS-staged kernel (called by dc_gemm_tn, gemm_tn.hip) ----------------------------
+// partial[slab][M][N] = A[rows of the slab, M]^T B[rows of the slab, N];  returns the number of slabs.
+struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
+DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
+    DcTnPlan pl;
+    pl.bm = M > 64 ? 128 : 64;
+    pl.bn = N > 64 ? 128 : 64;
+    const long tiles = (long)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn);
+    long slabs = std::min<long>(128, std::max<long>(1, 512 / tiles));      // ~2 workgroups per CU, bounded partial traffic
+    long rps = (R + slabs - 1) / slabs;
+    rps = std::max<long>((rps + BK - 1) / BK * BK, 4 * BK);
+    pl.rows_per_slab = rps;
+    pl.slabs = (int)((R + rps - 1) / rps);
+    return pl;
+}
+int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial,
+                     hipStream_t s) {
+    const DcTnPlan pl = dc_tn_lds_plan(R, M, N);
+    const Tile t{pl.bm, pl.bn};
+    const long tiles_m = (M + t.bm - 1) / t.bm;
+    GemmP p;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = partial; p.ldc = N;
+    p.M = M; p.N = N; p.K = R;
+    p.tiles_n = (N + t.bn - 1) / t.bn;
+    p.remap = 0;                       // tiles x slabs: every workgroup streams its own rows, nothing to co-locate
+    p.accumulate = 0;
+    p.k_per_slab = pl.rows_per_slab; p.slab_stride = (long)M * N;
+    p.phase = dc_option(DC_OPT_GEMM_PHASE);
+    p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
+    const bool fast = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && lda % 4 == 0 &&
+                      ldb % 4 == 0 && N % 4 == 0 && al16p(A) && al16p(B) && al16p(partial);
+    launch_fast<A_KM, B_KN, EPI_NONE>(p, t, tiles_m, pl.slabs, fast, s);
+    return pl.slabs;
+}
+
+// Y[M,N] (ldy) = X[M,K] (ldx) W[N,K]^T (ldw).  tile: 0 = automatic; 1..4 = 128x128, 128x64, 64x64, 64x128.
+DC_EXPORT int dc_linear_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N,
+                                int32_t K, float* Y, int64_t ldy, int32_t tile, void* stream) {
+    DC_REQUIRE(X && W && Y, "dc_linear_forward: null pointer");
+    DC_REQUIRE(M >= 0 && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N, "dc_linear_forward: bad size");
+    if (M == 0) return DC_OK;
+    return run_gemm("dc_linear_forward", B_NK, EPI_NONE, X, ldx, W, ldw, M, N, K, Y, ldy, 0, tile, nullptr, 0,
+                    static_cast<hipStream_t>(stream));
+}
+
+// dX[M,K] (lddx) (+)= dY[M,N] (lddy) W[N,K] (ldw)
+DC_EXPORT int dc_linear_backward_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, int64_t M, int32_t N,
+                                       int32_t K, float* dX, int64_t lddx, int32_t accumulate, int32_t tile,
+                                       void* stream) {
+    DC_REQUIRE(dY && W && dX, "dc_linear_backward_input: null pointer");
+    DC_REQUIRE(M >= 0 && N >= 1 && K >= 1 && lddy >= N && ldw >= K && lddx >= K, "dc_linear_backward_input: bad size");
+    if (M == 0) return DC_OK;
+    // as a product: C[M, K] = A[M, N] B[N, K] -- reduction over N, B stored reduction-major
+    return run_gemm("dc_linear_backward_input", B_KN, EPI_NONE, dY, lddy, W, ldw, M, K, N, dX, lddx, accumulate, tile,
+                    nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+DC_EXPORT size_t dc_linear_stats_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t tile) {
+    return (size_t)chunks_for(M, N, K, tile) * 2 * (size_t)N * sizeof(double);
+}
+
+// Linear + BatchNorm batch statistics in one pass over the output: Y = X W^T and, from the tile sums of the GEMM
+// epilogue, mean / invstd / scale = gamma * invstd / shift = beta - mean * scale (+ running statistics), exactly
+// what dc_bn_stats computes from Y (nn/nonlin.py:24-35).
+DC_EXPORT int dc_linear_bn_stats_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N,
+                                         int32_t K, float* Y, int64_t ldy, const float* gamma, const float* beta,
+                                         float eps, float momentum, float* running_mean, float* running_var,
+                                         float* mean, float* invstd, float* scale, float* shift, int32_t tile,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(X && W && Y && mean && invstd && scale && shift, "dc_linear_bn_stats_forward: null pointer");
+    DC_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N, "dc_linear_bn_stats_forward: bad size");
+    if (!workspace || workspace_bytes < dc_linear_stats_workspace_bytes(M, N, K, tile)) {
+        dc_set_error("dc_linear_bn_stats_forward: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(workspace);
+    if (int rc = run_gemm("dc_linear_bn_stats_forward", B_NK, EPI_COLSTATS, X, ldx, W, ldw, M, N, K, Y, ldy, 0, tile, part,
+                          N, s))
+        return rc;
+    const dccol::BnFin fin{(long)M, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+    hipLaunchKernelGGL((dccol::colreduce_final_kernel<dccol::BnFin>), dim3(N), dim3(64), 0, s, part,
+                       chunks_for(M, N, K, tile), N, fin);
+    DC_CHECK_LAUNCH("dc_linear_bn_stats_forward");
+    return DC_OK;
+}
+
+// Linear + VectorNonLin statistics: PQ[2n, 2co] = V[2n, K] Wst[2co, K]^T with interleaved (P_c, Q_c) columns, and the
+// batch statistics of |y| over the n points, (y_u, y_v) = (P_u - Q_v, P_v + Q_u)  (nn/nonlin.py:63-79; what
+// dc_vn_stats with combine = 2 computes from PQ).
+DC_EXPORT int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const float* Wst, int64_t ldw, int64_t n,
+                                         int32_t co, int32_t K, float* PQ, int64_t ldpq, const float* gamma,
+                                         const float* beta, float eps, float momentum, float* running_mean,
+                                         float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                         int32_t tile, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(V && Wst && PQ && mean && invstd && scale && shift, "dc_linear_vn_stats_forward: null pointer");
+    DC_REQUIRE(n >= 1 && co >= 1 && K >= 1 && ldv >= K && ldw >= K && ldpq >= 2 * co, "dc_linear_vn_stats_forward: bad size");
+    const long M = 2 * n;
+    const int N = 2 * co;
+    if (!workspace || workspace_bytes < dc_linear_stats_workspace_bytes(M, N, K, tile)) {
+        dc_set_error("dc_linear_vn_stats_forward: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(workspace);
+    if (int rc = run_gemm("dc_linear_vn_stats_forward", B_NK, EPI_VNSTATS, V, ldv, Wst, ldw, M, N, K, PQ, ldpq, 0, tile,
+                          part, co, s))
+        return rc;
+    const dccol::BnFin fin{(long)n, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+    hipLaunchKernelGGL((dccol::colreduce_final_kernel<dccol::BnFin>), dim3(co), dim3(64), 0, s, part,
+                       chunks_for(M, N, K, tile), co, fin);
+    DC_CHECK_LAUNCH("dc_linear_vn_stats_forward");
+    return DC_OK;
+}

@@ -169,9 +169,15 @@ Plan make_plan(long R, int M, int N) {
 
 }  // namespace
 
+// LDS-staged variant (gemm.hip): full-line 16-byte loads into LDS, fragments from LDS, 16-byte stores
+struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
+DcTnPlan dc_tn_lds_plan(long R, int M, int N);
+int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial, hipStream_t s);
+
 DC_EXPORT size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N) {
     const Plan p = make_plan(R, M, N);
-    return (size_t)p.slabs * M * N * sizeof(float);
+    const DcTnPlan q = dc_tn_lds_plan(R, M, N);
+    return (size_t)std::max(p.slabs, q.slabs) * M * N * sizeof(float);
 }
 
 // C[M,N] (ldc) (+)= A^T B with A [R,M] (lda), B [R,N] (ldb); M and N multiples of 32.
@@ -185,9 +191,17 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
         dc_set_error("dc_gemm_tn: workspace too small");
         return DC_ERR_WORKSPACE;
     }
-    const Plan p = make_plan(R, M, N);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* partial = static_cast<float*>(workspace);
+    if (dc_option(DC_OPT_TN_LDS)) {
+        const int slabs = dc_tn_lds_launch(A, (long)lda, B, (long)ldb, (long)R, M, N, partial, s);
+        const long mn2 = (long)M * N;
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn2, 64)), dim3(64 * RED_WAVES), 0, s, partial, slabs, mn2, N,
+                           C, (long)ldc, accumulate);
+        DC_CHECK_LAUNCH("dc_gemm_tn");
+        return DC_OK;
+    }
+    const Plan p = make_plan(R, M, N);
     dim3 grid(p.tiles_m * p.tiles_n, p.slabs);
 #define DC_TN_LAUNCH(WM, WN)                                                                                       \
     hipLaunchKernelGGL((gemm_tn_kernel<WM, WN>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, (long)R, M, N, \

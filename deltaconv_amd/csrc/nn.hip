@@ -526,6 +526,131 @@ DC_EXPORT int dc_vn_backward(const float* dout, int64_t lddo, const float* in, i
     return DC_OK;
 }
 
+// ---- split forms for synchronised BatchNorm (data parallel) -------------------
+// The fused entry points above reduce and finalise in one call.  With the batch sharded over ranks the
+// statistics of nn/nonlin.py:24-35 belong to the GLOBAL batch: each rank reduces its rows to fp64 column sums
+// (dc_bn_sums / dc_vn_sums / dc_*_backward_sums), the sums are all-reduced by the host (2C doubles per layer,
+// deltaconv_amd/dp.py), and dc_bn_coeffs_from_sums / dc_*_backward_apply continue from the global sums.
+DC_EXPORT int dc_bn_sums(const float* h, int64_t R, int32_t C, int64_t ldh, double* sums, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(h && sums, "dc_bn_sums: null pointer");
+    DC_REQUIRE(R >= 1 && C >= 1 && ldh >= C, "dc_bn_sums: bad size");
+    DC_WS_CHECK("dc_bn_sums", R, C)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, R, C);
+    const SumsFin fin{sums, C};
+    if (C % 4 == 0 && ldh % 4 == 0 && al16(h))
+        run_colreduce<4>(StatsF<4>{h, (long)ldh}, R, C, w, s, fin);
+    else
+        run_colreduce<1>(StatsF<1>{h, (long)ldh}, R, C, w, s, fin);
+    DC_CHECK_LAUNCH("dc_bn_sums");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_vn_sums(const float* in, int64_t n, int32_t co, int64_t ld, int32_t combine, double* sums,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(in && sums, "dc_vn_sums: null pointer");
+    DC_REQUIRE(n >= 1 && co >= 1 && ld >= (combine ? 2 * co : co), "dc_vn_sums: bad size");
+    DC_WS_CHECK("dc_vn_sums", n, co)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, n, co);
+    const SumsFin fin{sums, co};
+    if (co % 4 == 0 && ld % 4 == 0 && al16(in))
+        run_colreduce<4>(VnStatsF<4>{in, (long)ld, co, combine}, n, co, w, s, fin);
+    else
+        run_colreduce<1>(VnStatsF<1>{in, (long)ld, co, combine}, n, co, w, s, fin);
+    DC_CHECK_LAUNCH("dc_vn_sums");
+    return DC_OK;
+}
+
+// sums[2C] = (sum x, sum x^2) over `count` rows (all ranks) -> mean / invstd / scale / shift (+ running statistics).
+// count <= 0: the row count is read from the device, sums[2C] (a third block of one double, all-reduced with the sums).
+DC_EXPORT int dc_bn_coeffs_from_sums(const double* sums, int64_t count, int32_t C, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* running_mean,
+                                     float* running_var, float* mean, float* invstd, float* scale, float* shift,
+                                     void* stream) {
+    DC_REQUIRE(sums && mean && invstd && scale && shift, "dc_bn_coeffs_from_sums: null pointer");
+    DC_REQUIRE(C >= 1, "dc_bn_coeffs_from_sums: bad size");
+    const BnFin fin{(long)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
+    hipLaunchKernelGGL(bn_coeffs_from_sums_kernel, dim3(dc_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       sums, (long)count, C, fin);
+    DC_CHECK_LAUNCH("dc_bn_coeffs_from_sums");
+    return DC_OK;
+}
+
+// backward, step 1: sums[2C] = (sum dz, sum dz * xhat) over this rank's rows
+DC_EXPORT int dc_bn_act_backward_sums(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                                      float slope, double* sums, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    DC_REQUIRE(dy && h && scale && shift && mean && invstd && sums, "dc_bn_act_backward_sums: null pointer");
+    DC_REQUIRE(R >= 1 && C >= 1 && lddy >= C && ldh >= C, "dc_bn_act_backward_sums: bad size");
+    DC_WS_CHECK("dc_bn_act_backward_sums", R, C)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, R, C);
+    const SumsFin fin{sums, C};
+    if (C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && al16(dy) && al16(h))
+        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
+    else
+        run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
+    DC_CHECK_LAUNCH("dc_bn_act_backward_sums");
+    return DC_OK;
+}
+
+// backward, step 2: dh from the GLOBAL means m1 = sum dz / count, m2 = sum dz * xhat / count (fp32 [C] each)
+DC_EXPORT int dc_bn_act_backward_apply(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                                       const float* scale, const float* shift, const float* mean, const float* invstd,
+                                       const float* gamma, float slope, int32_t training, const float* m1,
+                                       const float* m2, float* dh, int64_t lddh, void* stream) {
+    DC_REQUIRE(dy && h && scale && shift && mean && invstd && m1 && m2 && dh, "dc_bn_act_backward_apply: null pointer");
+    DC_REQUIRE(R >= 1 && C >= 1 && lddy >= C && ldh >= C && lddh >= C, "dc_bn_act_backward_apply: bad size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && lddh % 4 == 0 && al16(dy) && al16(h) && al16(dh))
+        run_tile<4>(BnActBwdBody<4>{dy, h, scale, shift, mean, invstd, gamma, m1, m2, dh, (long)lddy, (long)ldh,
+                                    (long)lddh, slope, training}, R, C, s);
+    else
+        run_tile<1>(BnActBwdBody<1>{dy, h, scale, shift, mean, invstd, gamma, m1, m2, dh, (long)lddy, (long)ldh,
+                                    (long)lddh, slope, training}, R, C, s);
+    DC_CHECK_LAUNCH("dc_bn_act_backward_apply");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_vn_backward_sums(const float* dout, int64_t lddo, const float* in, int64_t ld, int32_t combine,
+                                  int64_t n, int32_t co, const float* scale, const float* shift, const float* mean,
+                                  const float* invstd, double* sums, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    DC_REQUIRE(dout && in && scale && shift && mean && invstd && sums, "dc_vn_backward_sums: null pointer");
+    DC_REQUIRE(n >= 1 && co >= 1 && lddo >= co && ld >= (combine ? 2 * co : co), "dc_vn_backward_sums: bad size");
+    DC_WS_CHECK("dc_vn_backward_sums", n, co)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, n, co);
+    const SumsFin fin{sums, co};
+    if (co % 4 == 0 && ld % 4 == 0 && lddo % 4 == 0 && al16(in) && al16(dout))
+        run_colreduce<4>(VnBwdF<4>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s, fin);
+    else
+        run_colreduce<1>(VnBwdF<1>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s, fin);
+    DC_CHECK_LAUNCH("dc_vn_backward_sums");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_vn_backward_apply(const float* dout, int64_t lddo, const float* in, int64_t ld, int32_t combine,
+                                   int64_t n, int32_t co, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, const float* gamma, int32_t training, const float* m1,
+                                   const float* m2, float* din, int64_t lddi, void* stream) {
+    DC_REQUIRE(dout && in && scale && shift && mean && invstd && m1 && m2 && din, "dc_vn_backward_apply: null pointer");
+    DC_REQUIRE(n >= 1 && co >= 1 && lddo >= co && ld >= (combine ? 2 * co : co) && lddi >= (combine ? 2 * co : co),
+               "dc_vn_backward_apply: bad size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (co % 4 == 0 && ld % 4 == 0 && lddo % 4 == 0 && lddi % 4 == 0 && al16(in) && al16(dout) && al16(din))
+        run_tile<4>(VnBwdBody<4>{in, dout, scale, shift, mean, invstd, gamma, m1, m2, din, (long)ld, (long)lddo,
+                                 (long)lddi, co, combine, training}, n, co, s);
+    else
+        run_tile<1>(VnBwdBody<1>{in, dout, scale, shift, mean, invstd, gamma, m1, m2, din, (long)ld, (long)lddo,
+                                 (long)lddi, co, combine, training}, n, co, s);
+    DC_CHECK_LAUNCH("dc_vn_backward_apply");
+    return DC_OK;
+}
+
 // ---- embedding head fused with per-cloud pooling ---------------------------------------------------
 // pooled[B, ldp] = [max_i y | mean_i y] over the N rows of each cloud, y = leaky(scale*h + shift);
 // argmax[B, C] = first maximal row within the cloud.  with_mean == 0 writes only the max block.

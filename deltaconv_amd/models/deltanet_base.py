@@ -87,7 +87,9 @@ class DeltaNetBase(torch.nn.Module):
         # heads concatenate them: deltanet_classification.py:42, deltanet_segmentation.py:58) when all layers
         # run as fused nodes; otherwise plain tensors
         widths = [c.out_channels for c in self.convs]
-        fusable = all(c.fuse_layer and c._fusable() is not None and w % 4 == 0 for c, w in zip(self.convs, widths))
+        from ..nn import fused
+        fusable = fused.sync_group() is None and all(c.fuse_layer and c._fusable() is not None and w % 4 == 0
+                                                     for c, w in zip(self.convs, widths))
         blocks = None
         if fusable and x.is_cuda:
             xall = torch.empty(x.shape[0], sum(widths), dtype=torch.float32, device=x.device)

@@ -34,7 +34,7 @@ def embed_and_pool(mlp, x, ptr_info, with_mean):
     blocks = list(mlp)
     last = blocks[-1]
     slope = fused.slope_of(last[2]) if isinstance(last, MLPBlock) else None
-    if _equal(ptr_info, x.shape[0]) and slope is not None and x.is_cuda:
+    if _equal(ptr_info, x.shape[0]) and slope is not None and x.is_cuda and fused.sync_group() is None:
         for blk in blocks[:-1]:
             x = blk(x)
         h = fused.linear(x, last[0].weight, last[0].bias)

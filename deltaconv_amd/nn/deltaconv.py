@@ -53,7 +53,8 @@ class DeltaConv(torch.nn.Module):
         out_block (optional): (buffer [n, W], column offset) of a concatenation buffer; when the layer runs as
         one fused node x' is ALSO written into that column block, which is returned as x."""
         graph = as_graph(edge_index, grad.graph)
-        slopes = self._fusable() if self.fuse_layer else None
+        # synchronised BatchNorm (dp.py) runs through the composed blocks: their statistics kernels have the split form
+        slopes = self._fusable() if (self.fuse_layer and fused.sync_group() is None) else None
         if slopes is None:
             return self.forward_composed(x, v, grad, div, graph)
         bm, bs = self.s_mlp_max[0], self.s_mlp[0]
@@ -106,7 +107,7 @@ class DeltaConv(torch.nn.Module):
         blocks = list(self.s_mlp_max)
         blk = blocks[0]
         slope = fused.slope_of(blk[2]) if isinstance(blk, MLPBlock) else None
-        if len(blocks) == 1 and slope is not None and slope >= 0 and blk[0].bias is None:
+        if len(blocks) == 1 and slope is not None and slope >= 0 and blk[0].bias is None and fused.sync_group() is None:
             y = F.linear(x, blk[0].weight)
             return fused.edge_max_bn(y, graph, blk[1].bn, slope)
         n, k = graph.n, graph.k

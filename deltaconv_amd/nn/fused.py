@@ -47,6 +47,23 @@ class defer_counters:
         return False
 
 
+def sync_group():
+    """Process group over which BatchNorm statistics are synchronised (deltaconv_amd/dp.py), or None."""
+    from .. import dp
+    return dp.sync_state()
+
+
+def _sync_stats(kernel_args, c, rows, dev, group):
+    """Local fp64 sums via a dc_*_sums entry point -> [sum_0 | sum_1 | rows] all-reduced over `group`.
+    Returns (global stats, local stats)."""
+    from .. import dp
+    local = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+    local[2 * c] = float(rows)
+    name, args = kernel_args
+    lib.call(name, *args(local))
+    return dp.all_reduce_stats(local.clone(), group), local
+
+
 def check_bn_rows(bn, rows):
     """torch.nn.functional.batch_norm refuses a train-mode batch with one value per channel (the reference
     hits this at B = 1 in its head: deltaconv/nn/nonlin.py:29-30, SURVEY.md section 8(d) C1 caveat); same here."""
@@ -75,7 +92,14 @@ class _BNAct(torch.autograd.Function):
         r, c = h.shape
         dev = h.device
         coef = torch.empty(4, c, dtype=torch.float32, device=dev)     # mean, invstd, scale, shift
-        if use_batch_stats:
+        ctx.group = sync_group() if use_batch_stats else None
+        if ctx.group is not None:                                     # statistics of the global batch
+            ws, nb = _ws(r, c, dev)
+            stats, _ = _sync_stats(("dc_bn_sums", lambda out: (h, r, c, c, out, ws, nb)), c, r, dev, ctx.group)
+            ctx.stats_cnt = stats[2 * c:2 * c + 1]
+            lib.call("dc_bn_coeffs_from_sums", stats, 0, c, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1],
+                     coef[2], coef[3])
+        elif use_batch_stats:
             ws, nb = _ws(r, c, dev)
             lib.call("dc_bn_stats", h, r, c, c, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1], coef[2],
                      coef[3], ws, nb)
@@ -98,8 +122,20 @@ class _BNAct(torch.autograd.Function):
         dgamma = torch.empty(c, dtype=torch.float32, device=h.device) if has_g else None
         dbeta = torch.empty(c, dtype=torch.float32, device=h.device) if has_b else None
         ws, nb = _ws(r, c, h.device)
-        lib.call("dc_bn_act_backward", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
-                 int(training), dh, c, dgamma, dbeta, ws, nb)
+        if ctx.group is not None:
+            stats, local = _sync_stats(("dc_bn_act_backward_sums", lambda out: (dy, c, h, c, r, c, coef[2], coef[3], coef[0],
+                                                                             coef[1], slope, out, ws, nb)), c, 0, h.device,
+                                       ctx.group)
+            if has_b:
+                dbeta.copy_(local[:c])
+            if has_g:
+                dgamma.copy_(local[c:2 * c])
+            m = (stats[:2 * c] / ctx.stats_cnt).float()
+            lib.call("dc_bn_act_backward_apply", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
+                     int(training), m[:c], m[c:], dh, c)
+        else:
+            lib.call("dc_bn_act_backward", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
+                     int(training), dh, c, dgamma, dbeta, ws, nb)
         return dh, dgamma, dbeta, None, None, None, None, None, None, (dy if has_res else None)
 
 
@@ -129,7 +165,15 @@ class _VectorNonLin(torch.autograd.Function):
         n = inp.shape[0] // 2
         dev = inp.device
         coef = torch.empty(4, co, dtype=torch.float32, device=dev)
-        if mode == 2:
+        ctx.group = sync_group() if mode == 2 else None
+        if ctx.group is not None:
+            ws, nb = _ws(n, co, dev)
+            stats, _ = _sync_stats(("dc_vn_sums", lambda out: (inp, n, co, ld, int(combine), out, ws, nb)), co, n, dev,
+                                   ctx.group)
+            ctx.stats_cnt = stats[2 * co:2 * co + 1]
+            lib.call("dc_bn_coeffs_from_sums", stats, 0, co, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1],
+                     coef[2], coef[3])
+        elif mode == 2:
             ws, nb = _ws(n, co, dev)
             lib.call("dc_vn_stats", inp, n, co, ld, int(combine), gamma, beta, eps, momentum, rm, rv, coef[0],
                      coef[1], coef[2], coef[3], ws, nb)
@@ -156,8 +200,20 @@ class _VectorNonLin(torch.autograd.Function):
         dgamma = torch.empty(co, dtype=torch.float32, device=dev) if has_g else None
         dbeta = torch.empty(co, dtype=torch.float32, device=dev) if has_b else None
         ws, nb = _ws(n, co, dev)
-        lib.call("dc_vn_backward", dout, co, inp, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1],
-                 gamma if mode else None, int(mode == 2), din, ld, dgamma, dbeta, ws, nb)
+        if ctx.group is not None:
+            stats, local = _sync_stats(("dc_vn_backward_sums", lambda out: (dout, co, inp, ld, combine, n, co, coef[2], coef[3],
+                                                                         coef[0], coef[1], out, ws, nb)), co, 0, dev,
+                                       ctx.group)
+            if has_b:
+                dbeta.copy_(local[:co])
+            if has_g:
+                dgamma.copy_(local[co:2 * co])
+            m = (stats[:2 * co] / ctx.stats_cnt).float()
+            lib.call("dc_vn_backward_apply", dout, co, inp, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1], gamma,
+                     1, m[:co], m[co:], din, ld)
+        else:
+            lib.call("dc_vn_backward", dout, co, inp, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1],
+                     gamma if mode else None, int(mode == 2), din, ld, dgamma, dbeta, ws, nb)
         return din, None, dgamma, dbeta, None, None, None, None, None
 
 

@@ -186,6 +186,65 @@ size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N);
 int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N, float* C,
                int64_t ldc, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- split statistics for synchronised BatchNorm (data parallel) ----------------------------------------
+ * Same arithmetic as dc_bn_stats / dc_vn_stats / dc_bn_act_backward / dc_vn_backward (nn/nonlin.py:24-35, 63-79),
+ * cut at the reduction so that the host can all-reduce the fp64 column sums across ranks in between
+ * (deltaconv_amd/dp.py).  sums: double [2*C] = (sum_0[C], sum_1[C]).
+ *   forward : dc_bn_sums | dc_vn_sums -> all-reduce -> dc_bn_coeffs_from_sums(count = rows of ALL ranks; count <= 0:
+ *             the count is on the device at sums[2*C], all-reduced together with the sums -- no host sync)
+ *   backward: dc_*_backward_sums -> all-reduce -> m1 = sum_0 / count, m2 = sum_1 / count -> dc_*_backward_apply;
+ *             dbeta = local sum_0, dgamma = local sum_1 (averaged with the other gradients afterwards). */
+int dc_bn_sums(const float* h, int64_t R, int32_t C, int64_t ldh, double* sums, void* workspace,
+               size_t workspace_bytes, void* stream);
+int dc_vn_sums(const float* in, int64_t n, int32_t co, int64_t ld, int32_t combine, double* sums, void* workspace,
+               size_t workspace_bytes, void* stream);
+int dc_bn_coeffs_from_sums(const double* sums, int64_t count, int32_t C, const float* gamma, const float* beta,
+                           float eps, float momentum, float* running_mean, float* running_var, float* mean,
+                           float* invstd, float* scale, float* shift, void* stream);
+int dc_bn_act_backward_sums(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                            const float* scale, const float* shift, const float* mean, const float* invstd,
+                            float slope, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int dc_bn_act_backward_apply(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             const float* gamma, float slope, int32_t training, const float* m1, const float* m2,
+                             float* dh, int64_t lddh, void* stream);
+int dc_vn_backward_sums(const float* dout, int64_t lddo, const float* in, int64_t ld, int32_t combine, int64_t n,
+                        int32_t co, const float* scale, const float* shift, const float* mean, const float* invstd,
+                        double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int dc_vn_backward_apply(const float* dout, int64_t lddo, const float* in, int64_t ld, int32_t combine, int64_t n,
+                         int32_t co, const float* scale, const float* shift, const float* mean, const float* invstd,
+                         const float* gamma, int32_t training, const float* m1, const float* m2, float* din,
+                         int64_t lddi, void* stream);
+
+/* ---- forward / input-gradient GEMMs of the per-point Linear layers on the fp32 matrix cores -------------
+ * Replace ATen addmm / mm behind every `Linear(bias=False)` of deltaconv/nn/mlp.py:9,15 (forward product and the
+ * input-gradient product of its autograd).  v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged, any M, N, K and
+ * leading dimensions (an unguarded fast path when everything is tile-aligned).  tile: 0 = automatic,
+ * 1..4 = 128x128, 128x64, 64x64, 64x128 (measurement).
+ *   dc_linear_forward           Y[M,N]  = X[M,K] W[N,K]^T
+ *   dc_linear_backward_input    dX[M,K] (+)= dY[M,N] W[N,K]
+ * and the forward product fused with the statistics of the layer that follows it (nn/nonlin.py:24-35, 63-79):
+ *   dc_linear_bn_stats_forward  Y = X W^T  + BatchNorm batch statistics of Y (== dc_bn_stats on Y)
+ *   dc_linear_vn_stats_forward  PQ[2n,2co] = V[2n,K] Wst[2co,K]^T (columns interleaved (P_c, Q_c)) + statistics of
+ *                               |y| over the n points (== dc_vn_stats(combine = 2) on PQ)
+ * The statistics come out of the GEMM epilogue (fp64 tile sums, ordered final stage): no pass over Y.
+ * Workspace: dc_linear_stats_workspace_bytes(M, N, K, tile)  (vn: M = 2n, N = 2co). */
+int dc_linear_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K,
+                      float* Y, int64_t ldy, int32_t tile, void* stream);
+int dc_linear_backward_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, int64_t M, int32_t N,
+                             int32_t K, float* dX, int64_t lddx, int32_t accumulate, int32_t tile, void* stream);
+size_t dc_linear_stats_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t tile);
+int dc_linear_bn_stats_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N,
+                               int32_t K, float* Y, int64_t ldy, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift, int32_t tile, void* workspace, size_t workspace_bytes,
+                               void* stream);
+int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const float* Wst, int64_t ldw, int64_t n, int32_t co,
+                               int32_t K, float* PQ, int64_t ldpq, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift, int32_t tile, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 /* ---- embedding head fused with the per-cloud pooling -------------------------------------------------
  * MLP([sum c, E]) -> global_max_pool | global_mean_pool  (deltaconv/models/deltanet_classification.py:42-49),
  * -> global_max_pool (deltanet_segmentation.py:58-61).  h = Linear output [B*N, C] (equal-size clouds);

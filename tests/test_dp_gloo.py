@@ -1,7 +1,8 @@
 """Data-parallel path on CPU: world_size-2 gloo processes.  Checks (1) FlatGradDataParallel's
 single flat all-reduce gives every rank the average gradient = the gradient of the global-batch
-mean loss, (2) Batch.shard partitions clouds with no overlap, (3) the oracle model trained on two
-shards (BN-free comparison) matches a single-process run on the full batch."""
+mean loss, (2) Batch.shard partitions clouds with no overlap, (3) the WHOLE model (the oracle's
+DeltaNetClassification, every BatchNorm converted to the synchronised form of deltaconv_amd/dp.py) stepped on two
+shards with sync_bn=True reproduces a single process on the full batch: logits, running statistics, gradients."""
 import os
 import sys
 
@@ -73,3 +74,73 @@ def test_shard_per_point_labels_and_categories():
     assert torch.equal(torch.cat([p.category for p in parts]), full.category)
     assert all(p.num_graphs == 2 and p.batch.max() == 1 and p.batch.min() == 0 for p in parts)
     assert parts[1].ptr.tolist() == [0, 16, 32]
+
+
+def _oracle_model():
+    import oracle
+    torch.manual_seed(1)
+    m = oracle.models.DeltaNetClassification(3, 10, conv_channels=(16, 16, 32), num_neighbors=8).train()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def _sync_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from deltaconv_amd.dp import FlatGradDataParallel, convert_sync_batchnorm
+    from deltaconv_amd.data import synthetic_batch
+    model = convert_sync_batchnorm(_oracle_model())
+    ddp = FlatGradDataParallel(model, sync_bn=True)
+    full = synthetic_batch(4, 96, seed=9, num_classes=10)
+    shard = full.shard(rank, world)
+    ddp.zero_grad()
+    out = ddp(shard)
+    oracle.loss.calc_loss(out, shard.y).backward()
+    ddp.reduce_gradients()
+    # numpy payloads: pickled by value (torch tensors travel as file descriptors the exiting worker may close first)
+    q.put((rank, out.detach().numpy().copy(),
+           {n: p.grad.numpy().copy() for n, p in model.named_parameters() if p.grad is not None},
+           {n: b.numpy().copy() for n, b in model.named_buffers() if "running" in n}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_whole_model_matches_single_process():
+    world, port = 2, 29547
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    t = torch.from_numpy
+    res = [(r, t(o), {n: t(g) for n, g in gs.items()}, {n: t(b) for n, b in bs.items()}) for r, o, gs, bs in res]
+    sys.path.insert(0, ROOT)
+    import oracle
+    from deltaconv_amd.data import synthetic_batch
+    ref = _oracle_model()
+    full = synthetic_batch(4, 96, seed=9, num_classes=10)
+    out = ref(full)
+    oracle.loss.calc_loss(out, full.y).backward()
+    logits = torch.cat([res[0][1], res[1][1]])
+    assert torch.allclose(logits, out, atol=2e-4, rtol=1e-4)           # global statistics: every cloud sees the same BN
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for n, p in ref.named_parameters():
+        if p.grad is None:
+            assert n not in res[0][2]
+            continue
+        for r in range(world):                                          # both ranks hold the same reduced gradient
+            err = float((res[r][2][n] - p.grad).abs().max()) / max(float(p.grad.abs().max()), 1e-3 * gmax)
+            assert err < 2e-3, (n, r, err)
+    for n, b in ref.named_buffers():
+        if "running" in n:
+            assert torch.allclose(res[0][3][n], b, atol=1e-5, rtol=1e-4), n
+            assert torch.equal(res[0][3][n], res[1][3][n]), n           # replicas stay identical

@@ -27,3 +27,17 @@ def test_bench_under_torchrun_single_rank():
         assert key in d
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and d["dtype"] == "f32"
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_graph_replay_with_gradient_reducer_and_sync_bn():
+    """tests/dist/gpu_worker.py under the launcher: (1) HIP-graph step + reduce_gradients() + optimizer for 3 steps is
+    bit-identical to eager; (2) the synchronised-BatchNorm path (split statistics kernels, all-reduced fp64 sums)
+    agrees with per-rank statistics on one rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "dist", "gpu_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["graph_dp_mismatches"] == []
+    assert d["sync_logits_err"] < 1e-4 and d["sync_grad_err"] < 5e-3 and d["sync_running_err"] < 1e-5, d

@@ -1,0 +1,142 @@
+"""Hand-written fp32-MFMA forward / input-gradient GEMMs (csrc/gemm.hip) vs a float64 torch product, through the
+C ABI: hot shapes of the reference models, ragged / unaligned / strided shapes, every tile configuration, the
+accumulate form, and the fused statistics epilogues against the stand-alone statistics kernels.
+Tolerance: fp32 accumulation over K terms -> scale-relative 2e-6 * sqrt(K) + 1e-6 (measured ~3e-7 * sqrt(K))."""
+import math
+
+import pytest
+import torch
+
+from deltaconv_amd._lib import lib
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1).to(DEV)        # asymmetric, full-range signs
+
+
+def _tol(k):
+    return 2e-6 * math.sqrt(k) + 1e-6
+
+
+SHAPES = [  # M, N, K
+    (32768, 64, 64), (32768, 64, 256), (32768, 128, 256), (32768, 256, 512), (8192, 1024, 512),
+    (65536, 128, 192), (65536, 256, 256),
+    (4096, 64, 12), (4096, 128, 70), (4096, 64, 3), (1000, 40, 256), (777, 50, 128), (130, 12, 64), (64, 64, 32),
+    (1, 8, 5), (2050, 192, 100),
+]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_linear_forward(M, N, K, tile):
+    if tile and M * N > 40_000_000:
+        pytest.skip("tile sweep on the big shapes is the lab's job")
+    x, w = _rand(M, K, seed=1), _rand(N, K, seed=2)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    lib.call("dc_linear_forward", x, K, w, K, M, N, K, y, N, tile)
+    ref = x.double() @ w.double().t()
+    assert rel_err(y, ref) < _tol(K)
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("tile", [0, 1, 3])
+def test_linear_backward_input(M, N, K, tile):
+    dy, w = _rand(M, N, seed=3), _rand(N, K, seed=4)
+    ref = dy.double() @ w.double()
+    dx = torch.full((M, K), float("nan"), device=DEV)
+    lib.call("dc_linear_backward_input", dy, N, w, K, M, N, K, dx, K, 0, tile)
+    assert rel_err(dx, ref) < _tol(N)
+    base = _rand(M, K, seed=5)
+    dx2 = base.clone()
+    lib.call("dc_linear_backward_input", dy, N, w, K, M, N, K, dx2, K, 1, tile)
+    assert rel_err(dx2, ref + base.double()) < _tol(N)
+
+
+def test_strided_operands_and_outputs():
+    """Operands / outputs living inside wider buffers (the concat-free layer buffers): leading dimensions."""
+    M, N, K = 3000, 64, 96
+    xbuf, ybuf = _rand(M, 4 * K, seed=6), torch.zeros(M, 3 * N, device=DEV)
+    x = xbuf[:, K:2 * K]
+    w = _rand(N, K, seed=7)
+    y = ybuf[:, N:2 * N]
+    lib.call("dc_linear_forward", x, 4 * K, w, K, M, N, K, y, 3 * N, 0)
+    assert rel_err(y, x.double() @ w.double().t()) < _tol(K)
+    assert float(ybuf[:, :N].abs().max()) == 0.0 and float(ybuf[:, 2 * N:].abs().max()) == 0.0
+    # unaligned base (offset of 1 float) and a weight view with an odd leading dimension (the [2co, K] view at K = 70)
+    xo = xbuf[:, 1:1 + K]
+    wbig = _rand(N, 2 * 35, seed=8)
+    wv = wbig.view(2 * N, 35)
+    xs = _rand(M, 35, seed=9)
+    y2 = torch.empty(M, 2 * N, device=DEV)
+    lib.call("dc_linear_forward", xs, 35, wv, 35, M, 2 * N, 35, y2, 2 * N, 0)
+    assert rel_err(y2, xs.double() @ wv.double().t()) < _tol(35)
+    y3 = torch.empty(M, N, device=DEV)
+    lib.call("dc_linear_forward", xo, 4 * K, w, K, M, N, K, y3, N, 0)
+    assert rel_err(y3, xo.double() @ w.double().t()) < _tol(K)
+
+
+def _bn_reference(y, gamma, beta, eps, mom, rm, rv):
+    r, c = y.shape
+    coef = torch.empty(4, c, device=DEV)
+    nb = lib.raw("dc_bn_workspace_bytes")(r, c)
+    ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=DEV)
+    lib.call("dc_bn_stats", y, r, c, c, gamma, beta, eps, mom, rm, rv, coef[0], coef[1], coef[2], coef[3], ws, nb)
+    return coef
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 64, 256), (4096, 256, 128), (1000, 40, 64), (130, 128, 70), (2, 64, 32)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_linear_bn_stats(M, N, K, tile):
+    x, w = _rand(M, K, seed=10), _rand(N, K, seed=11)
+    gamma, beta = _rand(N, seed=12) + 1.5, _rand(N, seed=13)
+    rm1, rv1 = _rand(N, seed=14), _rand(N, seed=15) + 2
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    y = torch.empty(M, N, device=DEV)
+    coef = torch.empty(4, N, device=DEV)
+    nb = lib.raw("dc_linear_stats_workspace_bytes")(M, N, K, tile)
+    ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=DEV)
+    lib.call("dc_linear_bn_stats_forward", x, K, w, K, M, N, K, y, N, gamma, beta, 1e-5, 0.1, rm1, rv1, coef[0], coef[1],
+             coef[2], coef[3], tile, ws, nb)
+    assert rel_err(y, x.double() @ w.double().t()) < _tol(K)
+    ref = _bn_reference(y, gamma, beta, 1e-5, 0.1, rm2, rv2)       # stand-alone statistics of the SAME output
+    for q in range(4):
+        assert rel_err(coef[q], ref[q]) < 1e-5, q
+    assert rel_err(rm1, rm2) < 1e-6 and rel_err(rv1, rv2) < 1e-5
+
+
+@pytest.mark.parametrize("n,co,K", [(16384, 64, 192), (2048, 128, 256), (500, 32, 70), (65, 20, 35), (1, 16, 32)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_linear_vn_stats(n, co, K, tile):
+    v, w = _rand(2 * n, K, seed=20), _rand(2 * co, K, seed=21)
+    gamma, beta = _rand(co, seed=22) + 1.5, _rand(co, seed=23)
+    rm1, rv1 = _rand(co, seed=24), _rand(co, seed=25) + 2
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    pq = torch.empty(2 * n, 2 * co, device=DEV)
+    coef = torch.empty(4, co, device=DEV)
+    nb = lib.raw("dc_linear_stats_workspace_bytes")(2 * n, 2 * co, K, tile)
+    ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=DEV)
+    lib.call("dc_linear_vn_stats_forward", v, K, w, K, n, co, K, pq, 2 * co, gamma, beta, 1e-5, 0.1, rm1, rv1, coef[0],
+             coef[1], coef[2], coef[3], tile, ws, nb)
+    assert rel_err(pq, v.double() @ w.double().t()) < _tol(K)
+    ref = torch.empty(4, co, device=DEV)
+    nb2 = lib.raw("dc_bn_workspace_bytes")(n, co)
+    ws2 = torch.empty((nb2 + 7) // 8, dtype=torch.float64, device=DEV)
+    lib.call("dc_vn_stats", pq, n, co, 2 * co, 2, gamma, beta, 1e-5, 0.1, rm2, rv2, ref[0], ref[1], ref[2], ref[3], ws2, nb2)
+    for q in range(4):
+        assert rel_err(coef[q], ref[q]) < 1e-5, q
+    assert rel_err(rm1, rm2) < 1e-6 and rel_err(rv1, rv2) < 1e-5
+
+
+def test_gemm_is_deterministic():
+    x, w = _rand(32768, 256, seed=30), _rand(128, 256, seed=31)
+    outs = []
+    for _ in range(2):
+        y = torch.empty(32768, 128, device=DEV)
+        lib.call("dc_linear_forward", x, 256, w, 256, 32768, 128, 256, y, 128, 0)
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])

@@ -112,9 +112,12 @@ def test_model_step_golden(name):
     assert np.max(np.abs(np.array(dots) - gd) / (gn + 1e-3 * gn.max())) < 5 * tol
     # and two weight gradients element by element (first edge MLP, first vector MLP)
     params = dict(model.named_parameters())
+    # (fp64 = truth.  The reference's own fp32 run is only as close to truth as its max-aggregation argmax
+    # choices allow -- 1.2e-2 on the edge-MLP weight of the B4 fixture -- so against it the bound is self-calibrated.)
     for pkey in ("deltanet_base.convs.0.s_mlp_max.0.0.weight", "deltanet_base.convs.1.v_mlp.0.0.weight"):
-        for tag in ("f64", "f32"):
-            assert rel_err(params[pkey].grad, g[f"g_{pkey}_{tag}"]) < 5 * tol, (pkey, tag)
+        g64, g32 = g[f"g_{pkey}_f64"], g[f"g_{pkey}_f32"]
+        assert rel_err(params[pkey].grad, g64) < 5 * tol, pkey
+        assert rel_err(params[pkey].grad, g32) < 5 * tol + rel_err(g32, g64), pkey
     key = ("lin_global" if kind == "seg" else "lin_embedding") + ".0.1.bn.running_mean"
     assert rel_err(dict(model.named_buffers())[key], g["rm_embed_f64"]) < tol
     assert rel_err(dict(model.named_buffers())[key.replace("running_mean", "running_var")], g["rv_embed_f64"]) < tol
