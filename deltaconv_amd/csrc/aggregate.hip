@@ -25,6 +25,89 @@ struct KnnMaxAffineF {
         knn_max_affine_fwd<V>(i, c0, r.ids, k, h, ldh, scale, shift, slope, out, ldo, arg, lda);
     }
 };
+
+// ---- backward: dh[j,c] (+)= sum over in-edges (i,s) of j with arg[i,c] == s of dout[i,c] -----------------------------
+// Same sums in the same (ascending edge) order as the generic transposed skeleton, but the loop over the in-edge list
+// runs in batches of KB edges: all KB slot words arg[i, c0:c0+4] are loaded first (independent 4-byte loads), then the
+// dout rows of the batch's hits (exec-masked 16-byte loads, issued together).  The edge-at-a-time form has two
+// DEPENDENT global loads per in-edge (the test needs the slot word, the value load needs the test): ~40 serialized L2
+// round trips per thread, 0.13 of the HBM roofline in r01 (profiles/r01p_kernels.log); batched it is 2 per KB edges.
+constexpr int KB = 8;
+
+template <int V>
+__global__ __launch_bounds__(256) void knn_max_bwd_kernel(long total, int groups, int remap, const int* __restrict__ tptr,
+                                                          const int* __restrict__ tedge, int k,
+                                                          const unsigned char* __restrict__ arg, long lda,
+                                                          const float* __restrict__ dout, long ldo,
+                                                          float* __restrict__ dh, long ldh, int accumulate) {
+    __shared__ int src[T_CHUNK];
+    __shared__ unsigned char slot[T_CHUNK];
+    const int tpb = blockDim.x;
+    const long t0 = dc_xcd_block(remap) * tpb;
+    if (t0 >= total) return;  // block-uniform
+    const long tl = min(t0 + (long)tpb, total) - 1;
+    const long pf = t0 / groups, pl = tl / groups;
+    const int e_begin = tptr[pf], e_end = tptr[pl + 1];
+    const long t = t0 + threadIdx.x;
+    const bool active = t < total;
+    const long j = active ? t / groups : pf;
+    const int c0 = active ? (int)(t - j * groups) * V : 0;
+    const int cb = active ? tptr[j] : 0, ce = active ? tptr[j + 1] : 0;
+    Vec<V> acc = vzero<V>();
+    for (int base = e_begin; base < e_end; base += T_CHUNK) {
+        const int cnt = min(T_CHUNK, e_end - base);
+        __syncthreads();
+        for (int q = threadIdx.x; q < cnt; q += tpb) {
+            const int e = tedge[base + q];
+            const int i = e / k;
+            src[q] = i;
+            slot[q] = (unsigned char)(e - i * k);
+        }
+        __syncthreads();
+        const int lo = max(cb, base) - base, hi = min(ce, base + cnt) - base;
+        for (int p0 = lo; p0 < hi; p0 += KB) {
+            unsigned hit[KB];       // bit q: channel c0 + q of edge p0 + u is the arg-max of its source point
+            long row[KB];
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const int p = p0 + u;
+                const bool ok = p < hi;
+                row[u] = ok ? (long)src[p] : 0;
+                const unsigned s = ok ? (unsigned)slot[p] : 0x1ffu;      // 0x1ff never equals a slot byte
+                unsigned m = 0;
+                if (V == 4) {   // the four slot bytes in one 32-bit load (c0 and lda are multiples of 4)
+                    const unsigned w = *reinterpret_cast<const unsigned*>(arg + row[u] * lda + c0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) m |= (((w >> (8 * q)) & 0xffu) == s ? 1u : 0u) << q;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < V; ++q) m |= ((unsigned)arg[row[u] * lda + c0 + q] == s ? 1u : 0u) << q;
+                }
+                hit[u] = m;
+            }
+            Vec<V> g[KB];
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                g[u] = vzero<V>();
+                if (hit[u]) g[u] = vload<V>(dout + row[u] * ldo + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < KB; ++u)
+#pragma unroll
+                for (int q = 0; q < V; ++q) acc.v[q] += ((hit[u] >> q) & 1u) ? g[u].v[q] : 0.f;
+        }
+    }
+    if (active) vout<V>(dh + j * ldh + c0, acc, accumulate);
+}
+
+template <int V>
+void launch_knn_max_bwd(long n, int C, const int* tptr, const int* tedge, int k, const unsigned char* arg,
+                        const float* dout, long ldo, float* dh, long ldh, int accumulate, hipStream_t s) {
+    const int groups = C / V;
+    const long total = n * groups;
+    hipLaunchKernelGGL((knn_max_bwd_kernel<V>), dim3(dc_cdiv(total, 256)), dim3(256), 0, s, total, groups,
+                       dc_option(DC_OPT_XCD_REMAP), tptr, tedge, k, arg, (long)C, dout, ldo, dh, ldh, accumulate);
+}
 }  // namespace
 
 DC_EXPORT int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float* out,
@@ -69,10 +152,16 @@ DC_EXPORT int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int
     DC_REQUIRE(ldo >= C && ldh >= C, "dc_knn_max_backward: leading dimension smaller than the row");
     if (n == 0 || C == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (pick_v(C, {(long)ldo, (long)ldh}, {dout, dh}) == 4)
-        launch_T<4>(n, C, nullptr, tptr, tedge, k, KnnMaxT<4>{arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate, C}, s);
-    else
-        launch_T<1>(n, C, nullptr, tptr, tedge, k, KnnMaxT<1>{arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate, C}, s);
+    if (dc_option(DC_OPT_GATHER_BATCH)) {       // A/B switch: the edge-at-a-time generic skeleton
+        if (pick_v(C, {(long)ldo, (long)ldh}, {dout, dh}) == 4)
+            launch_T<4>(n, C, nullptr, tptr, tedge, k, KnnMaxT<4>{arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate, C}, s);
+        else
+            launch_T<1>(n, C, nullptr, tptr, tedge, k, KnnMaxT<1>{arg, (long)C, dout, (long)ldo, dh, (long)ldh, accumulate, C}, s);
+    } else if (pick_v(C, {(long)ldo, (long)ldh}, {dout, dh}) == 4) {
+        launch_knn_max_bwd<4>(n, C, tptr, tedge, k, arg, dout, (long)ldo, dh, (long)ldh, accumulate, s);
+    } else {
+        launch_knn_max_bwd<1>(n, C, tptr, tedge, k, arg, dout, (long)ldo, dh, (long)ldh, accumulate, s);
+    }
     DC_CHECK_LAUNCH("dc_knn_max_backward");
     return DC_OK;
 }

@@ -36,6 +36,7 @@
 // Bound: MFMA (157 TFLOP/s fp32).  Per 32-deep K tile a 128 x 128 workgroup issues 64 MFMAs per wave (4096
 // cycles) against 32 KB of global loads (8 B/clk/CU) and 16 ds_read_b128 per wave.
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "nn_math.h"
 #include "colreduce.h"
@@ -61,6 +62,7 @@ struct GemmP {
     int tiles_n, remap, accumulate;
     long k_per_slab, slab_stride;          // split reduction: blockIdx.y = slab, C += slab * slab_stride
     int phase;                             // experiment: delay every other resident workgroup by half a K tile
+    int ablate;                            // experiment: drop parts of the main loop (timing only)
     double* part; int chunks, stat_cols;   // statistics partials [2][stat_cols][chunks]
 };
 
@@ -196,21 +198,60 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     store_tiles(0);
     __syncthreads();
     read_frags(0, 0, fa[0], fb[0]);
-    for (int kt = 0; kt < nk; ++kt) {
+    // One K tile.  MORE: the next tile exists -- its global loads, LDS stores and first fragment reads are part of
+    // the body.  The steady-state body is branch-free, so the whole tile is one scheduling region per side of the
+    // barrier and the sched_group_barrier sequence below spreads the memory instructions between the MFMAs (one
+    // vector-memory load, LDS read or LDS write per couple of MFMAs) instead of leaving them in clumps during which
+    // the matrix pipe idles (r02d ablation: the clumped loads + stores cost 20 % of the kernel).
+    constexpr int NMF = 4 * TM * TN;                                         // MFMAs per fragment set
+    constexpr int NLD = A_IT + B_IT;                                         // global loads = LDS stores per tile
+    constexpr int NRD = (AL == A_MK ? TM : 4 * TM) + (BL == B_NK ? TN : 4 * TN);   // LDS reads per fragment set
+    auto tile_body = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tiles(kbeg + (long)(kt + 1) * BK);
+        if (MORE) load_tiles(kbeg + (long)(kt + 1) * BK);
         read_frags(cur, 1, fa[1], fb[1]);
         mfma_group(fa[0], fb[0]);
         read_frags(cur, 2, fa[0], fb[0]);
         mfma_group(fa[1], fb[1]);
         read_frags(cur, 3, fa[1], fb[1]);
-        if (more) store_tiles(cur ^ 1);
+        if (MORE) store_tiles(cur ^ 1);
         mfma_group(fa[0], fb[0]);
-        __syncthreads();              // tile `cur` is consumed (its last fragments are in registers), tile cur^1 is written
-        if (more) read_frags(cur ^ 1, 0, fa[0], fb[0]);
+        // desired order of the region above
+        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                 // fragment set 1
+        if (MORE) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // one global load ...
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF / NLD > 0 ? NMF / NLD : 1, 0);   // ... per few MFMAs
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);                 // rest of group 0
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {                                      // group 1 with the reads of set 2
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF / NRD > 0 ? NMF / NRD : 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+#pragma unroll
+        for (int i = 0; i < NRD; ++i) {                                      // group 2 with the reads of set 3
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if (MORE) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {                                  // ... and the LDS stores of the next tile
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+        __syncthreads();   // tile `cur` is consumed (its last fragments are in registers), tile cur^1 is written
+        if (MORE) read_frags(cur ^ 1, 0, fa[0], fb[0]);
         mfma_group(fa[1], fb[1]);
-    }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) tile_body(kt, std::true_type{});
+    tile_body(nk - 1, std::false_type{});
     __syncthreads();                  // (the staging below reuses the operand buffers)
 
     // ---- statistics epilogue (rows beyond M hold zeros and add nothing)
@@ -374,6 +415,7 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.accumulate = accumulate;
     p.k_per_slab = K; p.slab_stride = 0;
     p.phase = dc_option(DC_OPT_GEMM_PHASE);
+    p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
     // fast path: no guards at all (every hot shape of the reference models)
     const bool fast = M % t.bm == 0 && N % t.bn == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
@@ -428,6 +470,7 @@ int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R,
     p.accumulate = 0;
     p.k_per_slab = pl.rows_per_slab; p.slab_stride = (long)M * N;
     p.phase = dc_option(DC_OPT_GEMM_PHASE);
+    p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
     const bool fast = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && lda % 4 == 0 &&
                       ldb % 4 == 0 && N % 4 == 0 && al16p(A) && al16p(B) && al16p(partial);
