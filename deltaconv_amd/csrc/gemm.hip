@@ -361,10 +361,14 @@ Tile pick_tile(long M, int N, int K, int tile) {
         case 4: return {64, 128};
         default: break;
     }
-    const int bn = N > 64 ? 128 : 64;
+    // column tile: 128 when it divides N (or N is large and ragged anyway), else 64 when THAT divides N -- a tile that
+    // divides the problem runs the unguarded fast path (e.g. N = 192: 3 x 64 instead of 2 x 128 with guards)
+    int bn = N > 64 ? 128 : 64;
+    if (N % 128 != 0 && N % 64 == 0) bn = 64;
     const long tn = (N + bn - 1) / bn;
-    // enough workgroups for 256 CUs x 2: fall back to 64-row tiles for short problems
-    const int bm = ((M + 127) / 128) * tn >= 384 ? 128 : 64;
+    // row tile: enough workgroups for 256 CUs x 2; 64-row tiles for short problems
+    int bm = ((M + 127) / 128) * tn >= 384 ? 128 : 64;
+    if (M % bm != 0 && M % 64 == 0) bm = 64;
     return {bm, bn};
 }
 

@@ -185,7 +185,7 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
                          float* C, int64_t ldc, int32_t accumulate, void* workspace, size_t workspace_bytes,
                          void* stream) {
     DC_REQUIRE(A && B && C, "dc_gemm_tn: null pointer");
-    DC_REQUIRE(R >= 1 && M >= 32 && N >= 32 && M % 32 == 0 && N % 32 == 0, "dc_gemm_tn: M, N must be multiples of 32");
+    DC_REQUIRE(R >= 1 && M >= 1 && N >= 1, "dc_gemm_tn: bad size");
     DC_REQUIRE(lda >= M && ldb >= N && ldc >= N, "dc_gemm_tn: leading dimension smaller than the row");
     if (!workspace || workspace_bytes < dc_gemm_tn_workspace_bytes(R, M, N)) {
         dc_set_error("dc_gemm_tn: workspace too small");
@@ -193,7 +193,10 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* partial = static_cast<float*>(workspace);
-    if (dc_option(DC_OPT_TN_LDS)) {
+    // direct-load kernel inside its measured window (multiples of 32, 16K..256K outputs); the LDS-staged kernel of
+    // gemm.hip for every other shape (any M, N, leading dimension)
+    const bool direct_ok = M % 32 == 0 && N % 32 == 0 && (long)M * N >= 16384;
+    if (!direct_ok || dc_option(DC_OPT_TN_LDS)) {
         const int slabs = dc_tn_lds_launch(A, (long)lda, B, (long)ldb, (long)R, M, N, partial, s);
         const long mn2 = (long)M * N;
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn2, 64)), dim3(64 * RED_WAVES), 0, s, partial, slabs, mn2, N,

@@ -37,6 +37,8 @@ def embed_and_pool(mlp, x, ptr_info, with_mean):
     if _equal(ptr_info, x.shape[0]) and slope is not None and x.is_cuda and fused.sync_group() is None:
         for blk in blocks[:-1]:
             x = blk(x)
+        if last[0].bias is None:
+            return fused.linear_bn_act_pool(x, last[0], last[1].bn, slope, nc, mx, with_mean)
         h = fused.linear(x, last[0].weight, last[0].bias)
         return fused.bn_act_pool(h, last[1].bn, slope, nc, mx, with_mean)
     x = mlp(x)

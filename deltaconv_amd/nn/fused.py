@@ -301,11 +301,11 @@ def gemm_tn(a, b):
     hand-written fp32-MFMA split-K kernel (csrc/gemm_tn.hip); everything else to the library."""
     r, m = a.shape
     n = b.shape[1]
-    # measured window (profiles/r01i_kernels.log, r01n): the MFMA kernel wins for 16K <= M*N <= 64K outputs
-    # against the TUNED library (e.g. 256x128: 31 vs 62 us) and ties up to 256K (512x256: 91 vs 88 us); against
-    # the library's default heuristic it wins by 5-18x there (448x256: 1.5 ms).  Larger problems (the
-    # 1024x512 embedding) and smaller ones stay with the library.
-    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m % 32 == 0 and n % 32 == 0 and 16384 <= m * n <= 262144
+    # measured (profiles/r01i_kernels.log, r01n, gpurun r02c): the MFMA kernels win or tie against the TUNED library
+    # up to 256K outputs (e.g. 256x128: 31 vs 62 us; 512x256: 91 vs 88 us; 64x64: 11 vs 10 us) and by 5-18x against
+    # its default heuristic (448x256: 1.5 ms).  Only the 1024x512 embedding (library 272 us vs 312 us) and per-cloud
+    # problems (few rows) stay with the library.
+    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m * n <= 262144
             and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
         nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, n)
@@ -315,32 +315,224 @@ def gemm_tn(a, b):
     return a.t() @ b
 
 
+# ---- dense products of the per-point Linear layers: hand-written fp32-MFMA kernels (csrc/gemm.hip) --------------
+USE_OWN_GEMM = True        # A/B switch: False = vendor library (torch.mm) for the forward / input-gradient products
+OWN_GEMM_MIN_ROWS = 1024   # per-cloud rows (classification head: B rows) stay with the library: launch-latency bound
+
+
+OWN_GEMM_MAX_WEIGHT = 262144   # input gradient of wider layers (the 1024 x 512 embedding) stays with the tuned library:
+                               # 240 us vs 276 us (profiles/r02f_step_timeline.txt); its forward product is hand-written
+                               # (statistics epilogue: 274 us vs 238 + 27 + 5 us)
+
+
+def _own_gemm(x):
+    return (USE_OWN_GEMM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= OWN_GEMM_MIN_ROWS
+            and x.stride(1) == 1)
+
+
+def _rowmajor(t):
+    return t if (t.dtype == torch.float32 and t.stride(-1) == 1 and t.stride(0) >= t.shape[1]) else t.contiguous().float()
+
+
+def mm_nt(x, w, out=None):
+    """x [M,K] (row stride = ld) @ w[N,K]^T -> [M,N]: forward product of a Linear layer (nn/mlp.py:9,15)."""
+    x, w = _rowmajor(x), _rowmajor(w)
+    m, k = x.shape
+    n = w.shape[0]
+    if not _own_gemm(x):
+        y = x @ w.t()
+        if out is None:
+            return y
+        out.copy_(y)
+        return out
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    lib.call("dc_linear_forward", x, x.stride(0), w, w.stride(0), m, n, k, out, out.stride(0), 0)
+    return out
+
+
+def mm_nn(dy, w, out=None, accumulate=False):
+    """dy [M,N] @ w[N,K] -> [M,K] (+= when accumulate): input gradient of a Linear layer."""
+    dy, w = _rowmajor(dy), _rowmajor(w)
+    m, n = dy.shape
+    k = w.shape[1]
+    if not _own_gemm(dy) or n * k > OWN_GEMM_MAX_WEIGHT:
+        if out is None:
+            return dy @ w
+        if accumulate:
+            out.addmm_(dy, w)
+        else:
+            torch.mm(dy, w, out=out) if out.is_contiguous() else out.copy_(dy @ w)
+        return out
+    if out is None:
+        assert not accumulate
+        out = torch.empty(m, k, dtype=torch.float32, device=dy.device)
+    lib.call("dc_linear_backward_input", dy, dy.stride(0), w, w.stride(0), m, n, k, out, out.stride(0), int(accumulate), 0)
+    return out
+
+
+def linear_stats(x, w, bn, gamma, beta, vn=False):
+    """h = x w^T together with the BatchNorm coefficients of the layer behind it, from the GEMM epilogue:
+    -> (h, coef[4, C] = mean / invstd / scale / shift, use_batch_stats).  vn: w = the [2co, K] view of a vector
+    block, statistics of the per-point norms of the interleaved (P_c, Q_c) output (C = co).  Running statistics and
+    num_batches_tracked advance exactly as in bn_act / vector_nonlin."""
+    x, w = _rowmajor(x), _rowmajor(w)
+    m, k = x.shape
+    n = w.shape[0]
+    c = n // 2 if vn else n
+    rows = m // 2 if vn else m
+    dev = x.device
+    check_bn_rows(bn, rows)
+    use_batch = bn.training or bn.running_mean is None
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    track = bn.training and bn.track_running_stats
+    if track:
+        bump_counter(bn)
+        if bn.momentum is None:
+            mom = 1.0 / float(bn.num_batches_tracked)
+    rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
+    coef = torch.empty(4, c, dtype=torch.float32, device=dev)
+    h = torch.empty(m, n, dtype=torch.float32, device=dev)
+    if use_batch and _own_gemm(x) and sync_group() is None:
+        nb = lib.raw("dc_linear_stats_workspace_bytes")(m, n, k, 0)
+        ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
+        if vn:
+            lib.call("dc_linear_vn_stats_forward", x, x.stride(0), w, w.stride(0), rows, c, k, h, n, gamma, beta,
+                     float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
+        else:
+            lib.call("dc_linear_bn_stats_forward", x, x.stride(0), w, w.stride(0), m, n, k, h, n, gamma, beta,
+                     float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
+        return h, coef, True
+    mm_nt(x, w, out=h)
+    if use_batch:
+        assert sync_group() is None, "synchronised BatchNorm runs through bn_act / vector_nonlin"
+        ws, nb = _ws(rows, c, dev)
+        if vn:
+            lib.call("dc_vn_stats", h, rows, c, n, 2, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1],
+                     coef[2], coef[3], ws, nb)
+        else:
+            lib.call("dc_bn_stats", h, m, n, n, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2],
+                     coef[3], ws, nb)
+    else:
+        lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, float(bn.eps), c, coef[0], coef[1], coef[2], coef[3])
+    return h, coef, use_batch
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T (+ b) on 2-D row-major x; the weight gradient dW = dY^T X goes through `gemm_tn` (own fp32
-    MFMA kernel inside its window), dX and the forward product through the library."""
+    """y = x W^T (+ b) on 2-D row-major x: forward and input gradient through csrc/gemm.hip, the weight gradient
+    dW = dY^T X through `gemm_tn` (own fp32-MFMA kernels; small / per-cloud problems stay with the library)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return F.linear(x, w, b)
+        if not _own_gemm(x):
+            return F.linear(x, w, b)
+        y = mm_nt(x, w)
+        if b is not None:
+            y += b
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         if dy.stride(1) != 1:
             dy = dy.contiguous()
-        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dx = mm_nn(dy, w) if ctx.needs_input_grad[0] else None
         dw = gemm_tn(dy, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
         db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 
 def linear(x, w, b=None):
-    """F.linear with the tall-skinny weight-gradient GEMM routed to csrc/gemm_tn.hip (2-D fp32 GPU inputs)."""
+    """F.linear on the hand-written GEMM kernels (2-D fp32 GPU inputs; otherwise torch)."""
     if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
         return _Linear.apply(x, w, b)
     return F.linear(x, w, b)
+
+
+class _LinearBNAct(torch.autograd.Function):
+    """One MLP block of nn/mlp.py:7-11 as a single node: y = leaky(batch_norm(x W^T)) (+ residual).  The batch
+    statistics come out of the GEMM epilogue (no pass over the Linear output), the backward is
+    BatchNorm/activation backward -> dW (gemm_tn) -> dX (gemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn, slope, residual):
+        h, coef, use_batch = linear_stats(x, w, bn, gamma, beta)
+        r, c = h.shape
+        y = torch.empty_like(h)
+        res = _c(residual)
+        lib.call("dc_bn_act", h, r, c, c, coef[2], coef[3], slope, res, c, y, c)
+        ctx.save_for_backward(x, w, h, coef, gamma)
+        ctx.cfg = (use_batch, slope, gamma is not None, beta is not None, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, h, coef, gamma = ctx.saved_tensors
+        training, slope, has_g, has_b, has_res = ctx.cfg
+        dy = _c(dy)
+        r, c = h.shape
+        dev = h.device
+        dh = torch.empty_like(h)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev) if has_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev) if has_b else None
+        ws, nb = _ws(r, c, dev)
+        lib.call("dc_bn_act_backward", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
+                 int(training), dh, c, dgamma, dbeta, ws, nb)
+        dw = gemm_tn(dh, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
+        dx = mm_nn(dh, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, dgamma, dbeta, None, None, (dy if has_res else None)
+
+
+def linear_bn_act(x, lin, bn, slope, residual=None):
+    """[Linear(no bias) -> BatchNorm1d -> leaky(slope)](x) (+ residual); lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d."""
+    if (lin.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and sync_group() is None):
+        return _LinearBNAct.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope), residual)
+    return bn_act(linear(x, lin.weight, lin.bias), bn, slope, residual)
+
+
+class _LinearBNActPool(torch.autograd.Function):
+    """pooled[B, (2)C] = [max | mean] over each cloud of leaky(batch_norm(x W^T)): the embedding MLP in front of the
+    global pooling (models/deltanet_classification.py:42-49, deltanet_segmentation.py:58-61).  Statistics from the
+    GEMM epilogue; the [B*N, C] activation is never materialised, in either direction (csrc/nn.hip: pool_fwd_kernel,
+    PoolBwdF, PoolBwdBody)."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn, slope, num_clouds, n_per, with_mean):
+        h, coef, use_batch = linear_stats(x, w, bn, gamma, beta)
+        r, c = h.shape
+        dev = h.device
+        width = 2 * c if with_mean else c
+        pooled = torch.empty(num_clouds, width, dtype=torch.float32, device=dev)
+        arg = torch.empty(num_clouds, c, dtype=torch.int32, device=dev)
+        lib.call("dc_bn_act_pool", h, c, num_clouds, n_per, c, coef[2], coef[3], slope, int(with_mean), pooled, width,
+                 arg)
+        ctx.save_for_backward(x, w, h, coef, gamma, arg)
+        ctx.cfg = (use_batch, slope, num_clouds, n_per, with_mean, gamma is not None, beta is not None)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, w, h, coef, gamma, arg = ctx.saved_tensors
+        training, slope, num_clouds, n_per, with_mean, has_g, has_b = ctx.cfg
+        dpooled = _c(dpooled)
+        r, c = h.shape
+        dev = h.device
+        dh = torch.empty_like(h)
+        dgamma = torch.empty(c, dtype=torch.float32, device=dev) if has_g else None
+        dbeta = torch.empty(c, dtype=torch.float32, device=dev) if has_b else None
+        ws, nb = _ws(r, c, dev)
+        lib.call("dc_bn_act_pool_backward", dpooled, dpooled.shape[1], arg, h, c, num_clouds, n_per, c, coef[2], coef[3],
+                 coef[0], coef[1], gamma, slope, int(with_mean), int(training), dh, c, dgamma, dbeta, ws, nb)
+        dw = gemm_tn(dh, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
+        dx = mm_nn(dh, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None
+
+
+def linear_bn_act_pool(x, lin, bn, slope, num_clouds, n_per, with_mean):
+    require_gpu()
+    return _LinearBNActPool.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope), num_clouds, n_per, with_mean)
 
 
 class _BNActPool(torch.autograd.Function):

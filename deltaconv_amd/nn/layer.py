@@ -17,9 +17,10 @@ owns its buffers:
 * the I_J fold of the first VectorMLP layer uses the reference's [co, 2K] weight as a [2co, K] view (GEMM
   output = interleaved (P_c, Q_c) columns), so neither the weight nor its gradient is re-stacked.
 
-Dense GEMMs are library calls (tuned, see deltaconv_amd/tuning).  Used when every MLP of the layer
-has depth 1 and standard activations (all reference models except the depth-2 segmentation net,
-which takes the composed path).
+Dense GEMMs: hand-written fp32-MFMA kernels (csrc/gemm.hip forward + input gradient, the forward ones with the
+BatchNorm statistics of the block in their epilogue; csrc/gemm_tn.hip weight gradient).  Used when every MLP of the
+layer has depth 1 and standard activations (all reference models except the depth-2 segmentation net, which takes
+the composed path).
 """
 import torch
 
@@ -121,7 +122,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
         # ---- scalar stream, max aggregation over the k neighbours (deltaconv.py:50-54)
         x_max = torch.empty(n, co, **f32)
         if cfg.centralized:
-            y0 = x @ Wm.t()
+            y0 = fused.mm_nt(x, Wm)
             stat = torch.empty(3, n, co, **f32)
             args = torch.empty(2, n, co, dtype=torch.uint8, device=dev)
             use_m, mom, rm, rv = _bn_mode(cfg.bn_m)
@@ -137,8 +138,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
                  x_max, co, None)
             max_saved = (y0, stat, args)
         else:
-            hm = x @ Wm.t()
-            coef_m, use_m = _bn_coeffs(hm, n, co, co, cfg.bn_m, gm, bm, dev)
+            hm, coef_m, use_m = fused.linear_stats(x, Wm, cfg.bn_m, gm, bm)      # GEMM + statistics epilogue
             arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
             call("dc_knn_max_affine", g.nbr, n, k, hm, co, co, coef_m[2], coef_m[3], cfg.slope_m, x_max, co, arg)
             max_saved = (hm, arg)
@@ -149,8 +149,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
             x_cat = torch.empty(n, 4 * ci, **f32)
             x_cat[:, :ci].copy_(x)
         call("dc_apply_div_curl_norm", D, g.nbr, n, k, v, ci, ldv, x_cat[:, ci:], 4 * ci)
-        hs = x_cat @ Ws.t()
-        coef_s, use_s = _bn_coeffs(hs, n, co, co, cfg.bn_s, gs, bs, dev)
+        hs, coef_s, use_s = fused.linear_stats(x_cat, Ws, cfg.bn_s, gs, bs)
         if cfg.chain is not None:
             xbuf = torch.empty(n, cfg.chain[0], **f32)
             x_new = xbuf[:, :co]
@@ -174,8 +173,8 @@ class DeltaConvLayerFn(torch.autograd.Function):
             call("dc_apply_hodge", G, g.nbr, n, k, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
             call("dc_apply_grad", G, g.nbr, n, k, x_new, co, ldxn, v_cat[:, 2 * ci:], K)
             Wst = Wv.view(2 * co, K)                                 # rows (c, half): the I_J fold, a free view
-            PQ = v_cat @ Wst.t()                                      # [2n, 2co], columns interleaved (P_c, Q_c)
-            coef_v, use_v = _bn_coeffs(PQ, n, co, 2 * co, cfg.bn_v, gv, bv, dev, vn_combine=2)
+            # [2n, 2co], columns interleaved (P_c, Q_c); statistics of the per-point norms from the GEMM epilogue
+            PQ, coef_v, use_v = fused.linear_stats(v_cat, Wst, cfg.bn_v, gv, bv, vn=True)
             if cfg.chain is not None and cfg.chain[1] is not None:
                 vbuf = torch.empty(2 * n, cfg.chain[1], **f32)
                 v_new = vbuf[:, :co]
@@ -225,7 +224,11 @@ class DeltaConvLayerFn(torch.autograd.Function):
             call("dc_vn_backward", dvn, lddvn, PQ, 2 * co, 2, n, co, coef_v[2], coef_v[3], coef_v[0], coef_v[1], gv,
                  int(use_v), dPQ, 2 * co, dgv, dbv, ws, nb)
             dWv = fused.gemm_tn(dPQ, v_cat).view(co, 2 * K)           # [2co, K] rows (c, half) = the [co, 2K] layout
-            dv_cat = dPQ @ Wst                                        # [2n, K]
+            if need_v or ctx.needs_input_grad[0]:
+                dv_cat = fused.mm_nn(dPQ, Wst)                        # [2n, K]
+            else:   # first layer (x, v carry no gradient): only the `grad @ x'` block of d v_cat is consumed
+                dv_cat = torch.empty(2 * n, K, **f32)
+                fused.mm_nn(dPQ, Wst[:, 2 * ci:].contiguous(), out=dv_cat[:, 2 * ci:])
             # grad^T of the `grad @ x'` block accumulates into d x'
             if not private:                    # accumulated into below: never touch autograd's buffer
                 dxn, lddx = (dxn.clone() if dxn.is_contiguous() else dxn.contiguous()), co
@@ -238,8 +241,10 @@ class DeltaConvLayerFn(torch.autograd.Function):
         call("dc_bn_act_backward", dxn, lddx, hs, co, n, co, coef_s[2], coef_s[3], coef_s[0], coef_s[1], gs, cfg.slope_s,
              int(use_s), dhs, co, dgs, dbs, ws, nb)
         dWs = fused.gemm_tn(dhs, x_cat)
-        d_xcat = dhs @ Ws                                             # [n, 4ci] = d[x | div | curl | norm]
-        if dv_cat is not None:   # hodge^T accumulates into d[div | curl]
+        d_xcat = None
+        if need_x or need_v:
+            d_xcat = fused.mm_nn(dhs, Ws)                             # [n, 4ci] = d[x | div | curl | norm]
+        if dv_cat is not None and d_xcat is not None:   # hodge^T accumulates into d[div | curl]
             call("dc_apply_hodge_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, ci:], ci, 2 * ci + co,
                  d_xcat[:, ci:], 4 * ci, 1)
         dv = None
@@ -274,7 +279,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
         dx = None
         if need_x:                            # d x = d_xcat[:, :ci] + dpre Wm, accumulated in place (GEMM with ldc = 4 ci)
             dx = d_xcat[:, :ci]
-            dx.addmm_(dpre, Wm)
+            fused.mm_nn(dpre, Wm, out=dx, accumulate=True)
         nz = lambda t, ref: t if ref is not None else None
         return (dx, dv, dWm, nz(dgm, gm), nz(dbm, gm), dWs, nz(dgs, gs), nz(dbs, gs), dWv, nz(dgv, gv), nz(dbv, gv),
                 None)

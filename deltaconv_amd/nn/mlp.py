@@ -25,11 +25,10 @@ class MLPBlock(Seq):
     def forward(self, x, residual=None):
         lin, bn, act = self[0], self[1], self[2]
         slope = fused.slope_of(act)
-        h = fused.linear(x, lin.weight, lin.bias)
         if slope is None:                       # exotic activation: BN fused, activation through torch
-            out = act(fused.bn_act(h, bn.bn, 1.0))
+            out = act(fused.linear_bn_act(x, lin, bn.bn, 1.0))
             return out if residual is None else out + residual
-        return fused.bn_act(h, bn.bn, slope, residual)
+        return fused.linear_bn_act(x, lin, bn.bn, slope, residual)
 
 
 class VectorBlock(Seq):

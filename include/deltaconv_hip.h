@@ -180,8 +180,9 @@ int dc_edge_max_backward(const float* dout, int64_t lddo, const float* y, int64_
 
 /* ---- weight-gradient GEMM on the fp32 matrix cores ---------------------------------------------------
  * C[M,N] (+)= A^T B,  A [R,M], B [R,N], R >> M,N  (dW = dY^T X of every per-point Linear layer: ATen mm in the
- * autograd of deltaconv/nn/mlp.py:9,15).  v_mfma_f32_32x32x2_f32, split over row slabs, ordered reduction.
- * M, N multiples of 32.  Workspace: dc_gemm_tn_workspace_bytes. */
+ * autograd of deltaconv/nn/mlp.py:9,15).  v_mfma_f32_32x32x2_f32, split over row slabs, ordered reduction (two
+ * kernels: direct global->register operand loads for multiples of 32 with 16K..256K outputs, LDS-staged for any
+ * other M, N).  Workspace: dc_gemm_tn_workspace_bytes. */
 size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N);
 int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N, float* C,
                int64_t ldc, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);

@@ -36,7 +36,7 @@ def make(seed=5):
 def main():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-    batches = [synthetic_batch(4, 256, seed=60 + i).cuda() for i in range(3)]
+    batches = [synthetic_batch(4, 256, seed=60 + i).to("cuda") for i in range(3)]
     res = {}
 
     # ---- 1. graph replay + reduce_gradients + optimizer vs eager
@@ -49,7 +49,7 @@ def main():
         o1.step()
     m2, o2 = make()
     d2 = dp.FlatGradDataParallel(m2, always_reduce=True)
-    static = synthetic_batch(4, 256, seed=60).cuda()
+    static = synthetic_batch(4, 256, seed=60).to("cuda")
     for _ in range(2):
         d2.zero_grad()
         calc_loss(d2(static), static.y).backward()

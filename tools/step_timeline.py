@@ -1,6 +1,6 @@
 """Ordered kernel timeline of ONE training step from a rocprofv3 --kernel-trace CSV.
 
-    python tools/step_timeline.py <dir-with-*kernel_trace.csv> [marker-substring=knn_]
+    python tools/step_timeline.py <dir-with-*kernel_trace.csv> [marker-substring=knn_wave_kernel]
 
 The step is delimited by consecutive occurrences of the marker kernel (the kNN launch that opens every
 step); prints each launch with its duration and the idle gap before it, then totals (busy, gaps)."""
@@ -8,7 +8,7 @@ import csv, glob, os, sys
 
 def main():
     d = sys.argv[1]
-    marker = sys.argv[2] if len(sys.argv) > 2 else "knn_"
+    marker = sys.argv[2] if len(sys.argv) > 2 else "knn_wave_kernel"
     files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     assert files, "no kernel_trace.csv under " + d
     rows = []
