@@ -86,72 +86,127 @@ def apply_roofline(graph, grad, div, C, iters=200):
         t = e0.elapsed_time(e1) / iters * 1e-3
         fam[name] = dict(us=round(t * 1e6, 2), bytes=nbytes, GBs=round(nbytes / t / 1e9, 1),
                          frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4))
-    # the hand-written fp32-MFMA weight-gradient GEMM (csrc/gemm_tn.hip) at the layer-2 v_mlp shape
+    # the hand-written fp32-MFMA GEMMs (csrc/gemm.hip, gemm_tn.hip): forward product of the embedding MLP with the
+    # BatchNorm-statistics epilogue (the largest GEMM of the step) and the layer-2 v_mlp weight gradient
+    def _time(fn, it=30):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / it * 1e-3
+    Me, Ne, Ke = n, 1024, 512
+    Xe, We = torch.randn(Me, Ke, device=dev), torch.randn(Ne, Ke, device=dev)
+    Ye, coef = torch.empty(Me, Ne, device=dev), torch.empty(4, Ne, device=dev)
+    ge = torch.ones(Ne, device=dev)
+    nbe = lib.raw("dc_linear_stats_workspace_bytes")(Me, Ne, Ke, 0)
+    wse = torch.empty((nbe + 7) // 8, dtype=torch.float64, device=dev)
+    te = _time(lambda: lib.call("dc_linear_bn_stats_forward", Xe, Ke, We, Ke, Me, Ne, Ke, Ye, Ne, ge, ge, 1e-5, 0.1, None,
+                                None, coef[0], coef[1], coef[2], coef[3], 0, wse, nbe))
     R, M, N = 2 * n, 256, 256
     A, Bm = torch.randn(R, M, device=dev), torch.randn(R, N, device=dev)
     Cout = torch.empty(M, N, device=dev)
     nb = lib.raw("dc_gemm_tn_workspace_bytes")(R, M, N)
     ws = torch.empty((nb + 3) // 4, device=dev)
-    fn = lambda: lib.call("dc_gemm_tn", A, M, Bm, N, R, M, N, Cout, N, 0, ws, ws.numel() * 4)
-    for _ in range(5):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(50):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    tg = e0.elapsed_time(e1) / 50 * 1e-3
-    mfma = dict(kernel=f"gemm_tn_kernel<2,2> + reduce (dW = dY^T X, {R}x{M}x{N}, fp32 v_mfma_f32_32x32x2)",
-                us=round(tg * 1e6, 1), achieved=round(2.0 * R * M * N / tg / 1e12, 1), peak=157.3, unit="TFLOP/s",
-                frac=round(2.0 * R * M * N / tg / 1e12 / 157.3, 3))
+    tg = _time(lambda: lib.call("dc_gemm_tn", A, M, Bm, N, R, M, N, Cout, N, 0, ws, ws.numel() * 4))
+    mfma = dict(kernel=f"gemm_kernel<128,128> + statistics epilogue + finaliser (Y = X W^T, {Me}x{Ne}x{Ke}, fp32 "
+                       "v_mfma_f32_32x32x2, LDS-staged)",
+                us=round(te * 1e6, 1), achieved=round(2.0 * Me * Ne * Ke / te / 1e12, 1), peak=157.3, unit="TFLOP/s",
+                frac=round(2.0 * Me * Ne * Ke / te / 1e12 / 157.3, 3),
+                weight_gradient=dict(kernel=f"gemm_tn_kernel<2,2> + reduce (dW = dY^T X, {R}x{M}x{N})",
+                                     us=round(tg * 1e6, 1), achieved=round(2.0 * R * M * N / tg / 1e12, 1),
+                                     frac=round(2.0 * R * M * N / tg / 1e12 / 157.3, 3)))
     head = fam["div_curl_norm"]
-    traffic = None      # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc)
+    # HBM bytes per launch from the PMC passes: counters cannot be read from inside the process, they come from separate
+    # `rocprofv3 --pmc` runs of tools/pmc_apply.sh on the binary named by `traffic_tag` (profiles/README.md)
+    traffic = traffic_tag = None
     try:
         import json as _json
         pmc = _json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_divcurlnorm.json")))
         if C == 64 and n == 32768 and k == 20:
-            traffic = pmc["traffic_bytes"]
+            traffic, traffic_tag = pmc["traffic_bytes"], pmc.get("tag")
     except Exception:
         pass
+    # Second bound, the one that actually limits the kernel: every neighbour row is gathered
+    # through the vector-memory (texture addresser / L1) path, 64 B/clk/CU.  Gathered bytes = 2 rows x 4C bytes per edge.
+    gathered = 2 * 4 * C * E
+    l1_peak = 64.0 * 256 * 2.4e9 / 1e9                      # GB/s: 64 B/clk/CU x 256 CUs x 2.4 GHz
+    l1 = dict(gathered_bytes=gathered, achieved=round(gathered / (head["us"] * 1e-6) / 1e9, 1), peak=round(l1_peak, 1),
+              unit="GB/s", frac=round(gathered / (head["us"] * 1e-6) / 1e9 / l1_peak, 4))
     return dict(bound="hbm", achieved=head["GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=head["frac"],
-                traffic=traffic, kernel="divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)", channels=C,
+                traffic=traffic, traffic_tag=traffic_tag,
+                cache_level="Infinity-Cache resident (working set ~50 MB per launch < 256 MB L3): `achieved` is "
+                            "algorithmic bytes / time against the HBM peak, the data mostly streams from L3 / fabric",
+                l1_gather=l1,
+                kernel="divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)", channels=C,
                 bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam, mfma=mfma)
 
 
+def _physical_cores():
+    """(physical cores, hardware threads) of this host from /proc/cpuinfo."""
+    hw = os.cpu_count() or 1
+    try:
+        cores, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        return (len(cores) or hw), hw
+    except OSError:
+        return hw, hw
+
+
 def cpu_baseline(args):
-    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload.
-    torch's intra-op pool is tried at a few sizes (all hardware threads is pathological for the
-    many small ops of this path); the best is reported together with the thread count used."""
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload, protocol of
+    SURVEY.md section 8(d): 3 warm-up + 10 timed steps, median; plus a 1-thread number.  torch's intra-op pool at all
+    hardware threads is pathological for the many small ops of this path, so the pool size is chosen first by a short
+    trial (1 warm-up + 1 timed step at 8 / 32 / 64 threads) and reported."""
+    import statistics
     import oracle
     from deltaconv_amd.data import synthetic_batch
-    hw = os.cpu_count() or 1
+    phys, hw = _physical_cores()
     b = synthetic_batch(args.cpu_clouds, args.points, seed=2)
     torch.manual_seed(1)
     model = oracle.models.DeltaNetClassification(3, 40, num_neighbors=args.k).train()
 
-    def one():
+    def one(batch=b):
         t0 = time.perf_counter()
         model.zero_grad()
-        oracle.loss.calc_loss(model(b), b.y).backward()
+        oracle.loss.calc_loss(model(batch), batch.y).backward()
         return time.perf_counter() - t0
 
-    best, trials, spent = None, {}, 0.0
-    for threads in sorted({min(hw, t) for t in (32, 8, 64)}, reverse=True):
+    trials = {}
+    for threads in sorted({min(hw, t) for t in (8, 32, 64)}):
         torch.set_num_threads(threads)
-        one()                                            # warm-up at this pool size
-        t = min(one(), one())
-        trials[threads] = round(args.cpu_clouds / t, 3)
-        spent += 3 * t
-        if best is None or t < best[1]:
-            best = (threads, t)
-        if spent > 40:
-            break
-    return dict(value=args.cpu_clouds / best[1], unit="clouds/s", cores=best[0], kind="port",
+        one()
+        trials[threads] = round(args.cpu_clouds / one(), 3)
+    best = max(trials, key=trials.get)
+    torch.set_num_threads(best)
+    for _ in range(3):
+        one()
+    times = [one() for _ in range(10)]
+    med = statistics.median(times)
+    small = synthetic_batch(2, args.points, seed=3)
+    torch.set_num_threads(1)
+    one(small)
+    t1 = statistics.median([one(small) for _ in range(3)])
+    torch.set_num_threads(best)
+    return dict(value=args.cpu_clouds / med, unit="clouds/s", cores=best, kind="port",
+                physical_cores=phys, hardware_threads=hw, one_thread_value=round(2 / t1, 3),
                 sample=f"oracle/ (torch-CPU restatement of the reference path), {args.cpu_clouds} clouds x "
-                       f"{args.points} pts, k={args.k}, fwd+bwd train mode, best of 2 after 1 warm-up per pool size; "
-                       f"clouds/s by torch threads: {trials}; host has {hw} hardware threads")
+                       f"{args.points} pts, k={args.k}, fwd+bwd train mode, 3 warm-up + 10 timed steps, median "
+                       f"(min {args.cpu_clouds / max(times):.2f} / max {args.cpu_clouds / min(times):.2f} clouds/s) at "
+                       f"{best} torch threads (trial clouds/s by threads: {trials}); 1 thread: 2 clouds, median of 3; "
+                       f"host: {phys} physical cores / {hw} hardware threads")
 
 
 def main():

@@ -50,7 +50,7 @@ constexpr int BK = 32;         // reduction tile
 constexpr int LDK = BK + 4;    // row stride (floats) of a k-contiguous operand tile in LDS
 constexpr int NT = 256;        // threads per workgroup (4 waves, 2 x 2)
 
-enum { EPI_NONE = 0, EPI_COLSTATS = 1, EPI_VNSTATS = 2 };
+enum { EPI_NONE = 0, EPI_COLSTATS = 1, EPI_VNSTATS = 2 /* interleaved (P_c, Q_c) columns */, EPI_VNSTATS0 = 3 /* plain [2n, co] */ };
 enum { B_NK = 0 /* W[N,K]: forward */, B_KN = 1 /* reduction-major: input gradient, weight gradient */ };
 enum { A_MK = 0 /* X[M,K]: reduction index contiguous */, A_KM = 1 /* dY[R,M]: reduction-major (weight gradient) */ };
 
@@ -270,6 +270,13 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
                         s0 += x;
                         s1 += x * x;
                     }
+                } else if (EPI == EPI_VNSTATS0) {   // rows (2r, 2r+1) = (u, v) components = registers (q, q+1), q even
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const double nr = (double)dcnn::vn_norm(acc[i][jn][q], acc[i][jn][q + 1]);
+                        s0 += nr;
+                        s1 += nr * nr;
+                    }
                 } else {   // rows (2r, 2r+1) = registers (q, q+1), q even; columns (2c, 2c+1) = (P_c, Q_c) = lanes (l, l+1)
 #pragma unroll
                     for (int q = 0; q < 16; q += 2) {
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
             s0 += __shfl_xor(s0, 32, 64);
             s1 += __shfl_xor(s1, 32, 64);
             if (lh == 0) {
-                if (EPI == EPI_COLSTATS) {
+                if (EPI == EPI_COLSTATS || EPI == EPI_VNSTATS0) {
                     const int c = wn0 + jn * 32 + li;
                     sst[(0 * 2 + (wave >> 1)) * SC + c] = s0;
                     sst[(1 * 2 + (wave >> 1)) * SC + c] = s1;
@@ -427,6 +434,7 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     if (bl == B_NK) {
         if (epi == EPI_COLSTATS) launch_fast<A_MK, B_NK, EPI_COLSTATS>(p, t, tiles_m, 1, fast, s);
         else if (epi == EPI_VNSTATS) launch_fast<A_MK, B_NK, EPI_VNSTATS>(p, t, tiles_m, 1, fast, s);
+        else if (epi == EPI_VNSTATS0) launch_fast<A_MK, B_NK, EPI_VNSTATS0>(p, t, tiles_m, 1, fast, s);
         else launch_fast<A_MK, B_NK, EPI_NONE>(p, t, tiles_m, 1, fast, s);
     } else {
         launch_fast<A_MK, B_KN, EPI_NONE>(p, t, tiles_m, 1, fast, s);
@@ -534,26 +542,28 @@ DC_EXPORT int dc_linear_bn_stats_forward(const float* X, int64_t ldx, const floa
     return DC_OK;
 }
 
-// Linear + VectorNonLin statistics: PQ[2n, 2co] = V[2n, K] Wst[2co, K]^T with interleaved (P_c, Q_c) columns, and the
-// batch statistics of |y| over the n points, (y_u, y_v) = (P_u - Q_v, P_v + Q_u)  (nn/nonlin.py:63-79; what
-// dc_vn_stats with combine = 2 computes from PQ).
+// Linear + VectorNonLin statistics (nn/nonlin.py:63-79).  interleaved != 0: PQ[2n, 2co] = V[2n, K] Wst[2co, K]^T with
+// interleaved (P_c, Q_c) columns, statistics of |y| over the n points, (y_u, y_v) = (P_u - Q_v, P_v + Q_u) -- what
+// dc_vn_stats(combine = 2) computes from PQ (first block of a VectorMLP, the I_J fold).  interleaved == 0:
+// Y[2n, co] = V[2n, K] W[co, K]^T, statistics of |(Y_2i, Y_2i+1)| -- dc_vn_stats(combine = 0) (deeper blocks).
 DC_EXPORT int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const float* Wst, int64_t ldw, int64_t n,
-                                         int32_t co, int32_t K, float* PQ, int64_t ldpq, const float* gamma,
-                                         const float* beta, float eps, float momentum, float* running_mean,
-                                         float* running_var, float* mean, float* invstd, float* scale, float* shift,
-                                         int32_t tile, void* workspace, size_t workspace_bytes, void* stream) {
+                                         int32_t co, int32_t K, float* PQ, int64_t ldpq, int32_t interleaved,
+                                         const float* gamma, const float* beta, float eps, float momentum,
+                                         float* running_mean, float* running_var, float* mean, float* invstd,
+                                         float* scale, float* shift, int32_t tile, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
     DC_REQUIRE(V && Wst && PQ && mean && invstd && scale && shift, "dc_linear_vn_stats_forward: null pointer");
-    DC_REQUIRE(n >= 1 && co >= 1 && K >= 1 && ldv >= K && ldw >= K && ldpq >= 2 * co, "dc_linear_vn_stats_forward: bad size");
     const long M = 2 * n;
-    const int N = 2 * co;
+    const int N = interleaved ? 2 * co : co;
+    DC_REQUIRE(n >= 1 && co >= 1 && K >= 1 && ldv >= K && ldw >= K && ldpq >= N, "dc_linear_vn_stats_forward: bad size");
     if (!workspace || workspace_bytes < dc_linear_stats_workspace_bytes(M, N, K, tile)) {
         dc_set_error("dc_linear_vn_stats_forward: workspace too small");
         return DC_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* part = static_cast<double*>(workspace);
-    if (int rc = run_gemm("dc_linear_vn_stats_forward", B_NK, EPI_VNSTATS, V, ldv, Wst, ldw, M, N, K, PQ, ldpq, 0, tile,
-                          part, co, s))
+    if (int rc = run_gemm("dc_linear_vn_stats_forward", B_NK, interleaved ? EPI_VNSTATS : EPI_VNSTATS0, V, ldv, Wst, ldw, M,
+                          N, K, PQ, ldpq, 0, tile, part, co, s))
         return rc;
     const dccol::BnFin fin{(long)n, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
     hipLaunchKernelGGL((dccol::colreduce_final_kernel<dccol::BnFin>), dim3(co), dim3(64), 0, s, part,

@@ -195,7 +195,7 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     float* partial = static_cast<float*>(workspace);
     // direct-load kernel inside its measured window (multiples of 32, 16K..256K outputs); the LDS-staged kernel of
     // gemm.hip for every other shape (any M, N, leading dimension)
-    const bool direct_ok = M % 32 == 0 && N % 32 == 0 && (long)M * N >= 16384;
+    const bool direct_ok = M % 32 == 0 && N % 32 == 0 && (long)M * N >= 16384 && (long)M * N <= 262144;
     if (!direct_ok || dc_option(DC_OPT_TN_LDS)) {
         const int slabs = dc_tn_lds_launch(A, (long)lda, B, (long)ldb, (long)R, M, N, partial, s);
         const long mn2 = (long)M * N;

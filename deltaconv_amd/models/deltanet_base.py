@@ -2,7 +2,6 @@
 import torch
 
 from ..nn import DeltaConv
-from ..nn.layer import offer_cat
 from ..geometry.graph import Graph
 from ..geometry.grad_div_mls import build_grad_div, build_tangent_basis, estimate_basis
 
@@ -94,13 +93,10 @@ class DeltaNetBase(torch.nn.Module):
         if fusable and x.is_cuda:
             xall = torch.empty(x.shape[0], sum(widths), dtype=torch.float32, device=x.device)
             blocks = [(xall, sum(widths[:i])) for i in range(len(widths))]
-            offer_cat(xall, widths)
         for i, conv in enumerate(self.convs):
             nxt = self.convs[i + 1] if i + 1 < len(self.convs) else None
             if blocks is not None:
-                xo, v = conv(x, v, grad, div, graph, next_layer=nxt, out_block=blocks[i])
-                x = conv._chained_x
-                conv._chained_x = None
+                xo, v, x = conv(x, v, grad, div, graph, next_layer=nxt, out_block=blocks[i])
                 out.append(xo)
             else:
                 x, v = conv(x, v, grad, div, graph, next_layer=nxt)

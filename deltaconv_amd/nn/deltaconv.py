@@ -28,54 +28,73 @@ class DeltaConv(torch.nn.Module):
         self.v_mlp = VectorMLP([in_channels * 4 + out_channels * 2] + [out_channels] * depth) if vector else None
 
     fuse_layer = True   # one autograd node per layer (nn/layer.py) when the layer qualifies
-    _chained_x = None
 
     def _fusable(self):
-        """depth-1 MLPs with BatchNorm, piecewise-linear activations, ReLU vector non-linearity, no bias."""
-        mlps = [self.s_mlp_max, self.s_mlp] + ([self.v_mlp] if self.v_mlp is not None else [])
-        if any(len(m) != 1 for m in mlps):
-            return None
-        bm, bs = self.s_mlp_max[0], self.s_mlp[0]
-        if not (isinstance(bm, MLPBlock) and isinstance(bs, MLPBlock)) or bm[0].bias is not None or bs[0].bias is not None:
-            return None
-        sm, ss = fused.slope_of(bm[2]), fused.slope_of(bs[2])
-        if sm is None or ss is None or (self.centralized and sm < 0):
+        """MLPs of [Linear(no bias) -> BatchNorm -> piecewise-linear activation] blocks and a ReLU vector
+        non-linearity with BatchNorm: -> (slopes of the s_mlp_max blocks, slopes of the s_mlp blocks) or None."""
+        out = []
+        for mlp in (self.s_mlp_max, self.s_mlp):
+            slopes = []
+            for blk in mlp:
+                if not isinstance(blk, MLPBlock) or blk[0].bias is not None:
+                    return None
+                sl = fused.slope_of(blk[2])
+                if sl is None:
+                    return None
+                slopes.append(sl)
+            if not slopes:
+                return None
+            out.append(slopes)
+        if self.centralized and len(out[0]) == 1 and out[0][0] < 0:
             return None
         if self.v_mlp is not None:
-            bv = self.v_mlp[0]
-            if not isinstance(bv, VectorBlock) or bv[1].batchnorm is None or not isinstance(bv[1].nonlin, torch.nn.ReLU):
+            if len(self.v_mlp) != len(self.s_mlp):
                 return None
-        return sm, ss
+            for blk in self.v_mlp:
+                if (not isinstance(blk, VectorBlock) or blk[1].batchnorm is None
+                        or not isinstance(blk[1].nonlin, torch.nn.ReLU)):
+                    return None
+        return out[0], out[1]
 
     def forward(self, x, v, grad, div, edge_index, next_layer=None, out_block=None):
         """next_layer (optional, beyond the reference signature): the DeltaConv that consumes this layer's
         outputs next; x' and v' are then produced directly inside its operand buffers (no copies).
         out_block (optional): (buffer [n, W], column offset) of a concatenation buffer; when the layer runs as
-        one fused node x' is ALSO written into that column block, which is returned as x."""
+        one fused node x' is ALSO written into that column block; the call then returns THREE values
+        (x' as that column block, v', x' as the view inside the next layer's operand buffer)."""
         graph = as_graph(edge_index, grad.graph)
         # synchronised BatchNorm (dp.py) runs through the composed blocks: their statistics kernels have the split form
-        slopes = self._fusable() if (self.fuse_layer and fused.sync_group() is None) else None
+        slopes = self._fusable() if (self.fuse_layer and fused.sync_group() is None and x.is_cuda) else None
         if slopes is None:
             return self.forward_composed(x, v, grad, div, graph)
-        bm, bs = self.s_mlp_max[0], self.s_mlp[0]
-        bv = self.v_mlp[0] if self.v_mlp is not None else None
+        slopes_m, slopes_s = slopes
         chain = None
         if (isinstance(next_layer, DeltaConv) and next_layer.fuse_layer and next_layer.in_channels == self.out_channels
                 and next_layer._fusable() is not None and self.out_channels % 4 == 0):
             co = self.out_channels
             chain = (4 * co, 2 * co + next_layer.out_channels
-                     if (bv is not None and next_layer.v_mlp is not None and next_layer.out_channels % 4 == 0) else None)
-        cfg = LayerCfg(graph, grad, div, bm[1].bn, bs[1].bn, bv[1].batchnorm.bn if bv is not None else None,
-                       self.centralized, slopes[0], slopes[1], bv is not None, chain, out_block)
-        vb = bv[1].batchnorm.bn if bv is not None else None
-        x_new, v_new, x_dup = DeltaConvLayerFn.apply(
-            x, v, bm[0].weight, bm[1].bn.weight, bm[1].bn.bias, bs[0].weight, bs[1].bn.weight, bs[1].bn.bias,
-            bv[0].weight if bv is not None else None, vb.weight if vb is not None else None,
-            vb.bias if vb is not None else None, cfg)
-        if out_block is not None:
-            self._chained_x = x_new          # what the next layer consumes (lives in its operand buffer)
-            return x_dup, (v_new if bv is not None else v)
-        return x_new, (v_new if bv is not None else v)
+                     if (self.v_mlp is not None and next_layer.v_mlp is not None and next_layer.out_channels % 4 == 0)
+                     else None)
+        x_max = None
+        blocks_m = list(self.s_mlp_max)
+        if self.centralized and len(blocks_m) > 1:
+            # edge MLP of depth > 1: BatchNorm over the [E, C] edge tensor between two products -- computed outside
+            x_max = self._centralized_max(x, graph)
+            blocks_m = []
+        blocks_s = list(self.s_mlp)
+        blocks_v = list(self.v_mlp) if self.v_mlp is not None else None
+        cfg = LayerCfg(graph, grad, div, [b[1].bn for b in blocks_m] if blocks_m else None, [b[1].bn for b in blocks_s],
+                       [b[1].batchnorm.bn for b in blocks_v] if blocks_v is not None else None,
+                       self.centralized, slopes_m, slopes_s, chain, out_block)
+        params = []
+        for b in blocks_m + blocks_s:
+            params.extend((b[0].weight, b[1].bn.weight, b[1].bn.bias))
+        for b in blocks_v or []:
+            params.extend((b[0].weight, b[1].batchnorm.bn.weight, b[1].batchnorm.bn.bias))
+        x_new, v_new, x_dup = DeltaConvLayerFn.apply(x, v, x_max, cfg, *params)
+        if out_block is not None:         # x_new = what the next layer consumes (lives in its operand buffer)
+            return x_dup, (v_new if blocks_v is not None else v), x_new
+        return x_new, (v_new if blocks_v is not None else v)
 
     def forward_composed(self, x, v, grad, div, edge_index):
         """The same layer as a chain of small autograd nodes (any depth / activation)."""

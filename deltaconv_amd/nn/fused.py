@@ -294,6 +294,7 @@ def edge_max_bn(y, graph, bn, slope):
 
 
 USE_MFMA_TN = True      # A/B switch: hand-written fp32-MFMA kernel for the tall-skinny weight gradients
+OWN_TN_MAX_OUTPUTS = 1 << 21
 
 
 def gemm_tn(a, b):
@@ -303,9 +304,9 @@ def gemm_tn(a, b):
     n = b.shape[1]
     # measured (profiles/r01i_kernels.log, r01n, gpurun r02c): the MFMA kernels win or tie against the TUNED library
     # up to 256K outputs (e.g. 256x128: 31 vs 62 us; 512x256: 91 vs 88 us; 64x64: 11 vs 10 us) and by 5-18x against
-    # its default heuristic (448x256: 1.5 ms).  Only the 1024x512 embedding (library 272 us vs 312 us) and per-cloud
-    # problems (few rows) stay with the library.
-    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m * n <= 262144
+    # its default heuristic (448x256: 1.5 ms); the 1024x512 embedding is ~4 % behind the tuned library (312 vs ~300 us)
+    # and ahead of the untuned one.  Only per-cloud problems (few rows) stay with the library.
+    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m * n <= OWN_TN_MAX_OUTPUTS
             and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
         nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, n)
@@ -320,9 +321,12 @@ USE_OWN_GEMM = True        # A/B switch: False = vendor library (torch.mm) for t
 OWN_GEMM_MIN_ROWS = 1024   # per-cloud rows (classification head: B rows) stay with the library: launch-latency bound
 
 
-OWN_GEMM_MAX_WEIGHT = 262144   # input gradient of wider layers (the 1024 x 512 embedding) stays with the tuned library:
-                               # 240 us vs 276 us (profiles/r02f_step_timeline.txt); its forward product is hand-written
-                               # (statistics epilogue: 274 us vs 238 + 27 + 5 us)
+# Every per-point product runs on the hand-written kernels, the embedding MLP included: against the per-shape TUNED
+# vendor library its input gradient is 276 vs 240 us and its weight gradient ~312 vs ~300 us at the ModelNet40 shape
+# (profiles/r02f_step_timeline.txt, r02e_gemm_lab.txt) -- 1 % of the step -- but against the library's default
+# heuristic (any shape without a shipped TunableOp entry: the other configurations) the hand-written kernels win by
+# 1.3-1.5x (ShapeNet embedding: 376 + 241 us vs ~250 + ~250 us), and the path no longer depends on tuning files.
+OWN_GEMM_MAX_WEIGHT = 1 << 30
 
 
 def _own_gemm(x):
@@ -371,15 +375,16 @@ def mm_nn(dy, w, out=None, accumulate=False):
     return out
 
 
-def linear_stats(x, w, bn, gamma, beta, vn=False):
+def linear_stats(x, w, bn, gamma, beta, vn=0):
     """h = x w^T together with the BatchNorm coefficients of the layer behind it, from the GEMM epilogue:
-    -> (h, coef[4, C] = mean / invstd / scale / shift, use_batch_stats).  vn: w = the [2co, K] view of a vector
-    block, statistics of the per-point norms of the interleaved (P_c, Q_c) output (C = co).  Running statistics and
-    num_batches_tracked advance exactly as in bn_act / vector_nonlin."""
+    -> (h, coef[4, C] = mean / invstd / scale / shift, use_batch_stats).  vn = 2: w = the [2co, K] view of the first
+    vector block, statistics of the per-point norms of the interleaved (P_c, Q_c) output (C = co); vn = 1: a deeper
+    vector block, h = [2n, co], norms over the row pairs.  Running statistics and num_batches_tracked advance exactly
+    as in bn_act / vector_nonlin."""
     x, w = _rowmajor(x), _rowmajor(w)
     m, k = x.shape
     n = w.shape[0]
-    c = n // 2 if vn else n
+    c = n // 2 if vn == 2 else n
     rows = m // 2 if vn else m
     dev = x.device
     check_bn_rows(bn, rows)
@@ -397,8 +402,8 @@ def linear_stats(x, w, bn, gamma, beta, vn=False):
         nb = lib.raw("dc_linear_stats_workspace_bytes")(m, n, k, 0)
         ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
         if vn:
-            lib.call("dc_linear_vn_stats_forward", x, x.stride(0), w, w.stride(0), rows, c, k, h, n, gamma, beta,
-                     float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
+            lib.call("dc_linear_vn_stats_forward", x, x.stride(0), w, w.stride(0), rows, c, k, h, n, int(vn == 2), gamma,
+                     beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
         else:
             lib.call("dc_linear_bn_stats_forward", x, x.stride(0), w, w.stride(0), m, n, k, h, n, gamma, beta,
                      float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
@@ -408,8 +413,8 @@ def linear_stats(x, w, bn, gamma, beta, vn=False):
         assert sync_group() is None, "synchronised BatchNorm runs through bn_act / vector_nonlin"
         ws, nb = _ws(rows, c, dev)
         if vn:
-            lib.call("dc_vn_stats", h, rows, c, n, 2, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1],
-                     coef[2], coef[3], ws, nb)
+            lib.call("dc_vn_stats", h, rows, c, n, 2 if vn == 2 else 0, gamma, beta, float(bn.eps), mom, rm, rv, coef[0],
+                     coef[1], coef[2], coef[3], ws, nb)
         else:
             lib.call("dc_bn_stats", h, m, n, n, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2],
                      coef[3], ws, nb)

@@ -10,17 +10,21 @@ owns its buffers:
 * in the backward pass every transposed apply accumulates in place (``accumulate=1``) into the
   gradient buffer of the tensor it belongs to -- no autograd ``add`` kernels, no zero fills;
 * the residual ``x_max + s_mlp(...)`` is folded into the BatchNorm/LeakyReLU kernel, the BatchNorm +
-  activation of ``s_mlp_max`` into the max-aggregation gather;
+  activation of the last ``s_mlp_max`` block into the max-aggregation gather;
 * consecutive layers chain their buffers: x' / v' are produced inside the NEXT layer's operand buffers and
   x' is written a second time into its column block of the concatenated embedding input (``LayerCfg.chain``,
-  ``LayerCfg.dup``) -- no copies between layers, no ``torch.cat`` of the layer outputs;
-* the I_J fold of the first VectorMLP layer uses the reference's [co, 2K] weight as a [2co, K] view (GEMM
+  ``LayerCfg.dup``) -- no copies between layers, no ``torch.cat`` of the layer outputs.  The hand-over needs no
+  registry: a chained tensor is a view whose ``_base`` IS the next operand buffer;
+* the I_J fold of the first VectorMLP block uses the reference's [co, 2K] weight as a [2co, K] view (GEMM
   output = interleaved (P_c, Q_c) columns), so neither the weight nor its gradient is re-stacked.
 
+MLPs of any depth (reference default 1; the part-segmentation net uses 2, models/deltanet_segmentation.py:10): every
+block but the last of a stream is [GEMM + statistics epilogue -> BatchNorm/activation kernel], the last block carries
+the fusions above.  Only the edge MLP of a centralized first layer with depth > 1 stays outside (its BatchNorm runs
+over the [E, C] edge tensor between two products): its result enters the node as ``x_max``.
+
 Dense GEMMs: hand-written fp32-MFMA kernels (csrc/gemm.hip forward + input gradient, the forward ones with the
-BatchNorm statistics of the block in their epilogue; csrc/gemm_tn.hip weight gradient).  Used when every MLP of the
-layer has depth 1 and standard activations (all reference models except the depth-2 segmentation net, which takes
-the composed path).
+BatchNorm statistics of the block in their epilogue; csrc/gemm_tn.hip weight gradient).
 """
 import torch
 
@@ -28,10 +32,6 @@ from .._lib import lib
 from . import fused
 
 _F32 = torch.float32
-
-
-def _c(t):
-    return t if (t.dtype == _F32 and t.is_contiguous()) else t.contiguous().float()
 
 
 def _rows(t):
@@ -42,36 +42,28 @@ def _rows(t):
 
 
 class LayerCfg:
-    """Non-tensor state of one call: graph, operators, BatchNorm modules, flags.
+    """Non-tensor state of one call: graph, operators, BatchNorm modules (one per block and stream), flags.
     chain = (width of the next layer's s_mlp operand, width of its v_mlp operand or None): the layer then
-    writes x' / v' straight into the left columns of those operands (allocated here, adopted by the next
-    layer through `_CHAIN`), so the next layer's `[x | ...]` / `[v | ...]` buffers need no copy."""
+    writes x' / v' straight into the left columns of those operands, so the next layer's `[x | ...]` /
+    `[v | ...]` buffers need no copy.
+    bns_m = None: the max-aggregation branch was computed outside (x_max is an input of the node)."""
 
-    def __init__(self, graph, grad, div, bn_m, bn_s, bn_v, centralized, slope_m, slope_s, vector, chain=None,
-                 dup=None):
+    def __init__(self, graph, grad, div, bns_m, bns_s, bns_v, centralized, slopes_m, slopes_s, chain=None, dup=None):
         self.graph, self.grad, self.div = graph, grad, div
-        self.bn_m, self.bn_s, self.bn_v = bn_m, bn_s, bn_v
-        self.centralized, self.slope_m, self.slope_s, self.vector = centralized, slope_m, slope_s, vector
+        self.bns_m, self.bns_s, self.bns_v = bns_m, bns_s, bns_v
+        self.centralized, self.slopes_m, self.slopes_s = centralized, slopes_m, slopes_s
+        self.vector = bns_v is not None
         self.chain = chain
         self.dup = dup     # (buffer [n, sum co], column offset): x' is written into that column block as well
 
 
-# operand buffers handed from one layer to the next: data_ptr of the view -> buffer.  The consumer pops its
-# entry; entries that are never consumed (the next layer was not called) are dropped by the size cap.
-_CHAIN = {}
-
-
-def _offer(view, buf):
-    if len(_CHAIN) >= 16:
-        _CHAIN.clear()
-    _CHAIN[view.data_ptr()] = buf
-
-
 def _adopt(t, rows, cols, width):
-    """The chain buffer [rows, width] whose left `cols` columns ARE `t`, or None."""
-    buf = _CHAIN.pop(t.data_ptr(), None)
-    if (buf is not None and tuple(buf.shape) == (rows, width) and tuple(t.shape) == (rows, cols)
-            and t.stride(0) == width and t.stride(1) == 1 and t.dtype == _F32 and buf.data_ptr() == t.data_ptr()):
+    """The buffer [rows, width] whose left `cols` columns ARE `t` (t was produced by the previous layer inside this
+    layer's operand buffer), or None."""
+    buf = t._base
+    if (buf is not None and buf.dim() == 2 and tuple(buf.shape) == (rows, width) and tuple(t.shape) == (rows, cols)
+            and t.stride(0) == width and t.stride(1) == 1 and t.dtype == _F32 and buf.dtype == _F32
+            and buf.is_contiguous() and buf.data_ptr() == t.data_ptr()):
         return buf
     return None
 
@@ -89,59 +81,92 @@ def _bn_mode(bn):
     return use_batch, mom, rm, rv
 
 
-def _bn_coeffs(h, rows, c, ld, bn, gamma, beta, dev, vn_combine=None):
-    """Batch (or running) statistics of h -> coef[4,c] = mean, invstd, scale, shift."""
-    fused.check_bn_rows(bn, rows)
-    use_batch, mom, rm, rv = _bn_mode(bn)
-    coef = torch.empty(4, c, dtype=_F32, device=dev)
-    if use_batch:
-        ws, nb = fused._ws(rows, c, dev)
-        if vn_combine is None:
-            lib.call("dc_bn_stats", h, rows, c, ld, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1],
-                     coef[2], coef[3], ws, nb)
-        else:
-            lib.call("dc_vn_stats", h, rows, c, ld, int(vn_combine), gamma, beta, float(bn.eps), mom, rm, rv,
-                     coef[0], coef[1], coef[2], coef[3], ws, nb)
-    else:
-        lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, float(bn.eps), c, coef[0], coef[1], coef[2], coef[3])
-    return coef, use_batch
+def _bn_backward(dy, lddy, h, coef, use, gamma, slope):
+    """-> (dh, dgamma, dbeta) of y = leaky(bn(h)) for the incoming dy (row stride lddy)."""
+    r, c = h.shape
+    dev = h.device
+    dh = torch.empty_like(h)
+    dg, db = torch.empty(c, dtype=_F32, device=dev), torch.empty(c, dtype=_F32, device=dev)
+    ws, nb = fused._ws(r, c, dev)
+    lib.call("dc_bn_act_backward", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope, int(use),
+             dh, c, dg, db, ws, nb)
+    return dh, dg, db
+
+
+def _vn_backward(dout, lddo, h, combine, coef, use, gamma):
+    """-> (dh, dgamma, dbeta) of the vector non-linearity on h ([2n, co], or interleaved (P, Q) [2n, 2co])."""
+    ld = h.shape[1]
+    co = ld // 2 if combine else ld
+    n = h.shape[0] // 2
+    dev = h.device
+    dh = torch.empty_like(h)
+    dg, db = torch.empty(co, dtype=_F32, device=dev), torch.empty(co, dtype=_F32, device=dev)
+    ws, nb = fused._ws(n, co, dev)
+    lib.call("dc_vn_backward", dout, lddo, h, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1], gamma, int(use),
+             dh, ld, dg, db, ws, nb)
+    return dh, dg, db
 
 
 class DeltaConvLayerFn(torch.autograd.Function):
+    """apply(x, v, x_max_or_None, cfg, *params); params = (W, gamma, beta) per block: the s_mlp_max blocks (none when
+    x_max is given), the s_mlp blocks, the v_mlp blocks (none for a layer without vector stream)."""
+
     @staticmethod
-    def forward(ctx, x, v, Wm, gm, bm, Ws, gs, bs, Wv, gv, bv, cfg):
+    def forward(ctx, x, v, x_max_ext, cfg, *params):
         g = cfg.graph
         n, k = g.n, g.k
         (x, ldx), (v, ldv) = _rows(x), _rows(v)
         dev = x.device
-        ci, co = x.shape[1], Wm.shape[0]
+        ci = x.shape[1]
         f32 = dict(dtype=_F32, device=dev)
         call = lib.call
         G, D = cfg.grad.coef, cfg.div.coef
+        nm = 0 if cfg.bns_m is None else len(cfg.bns_m)
+        ns = len(cfg.bns_s)
+        nv = len(cfg.bns_v) if cfg.vector else 0
+        blk = lambda i: params[3 * i:3 * i + 3]
+        pm, ps, pv = [blk(i) for i in range(nm)], [blk(nm + i) for i in range(ns)], [blk(nm + ns + i) for i in range(nv)]
+        co = ps[-1][0].shape[0]
+        saved_m, saved_s, saved_v = [], [], []      # per block: (input, h, coef, use_batch_stats)
 
         # ---- scalar stream, max aggregation over the k neighbours (deltaconv.py:50-54)
-        x_max = torch.empty(n, co, **f32)
-        if cfg.centralized:
-            y0 = fused.mm_nt(x, Wm)
-            stat = torch.empty(3, n, co, **f32)
-            args = torch.empty(2, n, co, dtype=torch.uint8, device=dev)
-            use_m, mom, rm, rv = _bn_mode(cfg.bn_m)
-            coef_m = torch.empty(4, co, **f32)
-            ws, nb = fused._ws(n, co, dev)
-            if not use_m:
-                call("dc_bn_eval_coeffs", gm, bm, rm, rv, float(cfg.bn_m.eps), co, coef_m[0], coef_m[1], coef_m[2],
-                     coef_m[3])
-            call("dc_edge_gather_stats", y0, co, g.nbr, n, k, co, int(use_m), gm, bm, float(cfg.bn_m.eps), mom,
-                 rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
-                 coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)
-            call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], cfg.slope_m,
-                 x_max, co, None)
-            max_saved = (y0, stat, args)
+        max_saved = None
+        if nm == 0:
+            x_max, ldm = _rows(x_max_ext)
         else:
-            hm, coef_m, use_m = fused.linear_stats(x, Wm, cfg.bn_m, gm, bm)      # GEMM + statistics epilogue
-            arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
-            call("dc_knn_max_affine", g.nbr, n, k, hm, co, co, coef_m[2], coef_m[3], cfg.slope_m, x_max, co, arg)
-            max_saved = (hm, arg)
+            x_max, ldm = torch.empty(n, co, **f32), co
+            inp = x
+            for (W, gm, bm), bn, slope in zip(pm[:-1], cfg.bns_m[:-1], cfg.slopes_m[:-1]):
+                h, coef, use = fused.linear_stats(inp, W, bn, gm, bm)
+                a = torch.empty_like(h)
+                call("dc_bn_act", h, n, h.shape[1], h.shape[1], coef[2], coef[3], slope, None, 0, a, h.shape[1])
+                saved_m.append((inp, h, coef, use))
+                inp = a
+            Wm, gm, bm = pm[-1]
+            bn_m, slope_m = cfg.bns_m[-1], cfg.slopes_m[-1]
+            if cfg.centralized:                      # depth 1 only (DeltaConv.forward routes depth > 1 outside)
+                y0 = fused.mm_nt(inp, Wm)
+                stat = torch.empty(3, n, co, **f32)
+                args = torch.empty(2, n, co, dtype=torch.uint8, device=dev)
+                use_m, mom, rm, rv = _bn_mode(bn_m)
+                coef_m = torch.empty(4, co, **f32)
+                ws, nb = fused._ws(n, co, dev)
+                if not use_m:
+                    call("dc_bn_eval_coeffs", gm, bm, rm, rv, float(bn_m.eps), co, coef_m[0], coef_m[1], coef_m[2],
+                         coef_m[3])
+                call("dc_edge_gather_stats", y0, co, g.nbr, n, k, co, int(use_m), gm, bm, float(bn_m.eps), mom,
+                     rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
+                     coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)
+                call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], slope_m,
+                     x_max, co, None)
+                max_saved = (stat, args)
+                saved_m.append((inp, y0, coef_m, use_m))
+            else:
+                hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
+                arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
+                call("dc_knn_max_affine", g.nbr, n, k, hm, co, co, coef_m[2], coef_m[3], slope_m, x_max, co, arg)
+                max_saved = (arg,)
+                saved_m.append((inp, hm, coef_m, use_m))
 
         # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)
         x_cat = _adopt(x, n, ci, 4 * ci)
@@ -149,21 +174,30 @@ class DeltaConvLayerFn(torch.autograd.Function):
             x_cat = torch.empty(n, 4 * ci, **f32)
             x_cat[:, :ci].copy_(x)
         call("dc_apply_div_curl_norm", D, g.nbr, n, k, v, ci, ldv, x_cat[:, ci:], 4 * ci)
-        hs, coef_s, use_s = fused.linear_stats(x_cat, Ws, cfg.bn_s, gs, bs)
+        inp = x_cat
+        for (W, gs, bs), bn, slope in zip(ps[:-1], cfg.bns_s[:-1], cfg.slopes_s[:-1]):
+            h, coef, use = fused.linear_stats(inp, W, bn, gs, bs)
+            a = torch.empty_like(h)
+            call("dc_bn_act", h, n, h.shape[1], h.shape[1], coef[2], coef[3], slope, None, 0, a, h.shape[1])
+            saved_s.append((inp, h, coef, use))
+            inp = a
+        Ws, gs, bs = ps[-1]
+        hs, coef_s, use_s = fused.linear_stats(inp, Ws, cfg.bns_s[-1], gs, bs)
+        saved_s.append((inp, hs, coef_s, use_s))
         if cfg.chain is not None:
             xbuf = torch.empty(n, cfg.chain[0], **f32)
             x_new = xbuf[:, :co]
-            _offer(x_new, xbuf)
         else:
             x_new = torch.empty(n, co, **f32)
         ldxn = x_new.stride(0)
         # the block view is created HERE (inside the node, like the chain views): an outside view object
         # must not be returned as an output of an autograd Function
         x_dup = cfg.dup[0][:, cfg.dup[1]:cfg.dup[1] + co] if cfg.dup is not None else None
-        call("dc_bn_act2", hs, n, co, co, coef_s[2], coef_s[3], cfg.slope_s, x_max, co, x_new, ldxn, x_dup,
+        call("dc_bn_act2", hs, n, co, co, coef_s[2], coef_s[3], cfg.slopes_s[-1], x_max, ldm, x_new, ldxn, x_dup,
              x_dup.stride(0) if x_dup is not None else 0)
 
         # ---- vector stream: [v | hodge v | grad x'] and its 90-degree rotation -> v_mlp (deltaconv.py:64-68)
+        v_new = None                       # without vector stream the caller passes v through (deltaconv.py:64,70)
         if cfg.vector:
             K = 2 * ci + co
             v_cat = _adopt(v, 2 * n, ci, K)
@@ -172,40 +206,63 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 v_cat[:, :ci].copy_(v)
             call("dc_apply_hodge", G, g.nbr, n, k, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
             call("dc_apply_grad", G, g.nbr, n, k, x_new, co, ldxn, v_cat[:, 2 * ci:], K)
-            Wst = Wv.view(2 * co, K)                                 # rows (c, half): the I_J fold, a free view
-            # [2n, 2co], columns interleaved (P_c, Q_c); statistics of the per-point norms from the GEMM epilogue
-            PQ, coef_v, use_v = fused.linear_stats(v_cat, Wst, cfg.bn_v, gv, bv, vn=True)
             if cfg.chain is not None and cfg.chain[1] is not None:
                 vbuf = torch.empty(2 * n, cfg.chain[1], **f32)
                 v_new = vbuf[:, :co]
-                _offer(v_new, vbuf)
             else:
                 v_new = torch.empty(2 * n, co, **f32)
-            call("dc_vn_apply", PQ, n, co, 2 * co, 2, coef_v[2], coef_v[3], v_new, v_new.stride(0))
-        else:
-            v_cat = PQ = coef_v = Wst = None
-            use_v = False
-            v_new = None                   # the caller passes v through untouched (deltaconv.py:64,70)
+            inp = v_cat
+            for j, ((W, gv, bv), bn) in enumerate(zip(pv, cfg.bns_v)):
+                c1 = W.shape[0]
+                if j == 0:
+                    # rows (c, half) of the [c1, 2K] weight: the I_J fold, a free view.  Output [2n, 2c1], columns
+                    # interleaved (P_c, Q_c); statistics of the per-point norms from the GEMM epilogue
+                    h, coef, use = fused.linear_stats(inp, W.view(2 * c1, K), bn, gv, bv, vn=2)
+                else:
+                    h, coef, use = fused.linear_stats(inp, W, bn, gv, bv, vn=1)
+                out = v_new if j == nv - 1 else torch.empty(2 * n, c1, **f32)
+                call("dc_vn_apply", h, n, c1, h.shape[1], 2 if j == 0 else 0, coef[2], coef[3], out, out.stride(0))
+                saved_v.append((inp, h, coef, use))
+                inp = out
 
         ctx.cfg = cfg
-        ctx.flags = (use_m, use_s, use_v, ci, co)
-        ctx.max_saved = max_saved
-        ctx.save_for_backward(x, v, Wm, gm, Ws, gs, Wst, gv, coef_m, x_cat, hs, coef_s, v_cat, PQ, coef_v)
+        ctx.meta = (ci, co, nm, ns, nv, [s[3] for s in saved_m], [s[3] for s in saved_s], [s[3] for s in saved_v],
+                    bool(cfg.centralized and nm > 0))
+        ctx.max_saved_n = 0 if max_saved is None else len(max_saved)
+        flat = [x, v, x_cat]
+        for s in saved_m + saved_s + saved_v:
+            flat.extend(s[:3])
+        flat.extend(max_saved or ())
+        flat.extend(params)
+        ctx.save_for_backward(*flat)
         return x_new, v_new, x_dup
 
     @staticmethod
     def backward(ctx, dx_new, dv_new, dx_dup):
         cfg = ctx.cfg
-        x, v, Wm, gm, Ws, gs, Wst, gv, coef_m, x_cat, hs, coef_s, v_cat, PQ, coef_v = ctx.saved_tensors
-        use_m, use_s, use_v, ci, co = ctx.flags
+        ci, co, nm, ns, nv, use_m, use_s, use_v, centralized = ctx.meta
+        sv = list(ctx.saved_tensors)
+        x, v, x_cat = sv[0], sv[1], sv[2]
+        pos = 3
+
+        def take(cnt):
+            nonlocal pos
+            out = [tuple(sv[pos + 3 * i:pos + 3 * i + 3]) for i in range(cnt)]
+            pos += 3 * cnt
+            return out
+        sm, ss, svv = take(nm), take(ns), take(nv)
+        max_saved = sv[pos:pos + ctx.max_saved_n]
+        params = sv[pos + ctx.max_saved_n:]
+        blk = lambda i: params[3 * i:3 * i + 3]
+        pm, ps, pv = [blk(i) for i in range(nm)], [blk(nm + i) for i in range(ns)], [blk(nm + ns + i) for i in range(nv)]
         g = cfg.graph
         n, k = g.n, g.k
         dev = x.device
         f32 = dict(dtype=_F32, device=dev)
         call = lib.call
         tptr, tedge = g.csc()
-        need_x, need_v = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        dWv = dgv = dbv = None
+        need_x, need_v, need_xmax = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gm_list, gs_list, gv_list = [None] * nm, [None] * ns, [None] * nv        # per block (dW, dgamma, dbeta)
 
         # d x' arrives from the next layer (dx_new) and / or from the concatenated embedding input (dx_dup)
         if dx_new is not None and dx_dup is not None:
@@ -214,36 +271,47 @@ class DeltaConvLayerFn(torch.autograd.Function):
             (dxn, lddx), private = _rows(dx_new if dx_new is not None else dx_dup), False
         else:
             dxn, lddx, private = torch.zeros(n, co, **f32), co, True
+
+        # ---- vector stream
         dv_cat = None
-        if cfg.vector and dv_new is not None:
+        if nv and dv_new is not None:
             K = 2 * ci + co
-            dvn, lddvn = _rows(dv_new)
-            dPQ = torch.empty_like(PQ)
-            dgv, dbv = torch.empty(co, **f32), torch.empty(co, **f32)
-            ws, nb = fused._ws(n, co, dev)
-            call("dc_vn_backward", dvn, lddvn, PQ, 2 * co, 2, n, co, coef_v[2], coef_v[3], coef_v[0], coef_v[1], gv,
-                 int(use_v), dPQ, 2 * co, dgv, dbv, ws, nb)
-            dWv = fused.gemm_tn(dPQ, v_cat).view(co, 2 * K)           # [2co, K] rows (c, half) = the [co, 2K] layout
-            if need_v or ctx.needs_input_grad[0]:
-                dv_cat = fused.mm_nn(dPQ, Wst)                        # [2n, K]
-            else:   # first layer (x, v carry no gradient): only the `grad @ x'` block of d v_cat is consumed
-                dv_cat = torch.empty(2 * n, K, **f32)
-                fused.mm_nn(dPQ, Wst[:, 2 * ci:].contiguous(), out=dv_cat[:, 2 * ci:])
+            dcur, ldd = _rows(dv_new)
+            for j in range(nv - 1, -1, -1):
+                inp, h, coef = svv[j]
+                W, gv, _ = pv[j]
+                dh, dg, db = _vn_backward(dcur, ldd, h, 2 if j == 0 else 0, coef, use_v[j], gv)
+                if j == 0:
+                    Wst = W.view(2 * W.shape[0], K)
+                    dW = fused.gemm_tn(dh, inp).view(W.shape[0], 2 * K)      # [2c, K] rows (c, half) = the [c, 2K] layout
+                    if need_v or need_x:
+                        dv_cat = fused.mm_nn(dh, Wst)                        # [2n, K]
+                    else:   # first layer (x, v carry no gradient): only the `grad @ x'` block of d v_cat is consumed
+                        dv_cat = torch.empty(2 * n, K, **f32)
+                        fused.mm_nn(dh, Wst[:, 2 * ci:].contiguous(), out=dv_cat[:, 2 * ci:])
+                else:
+                    dW = fused.gemm_tn(dh, inp)
+                    dcur = fused.mm_nn(dh, W)
+                    ldd = dcur.stride(0)
+                gv_list[j] = (dW, dg, db)
             # grad^T of the `grad @ x'` block accumulates into d x'
             if not private:                    # accumulated into below: never touch autograd's buffer
                 dxn, lddx = (dxn.clone() if dxn.is_contiguous() else dxn.contiguous()), co
             call("dc_apply_grad_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, dxn, lddx, 1)
 
-        # ---- s_mlp block (residual: d x_max = d x')
-        dhs = torch.empty_like(hs)
-        dgs, dbs = torch.empty(co, **f32), torch.empty(co, **f32)
-        ws, nb = fused._ws(n, co, dev)
-        call("dc_bn_act_backward", dxn, lddx, hs, co, n, co, coef_s[2], coef_s[3], coef_s[0], coef_s[1], gs, cfg.slope_s,
-             int(use_s), dhs, co, dgs, dbs, ws, nb)
-        dWs = fused.gemm_tn(dhs, x_cat)
+        # ---- s_mlp blocks (residual: d x_max = d x')
         d_xcat = None
-        if need_x or need_v:
-            d_xcat = fused.mm_nn(dhs, Ws)                             # [n, 4ci] = d[x | div | curl | norm]
+        dcur, ldd = dxn, lddx
+        for j in range(ns - 1, -1, -1):
+            inp, h, coef = ss[j]
+            W, gs, _ = ps[j]
+            dh, dg, db = _bn_backward(dcur, ldd, h, coef, use_s[j], gs, cfg.slopes_s[j])
+            gs_list[j] = (fused.gemm_tn(dh, inp), dg, db)
+            if j > 0:
+                dcur = fused.mm_nn(dh, W)
+                ldd = dcur.stride(0)
+            elif need_x or need_v:
+                d_xcat = fused.mm_nn(dh, W)                           # [n, 4ci] = d[x | div | curl | norm]
         if dv_cat is not None and d_xcat is not None:   # hodge^T accumulates into d[div | curl]
             call("dc_apply_hodge_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, ci:], ci, 2 * ci + co,
                  d_xcat[:, ci:], 4 * ci, 1)
@@ -259,41 +327,45 @@ class DeltaConvLayerFn(torch.autograd.Function):
                      dv, ci, 0)
 
         # ---- max-aggregation branch (d x_max = d x')
-        dgm, dbm = torch.empty(co, **f32), torch.empty(co, **f32)
-        ws, nb = fused._ws(n, co, dev)
-        if cfg.centralized:
-            y0, stat, args = ctx.max_saved
-            dzs, dy0 = torch.empty(n, co, **f32), torch.empty(n, co, **f32)
-            call("dc_edge_max_backward", dxn, lddx, y0, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
-                 stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slope_m, int(use_m), dzs, dy0, co, dgm, dbm,
-                 ws, nb)
-            dpre = dy0
+        dx = d_xcat[:, :ci] if (need_x and d_xcat is not None) else None
+        d_xmax = None
+        if nm == 0:
+            d_xmax = dxn if need_xmax else None
         else:
-            hm, arg = ctx.max_saved
-            dym = torch.empty(n, co, **f32)
-            call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, lddx, dym, co, 0)
-            dpre = torch.empty_like(hm)
-            call("dc_bn_act_backward", dym, co, hm, co, n, co, coef_m[2], coef_m[3], coef_m[0], coef_m[1], gm,
-                 cfg.slope_m, int(use_m), dpre, co, dgm, dbm, ws, nb)
-        dWm = fused.gemm_tn(dpre, x)
-        dx = None
-        if need_x:                            # d x = d_xcat[:, :ci] + dpre Wm, accumulated in place (GEMM with ldc = 4 ci)
-            dx = d_xcat[:, :ci]
-            fused.mm_nn(dpre, Wm, out=dx, accumulate=True)
-        nz = lambda t, ref: t if ref is not None else None
-        return (dx, dv, dWm, nz(dgm, gm), nz(dbm, gm), dWs, nz(dgs, gs), nz(dbs, gs), dWv, nz(dgv, gv), nz(dbv, gv),
-                None)
+            inp, hm, coef_m = sm[-1]
+            Wm, gm, _ = pm[-1]
+            if centralized:
+                stat, args = max_saved
+                dzs, dpre = torch.empty(n, co, **f32), torch.empty(n, co, **f32)
+                dg, db = torch.empty(co, **f32), torch.empty(co, **f32)
+                ws, nb = fused._ws(n, co, dev)
+                call("dc_edge_max_backward", dxn, lddx, hm, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
+                     stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slopes_m[-1], int(use_m[-1]), dzs, dpre, co,
+                     dg, db, ws, nb)
+            else:
+                (arg,) = max_saved
+                dym = torch.empty(n, co, **f32)
+                call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, lddx, dym, co, 0)
+                dpre, dg, db = _bn_backward(dym, co, hm, coef_m, use_m[-1], gm, cfg.slopes_m[-1])
+            gm_list[-1] = (fused.gemm_tn(dpre, inp), dg, db)
+            dh, W = dpre, Wm
+            for j in range(nm - 2, -1, -1):
+                da = fused.mm_nn(dh, W)
+                inp, h, coef = sm[j]
+                W, gmj, _ = pm[j]
+                dh, dg, db = _bn_backward(da, da.stride(0), h, coef, use_m[j], gmj, cfg.slopes_m[j])
+                gm_list[j] = (fused.gemm_tn(dh, inp), dg, db)
+            if need_x:                        # d x = d_xcat[:, :ci] + dh W, accumulated in place (GEMM with ldc = 4 ci)
+                fused.mm_nn(dh, W, out=dx, accumulate=True)
 
-
-# ---- concatenation of the layer outputs without a copy ---------------------------------------------
-_CATBUF = {}   # data_ptr of the first block -> (buffer [n, sum co], [(data_ptr, width), ...])
-
-
-def offer_cat(buf, widths):
-    if len(_CATBUF) >= 8:
-        _CATBUF.clear()
-    offs = [sum(widths[:i]) for i in range(len(widths))]
-    _CATBUF[buf.data_ptr()] = (buf, [(buf.data_ptr() + 4 * o, w) for o, w in zip(offs, widths)])
+        grads = []
+        for lst, pl in ((gm_list, pm), (gs_list, ps), (gv_list, pv)):
+            for got, (W, gamma, beta) in zip(lst, pl):
+                if got is None:
+                    grads.extend((None, None, None))
+                else:
+                    grads.extend((got[0], got[1] if gamma is not None else None, got[2] if beta is not None else None))
+        return (dx, dv, d_xmax, None, *grads)
 
 
 class _ViewCat(torch.autograd.Function):
@@ -317,11 +389,15 @@ class _ViewCat(torch.autograd.Function):
 
 def cat_outputs(xs):
     """torch.cat(xs, dim=1) (deltanet_classification.py:42, deltanet_segmentation.py:58) -- free when the
-    backbone already wrote every layer output into its column block of one buffer (`LayerCfg.dup`)."""
-    hit = _CATBUF.pop(xs[0].data_ptr(), None) if len(xs) else None
-    if hit is not None:
-        buf, blocks = hit
-        if len(blocks) == len(xs) and all(x.data_ptr() == p and x.shape[1] == w and x.stride(0) == buf.shape[1]
-                                          for x, (p, w) in zip(xs, blocks)):
+    backbone already wrote every layer output into its column block of one buffer (`LayerCfg.dup`): the tensors are
+    then views of that buffer (`_base`) at consecutive column offsets."""
+    buf = xs[0]._base if len(xs) else None
+    if buf is not None and buf.dim() == 2 and buf.is_contiguous() and buf.dtype == _F32:
+        off, ok = 0, True
+        for x in xs:
+            ok = ok and (x._base is buf and x.dim() == 2 and x.shape[0] == buf.shape[0] and x.stride(1) == 1
+                         and x.stride(0) == buf.shape[1] and x.storage_offset() == buf.storage_offset() + off)
+            off += x.shape[1] if x.dim() == 2 else 0
+        if ok and off == buf.shape[1]:
             return _ViewCat.apply((buf,), *xs)
     return torch.cat(xs, dim=1)

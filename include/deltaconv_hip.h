@@ -226,8 +226,9 @@ int dc_vn_backward_apply(const float* dout, int64_t lddo, const float* in, int64
  *   dc_linear_backward_input    dX[M,K] (+)= dY[M,N] W[N,K]
  * and the forward product fused with the statistics of the layer that follows it (nn/nonlin.py:24-35, 63-79):
  *   dc_linear_bn_stats_forward  Y = X W^T  + BatchNorm batch statistics of Y (== dc_bn_stats on Y)
- *   dc_linear_vn_stats_forward  PQ[2n,2co] = V[2n,K] Wst[2co,K]^T (columns interleaved (P_c, Q_c)) + statistics of
- *                               |y| over the n points (== dc_vn_stats(combine = 2) on PQ)
+ *   dc_linear_vn_stats_forward  interleaved: PQ[2n,2co] = V[2n,K] Wst[2co,K]^T (columns interleaved (P_c, Q_c)) +
+ *                               statistics of |y| over the n points (== dc_vn_stats(combine = 2) on PQ); otherwise
+ *                               Y[2n,co] = V W[co,K]^T + statistics of |(Y_2i, Y_2i+1)| (== dc_vn_stats(combine = 0))
  * The statistics come out of the GEMM epilogue (fp64 tile sums, ordered final stage): no pass over Y.
  * Workspace: dc_linear_stats_workspace_bytes(M, N, K, tile)  (vn: M = 2n, N = 2co). */
 int dc_linear_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K,
@@ -241,7 +242,8 @@ int dc_linear_bn_stats_forward(const float* X, int64_t ldx, const float* W, int6
                                float* scale, float* shift, int32_t tile, void* workspace, size_t workspace_bytes,
                                void* stream);
 int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const float* Wst, int64_t ldw, int64_t n, int32_t co,
-                               int32_t K, float* PQ, int64_t ldpq, const float* gamma, const float* beta, float eps,
+                               int32_t K, float* PQ, int64_t ldpq, int32_t interleaved, const float* gamma,
+                               const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
                                float* scale, float* shift, int32_t tile, void* workspace, size_t workspace_bytes,
                                void* stream);

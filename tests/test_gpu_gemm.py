@@ -120,7 +120,7 @@ def test_linear_vn_stats(n, co, K, tile):
     coef = torch.empty(4, co, device=DEV)
     nb = lib.raw("dc_linear_stats_workspace_bytes")(2 * n, 2 * co, K, tile)
     ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=DEV)
-    lib.call("dc_linear_vn_stats_forward", v, K, w, K, n, co, K, pq, 2 * co, gamma, beta, 1e-5, 0.1, rm1, rv1, coef[0],
+    lib.call("dc_linear_vn_stats_forward", v, K, w, K, n, co, K, pq, 2 * co, 1, gamma, beta, 1e-5, 0.1, rm1, rv1, coef[0],
              coef[1], coef[2], coef[3], tile, ws, nb)
     assert rel_err(pq, v.double() @ w.double().t()) < _tol(K)
     ref = torch.empty(4, co, device=DEV)
@@ -130,6 +130,26 @@ def test_linear_vn_stats(n, co, K, tile):
     for q in range(4):
         assert rel_err(coef[q], ref[q]) < 1e-5, q
     assert rel_err(rm1, rm2) < 1e-6 and rel_err(rv1, rv2) < 1e-5
+
+
+@pytest.mark.parametrize("n,co,K", [(16384, 64, 64), (2048, 128, 128), (500, 40, 70), (1, 16, 32)])
+@pytest.mark.parametrize("tile", [0, 1, 3])
+def test_linear_vn_stats_plain(n, co, K, tile):
+    """Deeper vector blocks: Y[2n, co] = V W^T, statistics of the norms of the (2i, 2i+1) row pairs."""
+    v, w = _rand(2 * n, K, seed=26), _rand(co, K, seed=27)
+    gamma, beta = _rand(co, seed=28) + 1.5, _rand(co, seed=29)
+    y = torch.empty(2 * n, co, device=DEV)
+    coef, ref = torch.empty(4, co, device=DEV), torch.empty(4, co, device=DEV)
+    nb = lib.raw("dc_linear_stats_workspace_bytes")(2 * n, co, K, tile)
+    ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=DEV)
+    lib.call("dc_linear_vn_stats_forward", v, K, w, K, n, co, K, y, co, 0, gamma, beta, 1e-5, 0.1, None, None, coef[0],
+             coef[1], coef[2], coef[3], tile, ws, nb)
+    assert rel_err(y, v.double() @ w.double().t()) < _tol(K)
+    nb2 = lib.raw("dc_bn_workspace_bytes")(n, co)
+    ws2 = torch.empty((nb2 + 7) // 8, dtype=torch.float64, device=DEV)
+    lib.call("dc_vn_stats", y, n, co, co, 0, gamma, beta, 1e-5, 0.1, None, None, ref[0], ref[1], ref[2], ref[3], ws2, nb2)
+    for q in range(4):
+        assert rel_err(coef[q], ref[q]) < 1e-5, q
 
 
 def test_gemm_is_deterministic():

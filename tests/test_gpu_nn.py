@@ -186,7 +186,8 @@ def test_centralized_layer_vs_oracle(depth, train):
 @pytest.mark.parametrize("centralized,vector,ci,co", [(True, True, 3, 32), (False, True, 32, 64), (False, False, 64, 64),
                                                       (False, True, 6, 10)])
 @pytest.mark.parametrize("train", [True, False])
-def test_fused_layer_matches_composed(centralized, vector, ci, co, train):
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_fused_layer_matches_composed(centralized, vector, ci, co, train, depth):
     """nn/layer.py (one autograd node, in-place accumulation, no cat) vs the chain of small nodes."""
     import deltaconv_amd as dc
     from deltaconv_amd.data import synthetic_batch
@@ -195,7 +196,7 @@ def test_fused_layer_matches_composed(centralized, vector, ci, co, train):
     xb, yb = dc.geometry.build_tangent_basis(b.norm)
     G, D = dc.geometry.build_grad_div(b.pos, b.norm, xb, yb, graph, b.batch)
     torch.manual_seed(7)
-    conv = dc.nn.DeltaConv(ci, co, depth=1, centralized=centralized, vector=vector).to(DEV)
+    conv = dc.nn.DeltaConv(ci, co, depth=depth, centralized=centralized, vector=vector).to(DEV)
     with torch.no_grad():
         for n_, p_ in conv.named_parameters():
             if n_.endswith("bn.weight"):
