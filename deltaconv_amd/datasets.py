@@ -1,6 +1,6 @@
 """Data side of the ModelNet / ShapeNet experiments without torch_geometric:
 an OFF mesh reader, a ``Data`` attribute bag the transforms operate on, ``Compose``, a collate into
-``deltaconv_amd.Batch`` and in-memory ``ModelNet`` / ``ShapeNet`` datasets with the constructors and on-disk
+``deltaconv_amd.Batch`` and in-memory ``ModelNet`` / ``ScanObjectNN`` / ``ShapeNet`` / ``ShapeSeg`` datasets with the constructors and on-disk
 layouts of the reference's ``experiments/datasets/modelnet.py:11-114`` (``root/raw/<category>/<train|test>/*.off``
 -> ``root/processed/{training,test}.pt`` after ``pre_transform``) and ``shapenet.py:13-200``.
 
@@ -158,6 +158,76 @@ class ModelNet(torch.utils.data.Dataset):
 
     def __repr__(self):
         return '{}{}({})'.format(self.__class__.__name__, self.name, len(self))
+
+
+class ScanObjectNN(torch.utils.data.Dataset):
+    """The pre-processed ScanObjectNN benchmark (experiments/datasets/scanobjectnn.py:12-110): same constructor, same
+    folder layout (``root/raw/main_split[_nobg]/<training|test>_objectdataset*.h5`` -> ``root/processed/<bg|nobg>_
+    <variant>/{training,test}.pt``), 'data' [N,2048,3] -> ``pos``, 'label' -> ``y``.  The HDF5 files are read by
+    ``deltaconv_amd.io_hdf5`` (pure numpy: h5py is not needed); an ``.npz`` with the same two arrays next to (or instead
+    of) an ``.h5`` file is accepted as well."""
+
+    url = "https://hkust-vgd.github.io/scanobjectnn/"
+    class_names = ['bag', 'bed', 'bin', 'box', 'cabinets', 'chair', 'desk', 'display', 'door', 'pillow', 'shelves',
+                   'sink', 'sofa', 'table', 'toilet']
+    augmentation_variants = [None, 'PB_T25', 'PB_T25_R', 'PB_T50_R', 'PB_T50_RS']
+    raw_file_dict = {
+        None: ['training_objectdataset.h5', 'test_objectdataset.h5'],
+        'PB_T25': ['training_objectdataset_augmented25_norot.h5', 'test_objectdataset_augmented25_norot.h5'],
+        'PB_T25_R': ['training_objectdataset_augmented25rot.h5', 'test_objectdataset_augmented25rot.h5'],
+        'PB_T50_R': ['training_objectdataset_augmentedrot.h5', 'test_objectdataset_augmentedrot.h5'],
+        'PB_T50_RS': ['training_objectdataset_augmentedrot_scale75.h5', 'test_objectdataset_augmentedrot_scale75.h5'],
+    }
+
+    def __init__(self, root, background=False, augmentation=None, train=True, transform=None, pre_transform=None,
+                 pre_filter=None):
+        assert augmentation in self.augmentation_variants
+        self.root, self.background, self.augmentation = root, background, augmentation
+        self.transform, self.pre_transform, self.pre_filter = transform, pre_transform, pre_filter
+        self.bg_path = 'main_split' if background else 'main_split_nobg'
+        self.raw_dir, self.processed_dir = osp.join(root, "raw"), osp.join(root, "processed")
+        folder = ('bg' if background else 'nobg') + '_' + (augmentation if augmentation is not None else 'vanilla')
+        paths = [osp.join(self.processed_dir, folder, f) for f in ("training.pt", "test.pt")]
+        if not all(osp.exists(p) for p in paths):
+            raws = [osp.join(self.raw_dir, self.bg_path, f) for f in self.raw_file_dict[augmentation]]
+            if not any(osp.exists(r) or osp.exists(r[:-3] + ".npz") for r in raws[:1]):
+                raise RuntimeError('Dataset not found, please download the dataset from {} and place the files in {}.'
+                                   .format(self.url, self.raw_dir))
+            os.makedirs(osp.dirname(paths[0]), exist_ok=True)
+            for raw, out in zip(raws, paths):
+                torch.save({"items": [dict(d.__dict__) for d in self._process(raw)]}, out)
+        blob = torch.load(paths[0] if train else paths[1], weights_only=False)
+        self.items = [Data(**d) for d in blob["items"]]
+
+    @staticmethod
+    def _arrays(raw):
+        import numpy as np
+        if osp.exists(raw):
+            from .io_hdf5 import File
+            f = File(raw)
+            return f["data"][...], f["label"][...]
+        z = np.load(raw[:-3] + ".npz")
+        return z["data"], z["label"]
+
+    def _process(self, raw):
+        pos, label = self._arrays(raw)
+        items = [Data(pos=torch.from_numpy(pos[i].astype("float32")), y=torch.tensor([int(label[i])]))
+                 for i in range(pos.shape[0])]
+        if self.pre_filter is not None:
+            items = [d for d in items if self.pre_filter(d)]
+        if self.pre_transform is not None:
+            items = [self.pre_transform(d) for d in items]
+        return items
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        data = self.items[i].clone()
+        return data if self.transform is None else self.transform(data)
+
+    def __repr__(self):
+        return '{}({})'.format(self.__class__.__name__, len(self))
 
 
 def read_txt_array(path):

@@ -64,6 +64,26 @@ def _sync_stats(kernel_args, c, rows, dev, group):
     return dp.all_reduce_stats(local.clone(), group), local
 
 
+def eval_coeffs(gamma, beta, rm, rv, eps, c):
+    """-> coef[4, c] = (mean, invstd, scale, shift) of an inference-mode BatchNorm: the layer folded to ONE per-channel
+    affine map (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale) that the CONSUMING kernel
+    applies (max-aggregation gather, activation + residual, pooling) -- in eval mode no BatchNorm pass exists.  The
+    rows depend only on the checkpoint: under torch.no_grad() they are computed once and kept on the running-mean
+    buffer until any of the tensors changes (in-place update = version bump, .to(device) / load = new storage)."""
+    key = (rm._version, rv._version, rm.data_ptr(), rv.data_ptr(), float(eps),
+           None if gamma is None else (gamma._version, gamma.data_ptr()),
+           None if beta is None else (beta._version, beta.data_ptr()))
+    cacheable = not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
+    hit = getattr(rm, "_dc_eval_coeffs", None) if cacheable else None
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    coef = torch.empty(4, c, dtype=torch.float32, device=rm.device)
+    lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, c, coef[0], coef[1], coef[2], coef[3])
+    if cacheable:
+        rm._dc_eval_coeffs = (key, coef)
+    return coef
+
+
 def check_bn_rows(bn, rows):
     """torch.nn.functional.batch_norm refuses a train-mode batch with one value per channel (the reference
     hits this at B = 1 in its head: deltaconv/nn/nonlin.py:29-30, SURVEY.md section 8(d) C1 caveat); same here."""
@@ -104,7 +124,7 @@ class _BNAct(torch.autograd.Function):
             lib.call("dc_bn_stats", h, r, c, c, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1], coef[2],
                      coef[3], ws, nb)
         else:
-            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, c, coef[0], coef[1], coef[2], coef[3])
+            coef = eval_coeffs(gamma, beta, rm, rv, eps, c)
         y = torch.empty_like(h)
         res = _c(residual)
         lib.call("dc_bn_act", h, r, c, c, coef[2], coef[3], slope, res, c, y, c)
@@ -178,7 +198,7 @@ class _VectorNonLin(torch.autograd.Function):
             lib.call("dc_vn_stats", inp, n, co, ld, int(combine), gamma, beta, eps, momentum, rm, rv, coef[0],
                      coef[1], coef[2], coef[3], ws, nb)
         elif mode == 1:
-            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, co, coef[0], coef[1], coef[2], coef[3])
+            coef = eval_coeffs(gamma, beta, rm, rv, eps, co)
         else:
             coef[0].zero_(); coef[1].fill_(1.0); coef[2].fill_(1.0); coef[3].copy_(beta)
         out = torch.empty(2 * n, co, dtype=torch.float32, device=dev)
@@ -250,7 +270,7 @@ class _EdgeMaxBN(torch.autograd.Function):
         coef = torch.empty(4, c, **f32)                      # mean, invstd, scale, shift
         ws, nb = _ws(n, c, dev)
         if not use_batch_stats:
-            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, c, coef[0], coef[1], coef[2], coef[3])
+            coef = eval_coeffs(gamma, beta, rm, rv, eps, c)
         lib.call("dc_edge_gather_stats", y, c, graph.nbr, n, k, c, int(use_batch_stats), gamma, beta, eps, momentum,
                  rm if use_batch_stats else None, rv if use_batch_stats else None, stat[0], stat[1], args[0], args[1],
                  stat[2], coef[0], coef[1], coef[2], coef[3], ws, nb)
@@ -419,7 +439,7 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
             lib.call("dc_bn_stats", h, m, n, n, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2],
                      coef[3], ws, nb)
     else:
-        lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, float(bn.eps), c, coef[0], coef[1], coef[2], coef[3])
+        coef = eval_coeffs(gamma, beta, rm, rv, float(bn.eps), c)
     return h, coef, use_batch
 
 
@@ -555,7 +575,7 @@ class _BNActPool(torch.autograd.Function):
             lib.call("dc_bn_stats", h, r, c, c, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1], coef[2],
                      coef[3], ws, nb)
         else:
-            lib.call("dc_bn_eval_coeffs", gamma, beta, rm, rv, eps, c, coef[0], coef[1], coef[2], coef[3])
+            coef = eval_coeffs(gamma, beta, rm, rv, eps, c)
         width = 2 * c if with_mean else c
         pooled = torch.empty(num_clouds, width, dtype=torch.float32, device=dev)
         arg = torch.empty(num_clouds, c, dtype=torch.int32, device=dev)

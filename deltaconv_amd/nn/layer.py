@@ -152,8 +152,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 coef_m = torch.empty(4, co, **f32)
                 ws, nb = fused._ws(n, co, dev)
                 if not use_m:
-                    call("dc_bn_eval_coeffs", gm, bm, rm, rv, float(bn_m.eps), co, coef_m[0], coef_m[1], coef_m[2],
-                         coef_m[3])
+                    coef_m = fused.eval_coeffs(gm, bm, rm, rv, float(bn_m.eps), co)
                 call("dc_edge_gather_stats", y0, co, g.nbr, n, k, co, int(use_m), gm, bm, float(bn_m.eps), mom,
                      rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
                      coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)

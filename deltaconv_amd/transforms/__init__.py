@@ -75,6 +75,12 @@ class NormalizeAxes(_Transform):
         return data
 
 
+def _is_batch(data):
+    """A collated multi-cloud batch (has a per-point cloud index and a cloud count) rather than one shape."""
+    return getattr(data, "batch", None) is not None and getattr(data, "num_graphs", None) is not None \
+        and data.batch.shape[0] == data.pos.shape[0]
+
+
 class RandomScale(_Transform):
     """random_scale.py:5-39: an independent factor PER AXIS drawn from ``scales``; normals follow with
     the inverse factors and are re-normalised."""
@@ -87,7 +93,13 @@ class RandomScale(_Transform):
         return str(self.scales)
 
     def __call__(self, data):
-        s = data.pos.new_empty(3).uniform_(*self.scales)
+        if _is_batch(data):
+            # a collated batch (deltaconv_amd.Batch), typically already on the GPU: one factor triple PER CLOUD, drawn
+            # and applied on the device of `pos` (two small kernels for the whole batch instead of one host-side
+            # transform per shape -- SURVEY.md section 8(f)-2: augmentation must not bottleneck 8 ranks on one host)
+            s = data.pos.new_empty(data.num_graphs, 3).uniform_(*self.scales)[data.batch]
+        else:
+            s = data.pos.new_empty(3).uniform_(*self.scales)
         data.pos = data.pos * s
         if getattr(data, 'norm', None) is not None:
             nrm = data.norm * (1 / s)
@@ -106,6 +118,11 @@ class RandomTranslateGlobal(_Transform):
 
     def __call__(self, data):
         t = _per_dim(self.translate, data.pos.size(1))
+        if _is_batch(data):                       # per-cloud offsets on the device of `pos` (see RandomScale)
+            lim = data.pos.new_tensor([abs(a) for a in t])
+            off = (data.pos.new_empty(data.num_graphs, len(t)).uniform_(-1.0, 1.0) * lim)[data.batch]
+            data.pos = data.pos + off
+            return data
         off = [data.pos.new_empty(1).uniform_(-abs(a), abs(a)) for a in t]   # one draw per axis, in order
         data.pos = data.pos + torch.stack(off, dim=-1)
         return data

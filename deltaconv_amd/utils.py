@@ -97,3 +97,42 @@ def load_checkpoint(model, path, strict=True):
     """model.load_state_dict(torch.load(path)) (train_modelnet.py:84), strict by default."""
     sd = torch.load(path, map_location='cpu', weights_only=True)
     return model.load_state_dict(sd, strict=strict)
+
+
+# ---- multi-vote evaluation of the part-segmentation experiment ----------------------------------------------
+@torch.no_grad()
+def evaluate_votes(model, loader, num_votes=10, device=None, transform=None, class_choice=None):
+    """experiments/test_shapenet.py:71-112: run the test set ``num_votes`` times (the dataset / ``transform``
+    re-augments every pass: RandomScale + RandomTranslateGlobal there), SUM the per-point logits of the passes, take
+    the arg-max, and report accuracy, mean per-class accuracy and the per-shape part IoU (``calc_shape_IoU``).
+    ``transform`` (optional) is applied to every collated batch after the move to ``device`` -- the GPU-side form of
+    the augmentation (deltaconv_amd.transforms on a Batch).  Clouds of one loader must have equal sizes, as in the
+    reference (it reshapes to [num_graphs, -1, classes])."""
+    model.eval()
+    acc, true_seg, label_seg = None, [], []
+    for vote in range(num_votes):
+        preds = []
+        for data in loader:
+            if device is not None:
+                data = data.to(device)
+            if transform is not None:
+                data = transform(data)
+            pred = model(data)
+            preds.append(pred.detach().float().cpu().numpy().reshape(data.num_graphs, -1, pred.size(1)))
+            if vote == 0:
+                true_seg.append(data.y.cpu().numpy().reshape(data.num_graphs, -1))
+                if getattr(data, "category", None) is not None:
+                    label_seg.append(data.category.max(dim=1)[1].cpu().numpy())
+        stacked = np.concatenate(preds, axis=0)
+        acc = stacked if acc is None else acc + stacked
+    pred_seg = np.argmax(acc, axis=2)
+    true_seg = np.concatenate(true_seg, axis=0)
+    flat_t, flat_p = true_seg.flatten(), pred_seg.flatten()
+    classes = np.unique(flat_t)
+    out = dict(pred=pred_seg, true=true_seg, accuracy=float((flat_t == flat_p).mean()),
+               balanced_accuracy=float(np.mean([(flat_p[flat_t == c] == c).mean() for c in classes])))
+    if label_seg:
+        label = np.concatenate(label_seg)
+        ious = calc_shape_IoU(pred_seg, true_seg, label, class_choice)
+        out.update(label=label, ious=ious, mean_iou=float(np.mean(ious)))
+    return out

@@ -230,3 +230,65 @@ def test_shapeseg_layout(tmp_path):
     assert float(tr[0].pos.norm(dim=1).max()) < 1.0                                   # pre_transform applied
     b = collate([tr[0], tr[1]])
     assert b.pos.shape == (8, 3) and b.y.shape == (8,)
+
+
+# ---- HDF5 reader + ScanObjectNN (files written by the real libhdf5: tests/golden/make_golden_h5.py) --------------------
+import numpy as np                                      # noqa: E402
+from tests.helpers import GOLDEN as _GOLDEN             # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["scanobjectnn_like_contiguous", "scanobjectnn_like_chunked_gzip", "mixed_types",
+                                  "nested_groups"])
+def test_hdf5_reader_against_libhdf5_files(name):
+    from deltaconv_amd.io_hdf5 import File
+    f = File(os.path.join(_GOLDEN, "h5", name + ".h5"))
+    exp = np.load(os.path.join(_GOLDEN, "h5", name + "_expected.npz"))
+    for key in exp.files:
+        d = f[key]
+        assert d.shape == exp[key].shape and d.dtype == exp[key].dtype
+        assert np.array_equal(d[...], exp[key]), key
+    if name != "nested_groups":
+        assert sorted(f.keys()) == sorted(exp.files)
+    else:
+        assert f.keys() == ["main_split"] and len(f["main_split/train"].keys()) == 40
+    with pytest.raises(KeyError):
+        f["no_such_dataset"]
+
+
+def test_hdf5_reader_rejects_what_it_cannot_read(tmp_path):
+    from deltaconv_amd.io_hdf5 import File
+    p = tmp_path / "x.h5"
+    p.write_bytes(b"not an hdf5 file at all" * 100)
+    with pytest.raises(ValueError):
+        File(str(p))
+    raw = bytearray(open(os.path.join(_GOLDEN, "h5", "mixed_types.h5"), "rb").read())
+    raw[8] = 2                                          # pretend superblock version 2 (libver='latest')
+    p.write_bytes(bytes(raw))
+    with pytest.raises(NotImplementedError):
+        File(str(p))
+
+
+def test_scanobjectnn_reference_layout(tmp_path):
+    """experiments/datasets/scanobjectnn.py: raw/main_split/<...>.h5 -> processed/bg_vanilla/{training,test}.pt."""
+    import shutil
+    from deltaconv_amd.datasets import ScanObjectNN
+    import deltaconv_amd.transforms as T
+    root = tmp_path / "ScanObjectNN"
+    raw = root / "raw" / "main_split"
+    raw.mkdir(parents=True)
+    src = os.path.join(_GOLDEN, "h5", "scanobjectnn_like_contiguous.h5")
+    shutil.copy(src, raw / "training_objectdataset.h5")
+    shutil.copy(src, raw / "test_objectdataset.h5")
+    exp = np.load(os.path.join(_GOLDEN, "h5", "scanobjectnn_like_contiguous_expected.npz"))
+    ds = ScanObjectNN(str(root), background=True, train=True, pre_transform=T.NormalizeScale())
+    assert len(ds) == 5 and repr(ds) == "ScanObjectNN(5)"
+    assert os.path.exists(root / "processed" / "bg_vanilla" / "training.pt")
+    d = ds[2]
+    assert d.pos.shape == (2048, 3) and int(d.y) == int(exp["label"][2])
+    assert float(d.pos.norm(dim=1).max()) == pytest.approx(0.999999, abs=1e-5)     # NormalizeScale ran
+    test = ScanObjectNN(str(root), background=True, train=False)                   # second open: cached
+    assert torch.equal(test[0].pos, ds[0].pos)
+    with pytest.raises(RuntimeError, match="Dataset not found"):
+        ScanObjectNN(str(tmp_path / "empty"), background=False)
+    with pytest.raises(AssertionError):
+        ScanObjectNN(str(root), augmentation="nope")

@@ -431,3 +431,32 @@ def test_eval_mode_logits_vs_oracle(kind, kw, bkw):
         ld = model(b.to(DEV))
     assert ld.shape == lo.shape
     assert rel_err(ld, lo) < (5e-3 if bkw.get("normals") is False else 1e-3)
+
+
+def test_eval_coefficient_cache_follows_the_checkpoint():
+    """Inference folds every BatchNorm into a per-channel affine map applied by the consuming kernel; under
+    torch.no_grad() the maps are cached on the running-mean buffers (nn/fused.py: eval_coeffs).  The cache must notice
+    every way the checkpoint can change: in-place updates, load_state_dict, a train step in between."""
+    b = synthetic_batch(2, 256, seed=90).to(DEV)
+    model = _model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).eval()
+    with torch.no_grad():
+        a1 = model(b)
+        a2 = model(b)                                                      # served from the cache
+        assert torch.equal(a1, a2)
+        bn = model.deltanet_base.convs[1].s_mlp[0][1].bn
+        assert getattr(bn.running_mean, "_dc_eval_coeffs", None) is not None
+        bn.running_mean.add_(0.25)                                         # in-place: version bump
+        a3 = model(b)
+        assert not torch.equal(a1, a3)
+        sd = {k_: v.clone() for k_, v in model.state_dict().items()}
+        sd["deltanet_base.convs.1.s_mlp.0.1.bn.running_mean"] -= 0.25
+        model.load_state_dict(sd)
+        assert torch.equal(model(b), a1)
+    model.train()
+    _no_dropout(model)
+    oracle.loss.calc_loss(model(b), b.y).backward()                        # running statistics move
+    model.eval()
+    fresh = _model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).eval()
+    fresh.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        assert torch.equal(model(b), fresh(b))

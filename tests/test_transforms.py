@@ -40,3 +40,27 @@ def test_geodesic_fps_transform_tiles_small_clouds():
     assert all(hasattr(T, n) for n in ["NormalizeScale", "NormalizeArea", "NormalizeAxes", "RandomScale",
                                        "RandomTranslateGlobal", "RandomRotate", "RandomNormals", "SamplePoints",
                                        "GeodesicFPS"])
+
+
+def test_batch_level_augmentation_is_per_cloud():
+    """RandomScale / RandomTranslateGlobal on a collated Batch (the GPU-side form): every cloud gets its own factor /
+    offset, normals follow the inverse scaling and stay unit length, shapes within a cloud stay rigid."""
+    import torch
+    import deltaconv_amd.transforms as T
+    from deltaconv_amd.data import synthetic_batch
+    torch.manual_seed(0)
+    b = synthetic_batch(4, 64, seed=3)
+    pos0, nrm0 = b.pos.clone(), b.norm.clone()
+    b = T.RandomScale((0.8, 1.25))(b)
+    ratio = (b.pos / pos0).view(4, 64, 3)
+    assert torch.allclose(ratio, ratio[:, :1].expand_as(ratio), atol=1e-5)          # one triple per cloud
+    assert float(ratio.min()) >= 0.8 - 1e-6 and float(ratio.max()) <= 1.25 + 1e-6
+    assert len({round(float(v), 5) for v in ratio[:, 0, 0]}) == 4                    # ... and they differ between clouds
+    assert torch.allclose(b.norm.norm(dim=1), torch.ones(256), atol=1e-5)
+    expect = nrm0 / ratio.reshape(-1, 3)
+    assert torch.allclose(b.norm, expect / expect.norm(dim=1, keepdim=True), atol=1e-5)
+    pos1 = b.pos.clone()
+    b = T.RandomTranslateGlobal(0.1)(b)
+    off = (b.pos - pos1).view(4, 64, 3)
+    assert torch.allclose(off, off[:, :1].expand_as(off), atol=1e-6) and float(off.abs().max()) <= 0.1 + 1e-6
+    assert len({round(float(v), 6) for v in off[:, 0, 0]}) == 4

@@ -41,3 +41,34 @@ def test_package_import_defaults_the_runtime_flag():
     import os
     import deltaconv_amd  # noqa: F401
     assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+
+
+def test_evaluate_votes_sums_logits_over_passes():
+    """experiments/test_shapenet.py:79-96: predictions of the votes are SUMMED before the arg-max."""
+    from deltaconv_amd.utils import evaluate_votes
+    from deltaconv_amd.data import synthetic_batch
+
+    class Flaky(torch.nn.Module):
+        """class 1 with margin 3 on the first call, class 0 with margin 1 on every later one: the summed vote flips
+        to class 0 only from the fourth pass on."""
+        def __init__(self):
+            super().__init__()
+            self.calls = 0
+
+        def forward(self, data):
+            self.calls += 1
+            out = torch.zeros(data.pos.shape[0], 4)
+            if self.calls == 1:
+                out[:, 1] = 3.0
+            else:
+                out[:, 0] = 1.0
+            return out
+
+    b = synthetic_batch(2, 16, seed=1, per_point_labels=True, categories=16, num_classes=4)
+    b.y = torch.zeros_like(b.y)
+    b.category = torch.zeros(2, 16); b.category[:, 0] = 1           # category 0 owns parts 0..3
+    r3 = evaluate_votes(Flaky(), [b], num_votes=3)
+    assert r3["accuracy"] == 0.0 and r3["pred"].shape == (2, 16)
+    r5 = evaluate_votes(Flaky(), [b], num_votes=5)
+    assert r5["accuracy"] == 1.0 and r5["balanced_accuracy"] == 1.0 and r5["mean_iou"] == 1.0
+    assert list(r5["label"]) == [0, 0]
