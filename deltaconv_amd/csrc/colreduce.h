@@ -114,6 +114,29 @@ struct BwdFin {
         m2[c] = (float)(s1 / (double)R);
     }
 };
+// backward sums -> dgamma / dbeta and the five per-column coefficients of the GEMM prologue (gemm.hip):
+//   dz = dy * act'(c_sc h + c_sh);  dh = c_g dz + c_a h + c_b  ==  gamma invstd (dz - m1 - xhat m2)   (training)
+//                                                              ==  scale dz                            (eval)
+struct BwdCoefFin {
+    long R; const float *gamma, *scale, *shift, *mean, *invstd; int training; float *dgamma, *dbeta, *coefs; int C;
+    __device__ void operator()(int c, double s0, double s1) const {
+        if (dbeta) dbeta[c] = (float)s0;
+        if (dgamma) dgamma[c] = (float)s1;
+        const double gi = (double)(gamma ? gamma[c] : 1.f) * (double)invstd[c];
+        coefs[c] = scale[c];
+        coefs[C + c] = shift[c];
+        if (training) {
+            const double m1 = s0 / (double)R, m2 = s1 / (double)R, is = invstd[c], mu = mean[c];
+            coefs[2 * C + c] = (float)gi;
+            coefs[3 * C + c] = (float)(-gi * m2 * is);
+            coefs[4 * C + c] = (float)(-gi * m1 + gi * m2 * is * mu);
+        } else {
+            coefs[2 * C + c] = scale[c];
+            coefs[3 * C + c] = 0.f;
+            coefs[4 * C + c] = 0.f;
+        }
+    }
+};
 struct NoFin {
     __device__ void operator()(int, double, double) const {}
 };

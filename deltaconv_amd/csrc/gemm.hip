@@ -62,7 +62,12 @@ struct GemmP {
     int tiles_n, remap, accumulate;
     long k_per_slab, slab_stride;          // split reduction: blockIdx.y = slab, C += slab * slab_stride
     int phase;                             // experiment: delay every other resident workgroup by half a K tile
-    int ablate;                            // experiment: drop parts of the main loop (timing only)
+    int ablate;                            // (unused)
+    // BatchNorm-backward prologue (PRO): the A operand is dh = bn_act_backward(dy, h), formed while staging:
+    //   dz = dy * (c_sc h + c_sh > 0 ? 1 : slope);   dh = c_g dz + c_a h + c_b     (dc_bn_act_backward_reduce)
+    const float* A2; long lda2;            // h, same shape / layout as A (= dy)
+    const float* pc; int pcn;              // packed per-column coefficients [5][pcn]: c_sc, c_sh, c_g, c_a, c_b
+    float slope;
     double* part; int chunks, stat_cols;   // statistics partials [2][stat_cols][chunks]
 };
 
@@ -83,8 +88,29 @@ __device__ __forceinline__ f32x4 gload4(const float* base, long ld, long row, lo
     return v;
 }
 
-template <int BM, int BN, int AL, int BL, bool FAST, int EPI>
-__global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
+template <bool FAST>
+__device__ __forceinline__ f32x4 cload4(const float* base, long col, long ncols) {      // 4 per-column coefficients
+    if (FAST) return *reinterpret_cast<const f32x4*>(base + col);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (col + e < ncols) v[e] = base[col + e];
+    return v;
+}
+
+__device__ __forceinline__ f32x4 bn_bwd_vec(const f32x4 dy, const f32x4 h, const f32x4 (&cf)[5], float slope) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(cf[0][e], h[e], cf[1][e]);
+        const float dz = dy[e] * (z > 0.f ? 1.f : slope);
+        o[e] = fmaf(cf[2][e], dz, fmaf(cf[3][e], h[e], cf[4][e]));
+    }
+    return o;
+}
+
+template <int BM, int BN, int AL, int BL, bool FAST, int EPI, int PRO = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workgroups per CU: <= 256 registers per lane
     constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;      // 32 x 32 accumulators per wave
     constexpr int A_FL = AL == A_MK ? BM * LDK : BK * BM;
@@ -114,14 +140,26 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
     f32x4 sa[A_IT], sb[B_IT];
+    f32x4 sa2[PRO ? A_IT : 1], cf[5];          // prologue: h tile, per-column coefficients of this thread's 4 columns
+    if (PRO && AL == A_KM) {                    // reduction-major A: the thread's columns never change
+#pragma unroll
+        for (int q = 0; q < 5; ++q) cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, m0 + (tid % (BM / 4)) * 4, p.M);
+    }
     auto load_tiles = [&](long k0) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + NT * it;
-            if (AL == A_MK)
+            if (AL == A_MK) {
                 sa[it] = gload4<FAST>(p.A, p.lda, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
-            else
+                if (PRO) sa2[it] = gload4<FAST>(p.A2, p.lda2, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
+            } else {
                 sa[it] = gload4<FAST>(p.A, p.lda, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
+                if (PRO) sa2[it] = gload4<FAST>(p.A2, p.lda2, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
+            }
+        }
+        if (PRO && AL == A_MK) {                // K-contiguous A: the columns are the reduction index of this tile
+#pragma unroll
+            for (int q = 0; q < 5; ++q) cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, k0 + (tid & 7) * 4, kend);
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -138,10 +176,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + NT * it;
+            const f32x4 va = PRO ? bn_bwd_vec(sa[it], sa2[it], cf, p.slope) : sa[it];
             if (AL == A_MK)
-                *reinterpret_cast<f32x4*>(a + (idx >> 3) * LDK + (idx & 7) * 4) = sa[it];
+                *reinterpret_cast<f32x4*>(a + (idx >> 3) * LDK + (idx & 7) * 4) = va;
             else
-                *reinterpret_cast<f32x4*>(a + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = sa[it];
+                *reinterpret_cast<f32x4*>(a + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = va;
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -204,7 +243,8 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
     // vector-memory load, LDS read or LDS write per couple of MFMAs) instead of leaving them in clumps during which
     // the matrix pipe idles (r02d ablation: the clumped loads + stores cost 20 % of the kernel).
     constexpr int NMF = 4 * TM * TN;                                         // MFMAs per fragment set
-    constexpr int NLD = A_IT + B_IT;                                         // global loads = LDS stores per tile
+    constexpr int NST = A_IT + B_IT;                                         // LDS stores per tile
+    constexpr int NLD = NST + (PRO ? A_IT + (AL == A_MK ? 5 : 0) : 0);       // global loads per tile
     constexpr int NRD = (AL == A_MK ? TM : 4 * TM) + (BL == B_NK ? TN : 4 * TN);   // LDS reads per fragment set
     auto tile_body = [&](int kt, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
@@ -240,7 +280,7 @@ __global__ __launch_bounds__(NT) void gemm_kernel(GemmP p) {
         }
         if (MORE) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {                                  // ... and the LDS stores of the next tile
+            for (int i = 0; i < NST; ++i) {                                  // ... and the LDS stores of the next tile
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
@@ -384,38 +424,41 @@ size_t lds_bytes(int bm, int bn, int al, int bl) {
     return std::max(2 * (a + b), (size_t)bm * bn) * sizeof(float);      // operand ring | output staging
 }
 
-template <int BM, int BN, int AL, int BL, bool FAST, int EPI>
+template <int BM, int BN, int AL, int BL, bool FAST, int EPI, int PRO>
 void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
     static bool configured = false;
     const size_t lds = lds_bytes(BM, BN, AL, BL);
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, FAST, EPI>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, FAST, EPI, PRO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, FAST, EPI>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, FAST, EPI, PRO>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
                        dim3(NT), lds, s, p);
 }
 
-template <int AL, int BL, bool FAST, int EPI>
+template <int AL, int BL, bool FAST, int EPI, int PRO>
 void launch_tile(const GemmP& p, Tile t, long tiles_m, int slabs, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
-    else if (t.bm == 128) launch_one<128, 64, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
-    else if (t.bn == 128) launch_one<64, 128, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
-    else launch_one<64, 64, AL, BL, FAST, EPI>(p, tiles_m, slabs, s);
+    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
+    else if (t.bm == 128) launch_one<128, 64, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
+    else if (t.bn == 128) launch_one<64, 128, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
+    else launch_one<64, 64, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
 }
 
-template <int AL, int BL, int EPI>
+template <int AL, int BL, int EPI, int PRO = 0>
 void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, bool fast, hipStream_t s) {
-    if (fast) launch_tile<AL, BL, true, EPI>(p, t, tiles_m, slabs, s);
-    else launch_tile<AL, BL, false, EPI>(p, t, tiles_m, slabs, s);
+    if (fast) launch_tile<AL, BL, true, EPI, PRO>(p, t, tiles_m, slabs, s);
+    else launch_tile<AL, BL, false, EPI, PRO>(p, t, tiles_m, slabs, s);
 }
 
 bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // bl: operand layout of W; epi: fused statistics; part/chunks filled by the caller for epi != 0
+struct Prologue { const float* h; long ldh; const float* coefs; int ncoef; float slope; };
+
 int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const float* B, long ldb, long M, int N, int K,
-             float* C, long ldc, int accumulate, int tile, double* part, int stat_cols, hipStream_t s) {
+             float* C, long ldc, int accumulate, int tile, double* part, int stat_cols, hipStream_t s,
+             const Prologue* pro = nullptr) {
     const Tile t = pick_tile(M, N, K, tile);
     const long tiles_m = (M + t.bm - 1) / t.bm;
     GemmP p;
@@ -428,10 +471,15 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.phase = dc_option(DC_OPT_GEMM_PHASE);
     p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
+    p.A2 = nullptr; p.lda2 = 0; p.pc = nullptr; p.pcn = 0; p.slope = 0.f;
     // fast path: no guards at all (every hot shape of the reference models)
-    const bool fast = M % t.bm == 0 && N % t.bn == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
-                      al16p(A) && al16p(B) && al16p(C);
-    if (bl == B_NK) {
+    bool fast = M % t.bm == 0 && N % t.bn == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+                al16p(A) && al16p(B) && al16p(C);
+    if (pro) {
+        p.A2 = pro->h; p.lda2 = pro->ldh; p.pc = pro->coefs; p.pcn = pro->ncoef; p.slope = pro->slope;
+        fast = fast && pro->ldh % 4 == 0 && al16p(pro->h) && al16p(pro->coefs) && pro->ncoef % 4 == 0;
+        launch_fast<A_MK, B_KN, EPI_NONE, 1>(p, t, tiles_m, 1, fast, s);
+    } else if (bl == B_NK) {
         if (epi == EPI_COLSTATS) launch_fast<A_MK, B_NK, EPI_COLSTATS>(p, t, tiles_m, 1, fast, s);
         else if (epi == EPI_VNSTATS) launch_fast<A_MK, B_NK, EPI_VNSTATS>(p, t, tiles_m, 1, fast, s);
         else if (epi == EPI_VNSTATS0) launch_fast<A_MK, B_NK, EPI_VNSTATS0>(p, t, tiles_m, 1, fast, s);
@@ -470,7 +518,7 @@ DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     return pl;
 }
 int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial,
-                     hipStream_t s) {
+                     hipStream_t s, const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f) {
     const DcTnPlan pl = dc_tn_lds_plan(R, M, N);
     const Tile t{pl.bm, pl.bn};
     const long tiles_m = (M + t.bm - 1) / t.bm;
@@ -484,9 +532,15 @@ int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R,
     p.phase = dc_option(DC_OPT_GEMM_PHASE);
     p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
-    const bool fast = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && lda % 4 == 0 &&
-                      ldb % 4 == 0 && N % 4 == 0 && al16p(A) && al16p(B) && al16p(partial);
-    launch_fast<A_KM, B_KN, EPI_NONE>(p, t, tiles_m, pl.slabs, fast, s);
+    p.A2 = h; p.lda2 = ldh; p.pc = coefs; p.pcn = M; p.slope = slope;
+    bool fast = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && lda % 4 == 0 &&
+                ldb % 4 == 0 && N % 4 == 0 && al16p(A) && al16p(B) && al16p(partial);
+    if (h) {
+        fast = fast && ldh % 4 == 0 && al16p(h) && al16p(coefs);
+        launch_fast<A_KM, B_KN, EPI_NONE, 1>(p, t, tiles_m, pl.slabs, fast, s);
+    } else {
+        launch_fast<A_KM, B_KN, EPI_NONE>(p, t, tiles_m, pl.slabs, fast, s);
+    }
     return pl.slabs;
 }
 
@@ -510,6 +564,20 @@ DC_EXPORT int dc_linear_backward_input(const float* dY, int64_t lddy, const floa
     // as a product: C[M, K] = A[M, N] B[N, K] -- reduction over N, B stored reduction-major
     return run_gemm("dc_linear_backward_input", B_KN, EPI_NONE, dY, lddy, W, ldw, M, K, N, dX, lddx, accumulate, tile,
                     nullptr, 0, static_cast<hipStream_t>(stream));
+}
+
+// dX[M,K] (lddx) (+)= dh[M,N] W[N,K] with dh = BatchNorm/activation backward of (dy, h) formed in the operand loader:
+// the [M,N] tensor dh is never written (coefs: dc_bn_act_backward_reduce).
+DC_EXPORT int dc_linear_bn_backward_input(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
+                                          float slope, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K,
+                                          float* dX, int64_t lddx, int32_t accumulate, int32_t tile, void* stream) {
+    DC_REQUIRE(dy && h && coefs && W && dX, "dc_linear_bn_backward_input: null pointer");
+    DC_REQUIRE(M >= 0 && N >= 1 && K >= 1 && lddy >= N && ldh >= N && ldw >= K && lddx >= K,
+               "dc_linear_bn_backward_input: bad size");
+    if (M == 0) return DC_OK;
+    const Prologue pro{h, (long)ldh, coefs, N, slope};
+    return run_gemm("dc_linear_bn_backward_input", B_KN, EPI_NONE, dy, lddy, W, ldw, M, K, N, dX, lddx, accumulate, tile,
+                    nullptr, 0, static_cast<hipStream_t>(stream), &pro);
 }
 
 DC_EXPORT size_t dc_linear_stats_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t tile) {

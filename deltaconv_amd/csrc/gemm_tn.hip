@@ -172,7 +172,8 @@ Plan make_plan(long R, int M, int N) {
 // LDS-staged variant (gemm.hip): full-line 16-byte loads into LDS, fragments from LDS, 16-byte stores
 struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
 DcTnPlan dc_tn_lds_plan(long R, int M, int N);
-int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial, hipStream_t s);
+int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial, hipStream_t s,
+                     const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f);
 
 DC_EXPORT size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N) {
     const Plan p = make_plan(R, M, N);
@@ -217,5 +218,29 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 64)), dim3(64 * RED_WAVES), 0, s, partial, p.slabs, mn, N, C,
                        (long)ldc, accumulate);
     DC_CHECK_LAUNCH("dc_gemm_tn");
+    return DC_OK;
+}
+
+// dW[N,K] (lddw) (+)= dh[R,N]^T X[R,K] with dh = BatchNorm/activation backward of (dy, h) formed in the operand loader
+// (LDS-staged kernel of gemm.hip, reduction split over row slabs, ordered reduction).  Workspace:
+// dc_gemm_tn_workspace_bytes(R, N, K).
+DC_EXPORT int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
+                                           float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K,
+                                           float* dW, int64_t lddw, int32_t accumulate, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(dy && h && coefs && X && dW, "dc_linear_bn_backward_weight: null pointer");
+    DC_REQUIRE(R >= 1 && N >= 1 && K >= 1 && lddy >= N && ldh >= N && ldx >= K && lddw >= K,
+               "dc_linear_bn_backward_weight: bad size");
+    if (!workspace || workspace_bytes < dc_gemm_tn_workspace_bytes(R, N, K)) {
+        dc_set_error("dc_linear_bn_backward_weight: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* partial = static_cast<float*>(workspace);
+    const int slabs = dc_tn_lds_launch(dy, (long)lddy, X, (long)ldx, (long)R, N, K, partial, s, h, (long)ldh, coefs, slope);
+    const long mn = (long)N * K;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 64)), dim3(64 * RED_WAVES), 0, s, partial, slabs, mn, K, dW,
+                       (long)lddw, accumulate);
+    DC_CHECK_LAUNCH("dc_linear_bn_backward_weight");
     return DC_OK;
 }

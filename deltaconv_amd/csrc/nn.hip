@@ -526,6 +526,27 @@ DC_EXPORT int dc_vn_backward(const float* dout, int64_t lddo, const float* in, i
     return DC_OK;
 }
 
+// Reduction half of dc_bn_act_backward for the fused GEMM prologue: dgamma, dbeta and the packed coefficients
+// coefs[5*C] (c_sc | c_sh | c_g | c_a | c_b) from which dc_linear_bn_backward_input / _weight rebuild
+// dh = c_g * dy * act'(c_sc h + c_sh) + c_a h + c_b on the fly -- the [R,C] gradient dh is never materialised.
+DC_EXPORT int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                                        const float* scale, const float* shift, const float* mean, const float* invstd,
+                                        const float* gamma, float slope, int32_t training, float* dgamma, float* dbeta,
+                                        float* coefs, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(dy && h && scale && shift && mean && invstd && coefs, "dc_bn_act_backward_reduce: null pointer");
+    DC_REQUIRE(R >= 1 && C >= 1 && lddy >= C && ldh >= C, "dc_bn_act_backward_reduce: bad size");
+    DC_WS_CHECK("dc_bn_act_backward_reduce", R, C)
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, R, C);
+    const BwdCoefFin fin{(long)R, gamma, scale, shift, mean, invstd, training, dgamma, dbeta, coefs, C};
+    if (C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && al16(dy) && al16(h))
+        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
+    else
+        run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
+    DC_CHECK_LAUNCH("dc_bn_act_backward_reduce");
+    return DC_OK;
+}
+
 // ---- split forms for synchronised BatchNorm (data parallel) -------------------
 // The fused entry points above reduce and finalise in one call.  With the batch sharded over ranks the
 // statistics of nn/nonlin.py:24-35 belong to the GLOBAL batch: each rank reduces its rows to fp64 column sums

@@ -24,6 +24,10 @@ _PENDING, _DEFER = [], [0]
 def bump_counter(bn):
     """num_batches_tracked += 1; inside ``defer_counters()`` the increments of a whole forward pass
     are applied by one multi-tensor launch instead of one tiny kernel per BatchNorm."""
+    # the statistics kernels write the running buffers through raw pointers (no autograd version bump): drop the
+    # cached inference coefficients of this layer (eval_coeffs) here, the one place every training-mode pass goes through
+    if getattr(bn.running_mean, "_dc_eval_coeffs", None) is not None:
+        del bn.running_mean._dc_eval_coeffs
     if _DEFER[0] and bn.momentum is not None:
         _PENDING.append(bn.num_batches_tracked)
     else:
@@ -443,6 +447,47 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
     return h, coef, use_batch
 
 
+FUSE_BN_BWD = True     # A/B switch: BatchNorm/activation backward folded into the consuming GEMMs (no dh tensor)
+
+
+def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_dinp=True, dinp_out=None,
+                      accumulate=False):
+    """Backward of one block y = leaky(batch_norm(inp W^T)) for the incoming dy [R, C] (row stride lddy):
+    -> (dW [C, K], dgamma, dbeta, d_inp [R, K] or None).  d_inp lands in `dinp_out` (+= when accumulate) if given.
+    Fused form (csrc/gemm.hip prologue): one reduction over (dy, h) yields dgamma / dbeta and five per-column
+    coefficients; both products rebuild dh = c_g dy act'(c_sc h + c_sh) + c_a h + c_b in their operand loaders, so the
+    [R, C] tensor dh is never written or read.  Otherwise: dc_bn_act_backward, then the two products on dh."""
+    r, c = h.shape
+    k = W.shape[1]
+    dev = h.device
+    dg = torch.empty(c, dtype=torch.float32, device=dev)
+    db = torch.empty(c, dtype=torch.float32, device=dev)
+    ws, nb = _ws(r, c, dev)
+    inp = _rowmajor(inp)
+    if FUSE_BN_BWD and _own_gemm(h) and USE_MFMA_TN and c * k <= OWN_TN_MAX_OUTPUTS:
+        coefs = torch.empty(5 * c, dtype=torch.float32, device=dev)
+        lib.call("dc_bn_act_backward_reduce", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
+                 int(use_batch), dg, db, coefs, ws, nb)
+        dW = torch.empty(c, k, dtype=torch.float32, device=dev)
+        nb2 = lib.raw("dc_gemm_tn_workspace_bytes")(r, c, k)
+        ws2 = torch.empty((nb2 + 3) // 4, dtype=torch.float32, device=dev)
+        lib.call("dc_linear_bn_backward_weight", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, dW, k, 0, ws2,
+                 ws2.numel() * 4)
+        dinp = None
+        if want_dinp:
+            dinp = dinp_out if dinp_out is not None else torch.empty(r, k, dtype=torch.float32, device=dev)
+            W = _rowmajor(W)
+            lib.call("dc_linear_bn_backward_input", dy, lddy, h, c, coefs, slope, W, W.stride(0), r, c, k, dinp,
+                     dinp.stride(0), int(accumulate), 0)
+        return dW, dg, db, dinp
+    dh = torch.empty_like(h)
+    lib.call("dc_bn_act_backward", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope, int(use_batch),
+             dh, c, dg, db, ws, nb)
+    dW = gemm_tn(dh, inp)
+    dinp = mm_nn(dh, W, out=dinp_out, accumulate=accumulate) if want_dinp else None
+    return dW, dg, db, dinp
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T (+ b) on 2-D row-major x: forward and input gradient through csrc/gemm.hip, the weight gradient
     dW = dY^T X through `gemm_tn` (own fp32-MFMA kernels; small / per-cloud problems stay with the library)."""
@@ -497,17 +542,9 @@ class _LinearBNAct(torch.autograd.Function):
         x, w, h, coef, gamma = ctx.saved_tensors
         training, slope, has_g, has_b, has_res = ctx.cfg
         dy = _c(dy)
-        r, c = h.shape
-        dev = h.device
-        dh = torch.empty_like(h)
-        dgamma = torch.empty(c, dtype=torch.float32, device=dev) if has_g else None
-        dbeta = torch.empty(c, dtype=torch.float32, device=dev) if has_b else None
-        ws, nb = _ws(r, c, dev)
-        lib.call("dc_bn_act_backward", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
-                 int(training), dh, c, dgamma, dbeta, ws, nb)
-        dw = gemm_tn(dh, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
-        dx = mm_nn(dh, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, dgamma, dbeta, None, None, (dy if has_res else None)
+        dw, dgamma, dbeta, dx = bn_block_backward(dy, dy.stride(0), x, h, coef, training, gamma, slope, w,
+                                                  want_dinp=ctx.needs_input_grad[0])
+        return (dx, dw, dgamma if has_g else None, dbeta if has_b else None, None, None, (dy if has_res else None))
 
 
 def linear_bn_act(x, lin, bn, slope, residual=None):

@@ -304,13 +304,14 @@ class DeltaConvLayerFn(torch.autograd.Function):
         for j in range(ns - 1, -1, -1):
             inp, h, coef = ss[j]
             W, gs, _ = ps[j]
-            dh, dg, db = _bn_backward(dcur, ldd, h, coef, use_s[j], gs, cfg.slopes_s[j])
-            gs_list[j] = (fused.gemm_tn(dh, inp), dg, db)
+            # (j == 0: d_inp = [n, 4ci] = d[x | div | curl | norm])
+            dW, dg, db, dinp = fused.bn_block_backward(dcur, ldd, inp, h, coef, use_s[j], gs, cfg.slopes_s[j], W,
+                                                       want_dinp=(j > 0 or need_x or need_v))
+            gs_list[j] = (dW, dg, db)
             if j > 0:
-                dcur = fused.mm_nn(dh, W)
-                ldd = dcur.stride(0)
-            elif need_x or need_v:
-                d_xcat = fused.mm_nn(dh, W)                           # [n, 4ci] = d[x | div | curl | norm]
+                dcur, ldd = dinp, dinp.stride(0)
+            else:
+                d_xcat = dinp
         if dv_cat is not None and d_xcat is not None:   # hodge^T accumulates into d[div | curl]
             call("dc_apply_hodge_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, ci:], ci, 2 * ci + co,
                  d_xcat[:, ci:], 4 * ci, 1)
@@ -341,21 +342,25 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 call("dc_edge_max_backward", dxn, lddx, hm, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
                      stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slopes_m[-1], int(use_m[-1]), dzs, dpre, co,
                      dg, db, ws, nb)
+                gm_list[-1] = (fused.gemm_tn(dpre, inp), dg, db)
+                dcur = fused.mm_nn(dpre, Wm) if nm > 1 else None
+                if nm == 1 and need_x:            # d x = d_xcat[:, :ci] + dpre Wm, accumulated in place (ldc = 4 ci)
+                    fused.mm_nn(dpre, Wm, out=dx, accumulate=True)
+                first = nm - 2
             else:
                 (arg,) = max_saved
-                dym = torch.empty(n, co, **f32)
-                call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, lddx, dym, co, 0)
-                dpre, dg, db = _bn_backward(dym, co, hm, coef_m, use_m[-1], gm, cfg.slopes_m[-1])
-            gm_list[-1] = (fused.gemm_tn(dpre, inp), dg, db)
-            dh, W = dpre, Wm
-            for j in range(nm - 2, -1, -1):
-                da = fused.mm_nn(dh, W)
+                dcur = torch.empty(n, co, **f32)
+                call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, lddx, dcur, co, 0)
+                first = nm - 1
+            for j in range(first, -1, -1):        # [Linear -> BN -> act] blocks, last to first; block 0 feeds d x
                 inp, h, coef = sm[j]
                 W, gmj, _ = pm[j]
-                dh, dg, db = _bn_backward(da, da.stride(0), h, coef, use_m[j], gmj, cfg.slopes_m[j])
-                gm_list[j] = (fused.gemm_tn(dh, inp), dg, db)
-            if need_x:                        # d x = d_xcat[:, :ci] + dh W, accumulated in place (GEMM with ldc = 4 ci)
-                fused.mm_nn(dh, W, out=dx, accumulate=True)
+                into_dx = j == 0 and need_x
+                dW, dg, db, dinp = fused.bn_block_backward(dcur, dcur.stride(0), inp, h, coef, use_m[j], gmj,
+                                                           cfg.slopes_m[j], W, want_dinp=(j > 0 or need_x),
+                                                           dinp_out=dx if into_dx else None, accumulate=into_dx)
+                gm_list[j] = (dW, dg, db)
+                dcur = dinp
 
         grads = []
         for lst, pl in ((gm_list, pm), (gs_list, ps), (gv_list, pv)):

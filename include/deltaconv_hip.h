@@ -248,6 +248,26 @@ int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const float* Wst, in
                                float* scale, float* shift, int32_t tile, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* ---- BatchNorm/activation backward folded into the GEMMs that consume it --------------------------------
+ * Backward of one MLP block y = leaky(batch_norm(x W^T)) (nn/mlp.py:7-11, nn/nonlin.py:24-35): instead of
+ * dc_bn_act_backward (reduce + a pass that writes dh) followed by two products that read dh,
+ *   dc_bn_act_backward_reduce     dgamma, dbeta, coefs[5*C]  (c_sc | c_sh | c_g | c_a | c_b)
+ *   dc_linear_bn_backward_input   dX[M,K] (+)= dh W,    dc_linear_bn_backward_weight   dW[N,K] (+)= dh^T X
+ * rebuild dh = c_g * dy * act'(c_sc h + c_sh) + c_a h + c_b inside their operand loaders: dh is never materialised
+ * (one launch and 3 passes over [M,N] less per block).  Workspaces: dc_bn_workspace_bytes(R, C) and
+ * dc_gemm_tn_workspace_bytes(R, N, K). */
+int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
+                              const float* scale, const float* shift, const float* mean, const float* invstd,
+                              const float* gamma, float slope, int32_t training, float* dgamma, float* dbeta,
+                              float* coefs, void* workspace, size_t workspace_bytes, void* stream);
+int dc_linear_bn_backward_input(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
+                                float slope, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K, float* dX,
+                                int64_t lddx, int32_t accumulate, int32_t tile, void* stream);
+int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
+                                 float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K, float* dW,
+                                 int64_t lddw, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+
 /* ---- embedding head fused with the per-cloud pooling -------------------------------------------------
  * MLP([sum c, E]) -> global_max_pool | global_mean_pool  (deltaconv/models/deltanet_classification.py:42-49),
  * -> global_max_pool (deltanet_segmentation.py:58-61).  h = Linear output [B*N, C] (equal-size clouds);

@@ -160,3 +160,30 @@ def test_gemm_is_deterministic():
         lib.call("dc_linear_forward", x, 256, w, 256, 32768, 128, 256, y, 128, 0)
         outs.append(y)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("R,C,K", [(32768, 64, 256), (32768, 256, 512), (4096, 128, 64), (3000, 40, 70), (1030, 64, 12)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_bn_block_backward_fused_matches_unfused(R, C, K, training, accumulate):
+    """BatchNorm/activation backward folded into the GEMM operand loaders (dc_bn_act_backward_reduce +
+    dc_linear_bn_backward_{input,weight}; dh never materialised) vs dc_bn_act_backward + plain products."""
+    from deltaconv_amd.nn import fused
+    x, w = _rand(R, K, seed=40), _rand(C, K, seed=41)
+    h = x @ w.t()
+    gamma, beta = _rand(C, seed=42) + 1.5, _rand(C, seed=43)
+    gamma[::3] *= -1                                              # negative scales: the sign test of act' matters
+    coef = _bn_reference(h, gamma, beta, 1e-5, 0.1, None, None)
+    dybuf = _rand(R, C + 8, seed=44)
+    dy = dybuf[:, 4:4 + C]                                        # strided incoming gradient
+    base = _rand(R, K + 4, seed=45)
+    res = []
+    for fuse in (True, False):
+        fused.FUSE_BN_BWD = fuse
+        out = base.clone()[:, :K] if accumulate else None
+        dW, dg, db, dinp = fused.bn_block_backward(dy, dy.stride(0), x, h, coef, training, gamma, 0.2, w, True,
+                                                   dinp_out=out, accumulate=accumulate)
+        res.append((dW, dg, db, dinp.clone()))
+    fused.FUSE_BN_BWD = True
+    for a, b in zip(*res):
+        assert rel_err(a, b) < 2e-5
