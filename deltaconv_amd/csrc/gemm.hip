@@ -273,17 +273,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
             __builtin_amdgcn_sched_group_barrier(0x008, NMF / NRD > 0 ? NMF / NRD : 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+        if (MORE) {                                                          // group 2: one LDS store of the next tile
+#pragma unroll                                                               // and one read of set 3 per couple of MFMAs
+            for (int i = 0; i < NST; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF / NST > 0 ? NMF / NST : 1, 0);
+            }
+        }
 #pragma unroll
-        for (int i = 0; i < NRD; ++i) {                                      // group 2 with the reads of set 3
+        for (int i = 0; i < NRD; ++i) {                                      // (reads not placed above)
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        if (MORE) {
-#pragma unroll
-            for (int i = 0; i < NST; ++i) {                                  // ... and the LDS stores of the next tile
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            }
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
         __syncthreads();   // tile `cur` is consumed (its last fragments are in registers), tile cur^1 is written
