@@ -508,10 +508,18 @@ int chunks_for(long M, int N, int K, int tile) {
 struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
 DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     DcTnPlan pl;
-    pl.bm = M > 64 ? 128 : 64;
-    pl.bn = N > 64 ? 128 : 64;
+    // r02r sweep (profiles/r02r_tn_sweep.txt): outputs below 64K elements run best on 64 x 64 tiles (more workgroups
+    // per slab, shorter epilogues) with ~768 workgroups, larger ones on 128 x 128 with ~576; at most 128 slabs
+    const bool small = (long)M * N < 65536;
+    pl.bm = (M > 64 && !small) ? 128 : 64;
+    pl.bn = (N > 64 && !small) ? 128 : 64;
+    if (const int t = dc_option(DC_OPT_TN_TILE)) {
+        pl.bm = (t == 1 || t == 2) ? 128 : 64;
+        pl.bn = (t == 1 || t == 4) ? 128 : 64;
+    }
     const long tiles = (long)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn);
-    long slabs = std::min<long>(128, std::max<long>(1, 512 / tiles));      // ~2 workgroups per CU, bounded partial traffic
+    long slabs = std::min<long>(128, std::max<long>(1, ((small ? 768 : 576) + tiles - 1) / tiles));
+    if (const int f = dc_option(DC_OPT_TN_SLABS)) slabs = f;
     long rps = (R + slabs - 1) / slabs;
     rps = std::max<long>((rps + BK - 1) / BK * BK, 4 * BK);
     pl.rows_per_slab = rps;

@@ -194,10 +194,11 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* partial = static_cast<float*>(workspace);
-    // direct-load kernel inside its measured window (multiples of 32, 16K..256K outputs); the LDS-staged kernel of
-    // gemm.hip for every other shape (any M, N, leading dimension)
-    const bool direct_ok = M % 32 == 0 && N % 32 == 0 && (long)M * N >= 16384 && (long)M * N <= 262144;
-    if (!direct_ok || dc_option(DC_OPT_TN_LDS)) {
+    // The LDS-staged kernel of gemm.hip (any M, N, leading dimension) is the product path: with the r02r tile / slab
+    // plan it matches or beats the direct-load kernel of round 1 on every measured shape.  That kernel stays
+    // reachable for A/B runs (option DC_OPT_TN_LDS = 2, multiples of 32 only).
+    const bool direct = dc_option(DC_OPT_TN_LDS) == 2 && M % 32 == 0 && N % 32 == 0;
+    if (!direct) {
         const int slabs = dc_tn_lds_launch(A, (long)lda, B, (long)ldb, (long)R, M, N, partial, s);
         const long mn2 = (long)M * N;
         hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn2, 64)), dim3(64 * RED_WAVES), 0, s, partial, slabs, mn2, N,

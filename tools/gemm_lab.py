@@ -28,13 +28,15 @@ def timeit(fn, iters=20, warm=3):
     torch.cuda.synchronize()
     g.replay()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
-    for _ in range(3):
+    best = 1e30                      # min over replays: filters clock ramps and neighbours on the box
+    for _ in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
         g.replay()
-    b.record()
-    b.synchronize()
-    return a.elapsed_time(b) * 1e3 / (3 * iters)
+        b.record()
+        b.synchronize()
+        best = min(best, a.elapsed_time(b) * 1e3 / iters)
+    return best
 
 
 FWD = [  # (label, M, N, K)
@@ -109,7 +111,7 @@ def main():
         ws = torch.empty((nb + 3) // 4, device=DEV)
         t_lib = timeit(lambda: torch.mm(a.t(), b, out=out))
         res = {}
-        for impl in (0, 1):
+        for impl in (2, 0):
             lib.raw("dc_set_option")(2, impl)
             res[impl] = timeit(lambda: lib.call("dc_gemm_tn", a, M, b, N, R, M, N, out, N, 0, ws, ws.numel() * 4))
             ref = a.double().t() @ b.double()
@@ -117,8 +119,8 @@ def main():
             assert err < 1e-4, (label, impl, err)
         lib.raw("dc_set_option")(2, 0)
         fl = 2.0 * R * M * N
-        print(f"tn {label + f' {R}x{M}x{N}':<30}{t_lib:10.1f}{res[0]:10.1f}{res[1]:10.1f}   TF/s {fl / t_lib / 1e6:6.1f} "
-              f"{fl / res[0] / 1e6:6.1f} {fl / res[1] / 1e6:6.1f}", flush=True)
+        print(f"tn {label + f' {R}x{M}x{N}':<30}{t_lib:10.1f}{res[2]:10.1f}{res[0]:10.1f}   TF/s {fl / t_lib / 1e6:6.1f} "
+              f"{fl / res[2] / 1e6:6.1f} {fl / res[0] / 1e6:6.1f}", flush=True)
 
 
 if __name__ == "__main__":
