@@ -109,6 +109,59 @@ __device__ __forceinline__ f32x4 bn_bwd_vec(const f32x4 dy, const f32x4 h, const
     return o;
 }
 
+// ---- instruction order of one K tile, as a compile-time list of sched_group_barrier (mask, count) groups.
+// Every group names an exact, non-zero count: a group that asks for more MFMAs than its fragment set holds takes
+// them from the next set, and an EMPTY group cuts the ordering chain (the edges run between consecutive groups).
+//   set-1 LDS reads | group 0: global loads of the next tile in its first slots | group 1: set-2 reads |
+//   group 2: set-3 reads in its first slots, the LDS stores of the next tile in its LAST slots (latest = most
+//   time for the loads to land)                                  masks: 0x008 MFMA, 0x020 VMEM read, 0x100 / 0x200 DS read / write
+template <int NMF, int NLD, int NRD, int NST, bool MORE, bool LOAD>
+struct SchedPlan {
+    static constexpr int MAXG = 1 + 9 * NMF + 3;
+    int mask[MAXG] = {}, cnt[MAXG] = {};
+    int len = 0;
+    constexpr void push(int m, int n) {
+        if (n > 0) { mask[len] = m; cnt[len] = n; ++len; }
+    }
+    static constexpr int share(int total, int slots, int i) {       // i-th of `slots` near-equal parts of `total`
+        return i < slots ? total / slots + (i < total % slots ? 1 : 0) : 0;
+    }
+    constexpr SchedPlan() {
+        constexpr int S0 = NLD < NMF ? NLD : NMF, S1 = NRD < NMF ? NRD : NMF, S2 = NST < NMF ? NST : NMF;
+        push(0x100, NRD);
+        if (LOAD) {
+            for (int i = 0; i < S0; ++i) { push(0x020, share(NLD, S0, i)); push(0x008, 1); }
+            push(0x008, NMF - S0);
+        } else {
+            push(0x008, NMF);
+        }
+        for (int i = 0; i < S1; ++i) { push(0x100, share(NRD, S1, i)); push(0x008, 1); }
+        push(0x008, NMF - S1);
+        for (int i = 0; i < NMF; ++i) {
+            if (MORE && i >= NMF - S2) push(0x200, share(NST, S2, i - (NMF - S2)));
+            push(0x100, share(NRD, S1, i));
+            push(0x008, 1);
+        }
+    }
+};
+template <int M, int N>
+__device__ __forceinline__ void sched_group() {
+    if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(M, N, 0);
+}
+template <class P, int... I>
+__device__ __forceinline__ void emit_sched(std::integer_sequence<int, I...>) {
+    constexpr P plan{};
+    (sched_group<plan.mask[I], plan.cnt[I]>(), ...);
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter (vmcnt(0)),
+// which would make every K tile wait for the global loads issued for the tiles AFTER the next one.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_sched_barrier(0);      // nothing is scheduled across (the MFMAs are not memory operations)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int BM, int BN, int AL, int BL, bool FAST, int EPI, int PRO = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workgroups per CU: <= 256 registers per lane
     constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
@@ -139,21 +192,28 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
-    f32x4 sa[A_IT], sb[B_IT];
+    // Staging registers global -> LDS.  Two sets (plain GEMM): tile kt+2 is requested while tile kt is multiplied and
+    // reaches LDS during tile kt+1, so a whole K tile of MFMAs (~2.6k cycles) covers the load latency before the first
+    // s_waitcnt (r02o counters: with one set the waves sat in waitcnt/barrier 12 % of their cycles, the library 4 %).
+    // One set where a second does not fit the 256-register budget (2 workgroups per CU) without spilling: the
+    // prologue variants (h tile + coefficients) and the 128 x 128 tile with a reduction-major B operand.
+    constexpr int STG = (PRO || (BM == 128 && BN == 128 && BL == B_KN)) ? 1 : 2;
+    f32x4 sa[STG][A_IT], sb[STG][B_IT];
     f32x4 sa2[PRO ? A_IT : 1], cf[5];          // prologue: h tile, per-column coefficients of this thread's 4 columns
     if (PRO && AL == A_KM) {                    // reduction-major A: the thread's columns never change
 #pragma unroll
         for (int q = 0; q < 5; ++q) cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, m0 + (tid % (BM / 4)) * 4, p.M);
     }
-    auto load_tiles = [&](long k0) {
+    auto load_tiles = [&](long k0, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + NT * it;
             if (AL == A_MK) {
-                sa[it] = gload4<FAST>(p.A, p.lda, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
+                sa[S][it] = gload4<FAST>(p.A, p.lda, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
                 if (PRO) sa2[it] = gload4<FAST>(p.A2, p.lda2, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
             } else {
-                sa[it] = gload4<FAST>(p.A, p.lda, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
+                sa[S][it] = gload4<FAST>(p.A, p.lda, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
                 if (PRO) sa2[it] = gload4<FAST>(p.A2, p.lda2, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
             }
         }
@@ -165,18 +225,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
         for (int it = 0; it < B_IT; ++it) {
             const int idx = tid + NT * it;
             if (BL == B_NK)
-                sb[it] = gload4<FAST>(p.B, p.ldb, n0 + (idx >> 3), p.N, k0 + (idx & 7) * 4, kend);
+                sb[S][it] = gload4<FAST>(p.B, p.ldb, n0 + (idx >> 3), p.N, k0 + (idx & 7) * 4, kend);
             else
-                sb[it] = gload4<FAST>(p.B, p.ldb, k0 + idx / (BN / 4), kend, n0 + (idx % (BN / 4)) * 4, p.N);
+                sb[S][it] = gload4<FAST>(p.B, p.ldb, k0 + idx / (BN / 4), kend, n0 + (idx % (BN / 4)) * 4, p.N);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
         float* a = As + buf * A_FL;
         float* b = Bs + buf * B_FL;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + NT * it;
-            const f32x4 va = PRO ? bn_bwd_vec(sa[it], sa2[it], cf, p.slope) : sa[it];
+            const f32x4 va = PRO ? bn_bwd_vec(sa[S][it], sa2[it], cf, p.slope) : sa[S][it];
             if (AL == A_MK)
                 *reinterpret_cast<f32x4*>(a + (idx >> 3) * LDK + (idx & 7) * 4) = va;
             else
@@ -186,9 +247,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
         for (int it = 0; it < B_IT; ++it) {
             const int idx = tid + NT * it;
             if (BL == B_NK)
-                *reinterpret_cast<f32x4*>(b + (idx >> 3) * LDK + (idx & 7) * 4) = sb[it];
+                *reinterpret_cast<f32x4*>(b + (idx >> 3) * LDK + (idx & 7) * 4) = sb[S][it];
             else
-                *reinterpret_cast<f32x4*>(b + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = sb[it];
+                *reinterpret_cast<f32x4*>(b + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = sb[S][it];
         }
     };
     // Fragments are double-buffered in registers and the loop is software-pipelined by hand: while the 4 k-steps of
@@ -233,9 +294,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
 
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
     if (p.phase && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(32);   // de-phase the two workgroups of a CU
-    load_tiles(kbeg);
-    store_tiles(0);
-    __syncthreads();
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, STG - 1>;
+    load_tiles(kbeg, S0{});
+    store_tiles(0, S0{});
+    if (STG == 2 && nk > 1) load_tiles(kbeg + BK, S1{});
+    lds_barrier();
     read_frags(0, 0, fa[0], fb[0]);
     // One K tile.  MORE: the next tile exists -- its global loads, LDS stores and first fragment reads are part of
     // the body.  The steady-state body is branch-free, so the whole tile is one scheduling region per side of the
@@ -246,53 +310,55 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
     constexpr int NST = A_IT + B_IT;                                         // LDS stores per tile
     constexpr int NLD = NST + (PRO ? A_IT + (AL == A_MK ? 5 : 0) : 0);       // global loads per tile
     constexpr int NRD = (AL == A_MK ? TM : 4 * TM) + (BL == B_NK ? TN : 4 * TN);   // LDS reads per fragment set
-    auto tile_body = [&](int kt, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
+    // par_tag: parity of kt (static: it selects the staging set); more_tag: tile kt+1 exists (its LDS stores and first
+    // fragment reads are part of the body); load_tag: tile kt+STG exists (its global loads are issued here)
+    auto tile_body = [&](int kt, auto par_tag, auto more_tag, auto load_tag) {
+        constexpr bool MORE = decltype(more_tag)::value, LOAD = decltype(load_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;
+        using SL = std::integral_constant<int, STG == 2 ? PAR : 0>;          // set the new loads land in
+        using SS = std::integral_constant<int, STG == 2 ? PAR ^ 1 : 0>;      // set holding tile kt+1
         const int cur = kt & 1;
-        if (MORE) load_tiles(kbeg + (long)(kt + 1) * BK);
+        if (LOAD) load_tiles(kbeg + (long)(kt + STG) * BK, SL{});
         read_frags(cur, 1, fa[1], fb[1]);
         mfma_group(fa[0], fb[0]);
         read_frags(cur, 2, fa[0], fb[0]);
         mfma_group(fa[1], fb[1]);
         read_frags(cur, 3, fa[1], fb[1]);
-        if (MORE) store_tiles(cur ^ 1);
+        if (MORE) store_tiles(cur ^ 1, SS{});
         mfma_group(fa[0], fb[0]);
-        // desired order of the region above
-        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);                 // fragment set 1
-        if (MORE) {
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // one global load ...
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF / NLD > 0 ? NMF / NLD : 1, 0);   // ... per few MFMAs
-            }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);                 // rest of group 0
-#pragma unroll
-        for (int i = 0; i < NRD; ++i) {                                      // group 1 with the reads of set 2
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF / NRD > 0 ? NMF / NRD : 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
-        if (MORE) {                                                          // group 2: one LDS store of the next tile
-#pragma unroll                                                               // and one read of set 3 per couple of MFMAs
-            for (int i = 0; i < NST; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NMF / NST > 0 ? NMF / NST : 1, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NRD; ++i) {                                      // (reads not placed above)
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
-        __syncthreads();   // tile `cur` is consumed (its last fragments are in registers), tile cur^1 is written
+        // desired order of the region above (SchedPlan: exact counts, no empty groups)
+        emit_sched<SchedPlan<NMF, NLD, NRD, NST, MORE, LOAD>>(std::make_integer_sequence<int, SchedPlan<NMF, NLD, NRD, NST, MORE, LOAD>::MAXG>{});
+        lds_barrier();     // tile `cur` is consumed (its last fragments are in registers), tile cur^1 is written
         if (MORE) read_frags(cur ^ 1, 0, fa[0], fb[0]);
         mfma_group(fa[1], fb[1]);
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) tile_body(kt, std::true_type{});
-    tile_body(nk - 1, std::false_type{});
+    {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        using T = std::true_type;
+        using F = std::false_type;
+        if (STG == 2) {
+            int kt = 0;
+            for (; kt + 3 < nk; kt += 2) {          // steady state, two tiles per trip (static staging sets)
+                tile_body(kt, P0{}, T{}, T{});
+                tile_body(kt + 1, P1{}, T{}, T{});
+            }
+            const int rem = nk - kt;                // 1 .. 3 tiles left, kt even
+            if (rem == 3) {
+                tile_body(kt, P0{}, T{}, T{});
+                tile_body(kt + 1, P1{}, T{}, F{});
+                tile_body(kt + 2, P0{}, F{}, F{});
+            } else if (rem == 2) {
+                tile_body(kt, P0{}, T{}, F{});
+                tile_body(kt + 1, P1{}, F{}, F{});
+            } else {
+                tile_body(kt, P0{}, F{}, F{});
+            }
+        } else {
+            for (int kt = 0; kt + 1 < nk; ++kt) tile_body(kt, P0{}, T{}, T{});
+            tile_body(nk - 1, P0{}, F{}, F{});
+        }
+    }
     __syncthreads();                  // (the staging below reuses the operand buffers)
 
     // ---- statistics epilogue (rows beyond M hold zeros and add nothing)
@@ -509,7 +575,8 @@ struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
 DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     DcTnPlan pl;
     // r02r sweep (profiles/r02r_tn_sweep.txt): outputs below 64K elements run best on 64 x 64 tiles (more workgroups
-    // per slab, shorter epilogues) with ~768 workgroups, larger ones on 128 x 128 with ~576; at most 128 slabs
+    // per slab, shorter epilogues; 4 fit a CU) with ~768 workgroups; larger ones on 128 x 128 tiles with at most 512
+    // workgroups = ONE resident wave of 2 per CU (576 cost +25 %: a second, nearly empty round); <= 128 slabs
     const bool small = (long)M * N < 65536;
     pl.bm = (M > 64 && !small) ? 128 : 64;
     pl.bn = (N > 64 && !small) ? 128 : 64;
@@ -518,7 +585,7 @@ DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
         pl.bn = (t == 1 || t == 4) ? 128 : 64;
     }
     const long tiles = (long)((M + pl.bm - 1) / pl.bm) * ((N + pl.bn - 1) / pl.bn);
-    long slabs = std::min<long>(128, std::max<long>(1, ((small ? 768 : 576) + tiles - 1) / tiles));
+    long slabs = std::min<long>(128, std::max<long>(1, (small ? 768 : 512) / tiles));
     if (const int f = dc_option(DC_OPT_TN_SLABS)) slabs = f;
     long rps = (R + slabs - 1) / slabs;
     rps = std::max<long>((rps + BK - 1) / BK * BK, 4 * BK);

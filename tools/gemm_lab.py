@@ -6,6 +6,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import deltaconv_amd._lib as _L
+if os.environ.get("DC_AB_LIB"):            # A/B runs: another build of the library (tools/ab/, not tracked)
+    _L.LIB_PATH = os.path.abspath(os.environ["DC_AB_LIB"])
 from deltaconv_amd._lib import lib
 
 DEV = "cuda"
