@@ -88,6 +88,16 @@ __device__ __forceinline__ f32x4 gload4(const float* base, long ld, long row, lo
     return v;
 }
 
+// Fast-path load: buffer_load through a descriptor built from the wave-uniform tile origin (SGPRs), a wave-uniform
+// byte offset (soff: which of the thread's loads) and ONE 32-bit per-thread byte offset per operand (voff) -- no 64-bit
+// per-load address registers and no VALU address arithmetic in the K loop.  num_records = 2^31: no range clipping.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 uload4(const float* ubase, unsigned voff, unsigned soff = 0) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ubase), 0, 0x7FFFFFFF, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
 template <bool FAST>
 __device__ __forceinline__ f32x4 cload4(const float* base, long col, long ncols) {      // 4 per-column coefficients
     if (FAST) return *reinterpret_cast<const f32x4*>(base + col);
@@ -204,8 +214,35 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
 #pragma unroll
         for (int q = 0; q < 5; ++q) cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, m0 + (tid % (BM / 4)) * 4, p.M);
     }
+    // fast path: per-thread byte offsets inside a K tile (one per operand) and the row step between two loads
+    const unsigned voa = AL == A_MK ? (unsigned)(((tid >> 3) * p.lda + (tid & 7) * 4) * 4)
+                                    : (unsigned)(((tid / (BM / 4)) * p.lda + (tid % (BM / 4)) * 4) * 4);
+    const unsigned voa2 = AL == A_MK ? (unsigned)(((tid >> 3) * p.lda2 + (tid & 7) * 4) * 4)
+                                     : (unsigned)(((tid / (BM / 4)) * p.lda2 + (tid % (BM / 4)) * 4) * 4);
+    const unsigned vob = BL == B_NK ? (unsigned)(((tid >> 3) * p.ldb + (tid & 7) * 4) * 4)
+                                    : (unsigned)(((tid / (BN / 4)) * p.ldb + (tid % (BN / 4)) * 4) * 4);
+    constexpr int A_STEP = AL == A_MK ? NT / 8 : NT / (BM / 4);      // rows between the loads `it` and `it + 1`
+    constexpr int B_STEP = BL == B_NK ? NT / 8 : NT / (BN / 4);
     auto load_tiles = [&](long k0, auto slot_tag) {
         constexpr int S = decltype(slot_tag)::value;
+        if (FAST) {
+            const float* ua = AL == A_MK ? p.A + m0 * p.lda + k0 : p.A + k0 * p.lda + m0;          // wave-uniform
+            const float* ub = BL == B_NK ? p.B + (long)n0 * p.ldb + k0 : p.B + k0 * p.ldb + n0;
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) sa[S][it] = uload4(ua, voa, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda);
+            if (PRO) {
+                const float* ua2 = AL == A_MK ? p.A2 + m0 * p.lda2 + k0 : p.A2 + k0 * p.lda2 + m0;
+#pragma unroll
+                for (int it = 0; it < A_IT; ++it) sa2[it] = uload4(ua2, voa2, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda2);
+                if (AL == A_MK) {
+#pragma unroll
+                    for (int q = 0; q < 5; ++q) cf[q] = uload4(p.pc + (long)q * p.pcn + k0, (unsigned)((tid & 7) * 16));
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) sb[S][it] = uload4(ub, vob, (unsigned)(it * B_STEP * 4) * (unsigned)p.ldb);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int idx = tid + NT * it;
@@ -541,10 +578,11 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.A2 = nullptr; p.lda2 = 0; p.pc = nullptr; p.pcn = 0; p.slope = 0.f;
     // fast path: no guards at all (every hot shape of the reference models)
     bool fast = M % t.bm == 0 && N % t.bn == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
+                lda < (1 << 21) && ldb < (1 << 21) &&      // 32-bit in-tile byte offsets (uload4)
                 al16p(A) && al16p(B) && al16p(C);
     if (pro) {
         p.A2 = pro->h; p.lda2 = pro->ldh; p.pc = pro->coefs; p.pcn = pro->ncoef; p.slope = pro->slope;
-        fast = fast && pro->ldh % 4 == 0 && al16p(pro->h) && al16p(pro->coefs) && pro->ncoef % 4 == 0;
+        fast = fast && pro->ldh % 4 == 0 && pro->ldh < (1 << 21) && al16p(pro->h) && al16p(pro->coefs) && pro->ncoef % 4 == 0;
         launch_fast<A_MK, B_KN, EPI_NONE, 1>(p, t, tiles_m, 1, fast, s);
     } else if (bl == B_NK) {
         if (epi == EPI_COLSTATS) launch_fast<A_MK, B_NK, EPI_COLSTATS>(p, t, tiles_m, 1, fast, s);
@@ -610,9 +648,10 @@ int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R,
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
     p.A2 = h; p.lda2 = ldh; p.pc = coefs; p.pcn = M; p.slope = slope;
     bool fast = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && lda % 4 == 0 &&
+                lda < (1 << 21) && ldb < (1 << 21) &&
                 ldb % 4 == 0 && N % 4 == 0 && al16p(A) && al16p(B) && al16p(partial);
     if (h) {
-        fast = fast && ldh % 4 == 0 && al16p(h) && al16p(coefs);
+        fast = fast && ldh % 4 == 0 && ldh < (1 << 21) && al16p(h) && al16p(coefs);
         launch_fast<A_KM, B_KN, EPI_NONE, 1>(p, t, tiles_m, pl.slabs, fast, s);
     } else {
         launch_fast<A_KM, B_KN, EPI_NONE>(p, t, tiles_m, pl.slabs, fast, s);
