@@ -119,51 +119,6 @@ __device__ __forceinline__ f32x4 bn_bwd_vec(const f32x4 dy, const f32x4 h, const
     return o;
 }
 
-// ---- instruction order of one K tile, as a compile-time list of sched_group_barrier (mask, count) groups.
-// Every group names an exact, non-zero count: a group that asks for more MFMAs than its fragment set holds takes
-// them from the next set, and an EMPTY group cuts the ordering chain (the edges run between consecutive groups).
-//   set-1 LDS reads | group 0: global loads of the next tile in its first slots | group 1: set-2 reads |
-//   group 2: set-3 reads in its first slots, the LDS stores of the next tile in its LAST slots (latest = most
-//   time for the loads to land)                                  masks: 0x008 MFMA, 0x020 VMEM read, 0x100 / 0x200 DS read / write
-template <int NMF, int NLD, int NRD, int NST, bool MORE, bool LOAD>
-struct SchedPlan {
-    static constexpr int MAXG = 1 + 9 * NMF + 3;
-    int mask[MAXG] = {}, cnt[MAXG] = {};
-    int len = 0;
-    constexpr void push(int m, int n) {
-        if (n > 0) { mask[len] = m; cnt[len] = n; ++len; }
-    }
-    static constexpr int share(int total, int slots, int i) {       // i-th of `slots` near-equal parts of `total`
-        return i < slots ? total / slots + (i < total % slots ? 1 : 0) : 0;
-    }
-    constexpr SchedPlan() {
-        constexpr int S0 = NLD < NMF ? NLD : NMF, S1 = NRD < NMF ? NRD : NMF, S2 = NST < NMF ? NST : NMF;
-        push(0x100, NRD);
-        if (LOAD) {
-            for (int i = 0; i < S0; ++i) { push(0x020, share(NLD, S0, i)); push(0x008, 1); }
-            push(0x008, NMF - S0);
-        } else {
-            push(0x008, NMF);
-        }
-        for (int i = 0; i < S1; ++i) { push(0x100, share(NRD, S1, i)); push(0x008, 1); }
-        push(0x008, NMF - S1);
-        for (int i = 0; i < NMF; ++i) {
-            if (MORE && i >= NMF - S2) push(0x200, share(NST, S2, i - (NMF - S2)));
-            push(0x100, share(NRD, S1, i));
-            push(0x008, 1);
-        }
-    }
-};
-template <int M, int N>
-__device__ __forceinline__ void sched_group() {
-    if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(M, N, 0);
-}
-template <class P, int... I>
-__device__ __forceinline__ void emit_sched(std::integer_sequence<int, I...>) {
-    constexpr P plan{};
-    (sched_group<plan.mask[I], plan.cnt[I]>(), ...);
-}
-
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also drains the vector-memory counter (vmcnt(0)),
 // which would make every K tile wait for the global loads issued for the tiles AFTER the next one.
 __device__ __forceinline__ void lds_barrier() {
@@ -223,94 +178,88 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
                                     : (unsigned)(((tid / (BN / 4)) * p.ldb + (tid % (BN / 4)) * 4) * 4);
     constexpr int A_STEP = AL == A_MK ? NT / 8 : NT / (BM / 4);      // rows between the loads `it` and `it + 1`
     constexpr int B_STEP = BL == B_NK ? NT / 8 : NT / (BN / 4);
-    auto load_tiles = [&](long k0, auto slot_tag) {
+    // The K tile moves in PIECES (one 16-byte load / LDS store per thread, one fragment register per lane), so the
+    // loop body below can place every memory instruction at a chosen MFMA.
+    constexpr int NST = A_IT + B_IT;                                         // LDS stores per tile
+    constexpr int NLD = NST + (PRO ? A_IT + (AL == A_MK ? 5 : 0) : 0);       // global loads per tile
+    constexpr int NRP = TM + TN;                                             // fragment reads per set
+    // global load n of the K tile at k0 -> staging set S.  n: A pieces, B pieces, then (prologue) h pieces, coefficients
+    auto load_piece = [&](int n, long k0, auto slot_tag) {
         constexpr int S = decltype(slot_tag)::value;
-        if (FAST) {
-            const float* ua = AL == A_MK ? p.A + m0 * p.lda + k0 : p.A + k0 * p.lda + m0;          // wave-uniform
-            const float* ub = BL == B_NK ? p.B + (long)n0 * p.ldb + k0 : p.B + k0 * p.ldb + n0;
-#pragma unroll
-            for (int it = 0; it < A_IT; ++it) sa[S][it] = uload4(ua, voa, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda);
-            if (PRO) {
-                const float* ua2 = AL == A_MK ? p.A2 + m0 * p.lda2 + k0 : p.A2 + k0 * p.lda2 + m0;
-#pragma unroll
-                for (int it = 0; it < A_IT; ++it) sa2[it] = uload4(ua2, voa2, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda2);
-                if (AL == A_MK) {
-#pragma unroll
-                    for (int q = 0; q < 5; ++q) cf[q] = uload4(p.pc + (long)q * p.pcn + k0, (unsigned)((tid & 7) * 16));
-                }
-            }
-#pragma unroll
-            for (int it = 0; it < B_IT; ++it) sb[S][it] = uload4(ub, vob, (unsigned)(it * B_STEP * 4) * (unsigned)p.ldb);
-            return;
-        }
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int idx = tid + NT * it;
-            if (AL == A_MK) {
+        if (n < A_IT) {
+            const int it = n, idx = tid + NT * it;
+            if (FAST) {
+                const float* ua = AL == A_MK ? p.A + m0 * p.lda + k0 : p.A + k0 * p.lda + m0;      // wave-uniform
+                sa[S][it] = uload4(ua, voa, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda);
+            } else if (AL == A_MK) {
                 sa[S][it] = gload4<FAST>(p.A, p.lda, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
-                if (PRO) sa2[it] = gload4<FAST>(p.A2, p.lda2, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
             } else {
                 sa[S][it] = gload4<FAST>(p.A, p.lda, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
-                if (PRO) sa2[it] = gload4<FAST>(p.A2, p.lda2, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
             }
-        }
-        if (PRO && AL == A_MK) {                // K-contiguous A: the columns are the reduction index of this tile
-#pragma unroll
-            for (int q = 0; q < 5; ++q) cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, k0 + (tid & 7) * 4, kend);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int idx = tid + NT * it;
-            if (BL == B_NK)
+        } else if (n < NST) {
+            const int it = n - A_IT, idx = tid + NT * it;
+            if (FAST) {
+                const float* ub = BL == B_NK ? p.B + (long)n0 * p.ldb + k0 : p.B + k0 * p.ldb + n0;
+                sb[S][it] = uload4(ub, vob, (unsigned)(it * B_STEP * 4) * (unsigned)p.ldb);
+            } else if (BL == B_NK) {
                 sb[S][it] = gload4<FAST>(p.B, p.ldb, n0 + (idx >> 3), p.N, k0 + (idx & 7) * 4, kend);
-            else
+            } else {
                 sb[S][it] = gload4<FAST>(p.B, p.ldb, k0 + idx / (BN / 4), kend, n0 + (idx % (BN / 4)) * 4, p.N);
+            }
+        } else if (PRO && n < NST + A_IT) {
+            const int it = n - NST, idx = tid + NT * it;
+            if (FAST) {
+                const float* ua2 = AL == A_MK ? p.A2 + m0 * p.lda2 + k0 : p.A2 + k0 * p.lda2 + m0;
+                sa2[it] = uload4(ua2, voa2, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda2);
+            } else if (AL == A_MK) {
+                sa2[it] = gload4<FAST>(p.A2, p.lda2, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
+            } else {
+                sa2[it] = gload4<FAST>(p.A2, p.lda2, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
+            }
+        } else if (PRO && AL == A_MK) {         // K-contiguous A: the columns are the reduction index of this tile
+            const int q = n - NST - A_IT;
+            if (FAST) cf[q] = uload4(p.pc + (long)q * p.pcn + k0, (unsigned)((tid & 7) * 16));
+            else cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, k0 + (tid & 7) * 4, kend);
         }
     };
-    auto store_tiles = [&](int buf, auto slot_tag) {
+    // LDS store n (A pieces, then B pieces) of staging set S -> buffer buf
+    auto store_piece = [&](int n, int buf, auto slot_tag) {
         constexpr int S = decltype(slot_tag)::value;
-        float* a = As + buf * A_FL;
-        float* b = Bs + buf * B_FL;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int idx = tid + NT * it;
+        if (n < A_IT) {
+            const int it = n, idx = tid + NT * it;
+            float* a = As + buf * A_FL;
             const f32x4 va = PRO ? bn_bwd_vec(sa[S][it], sa2[it], cf, p.slope) : sa[S][it];
             if (AL == A_MK)
                 *reinterpret_cast<f32x4*>(a + (idx >> 3) * LDK + (idx & 7) * 4) = va;
             else
                 *reinterpret_cast<f32x4*>(a + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = va;
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int idx = tid + NT * it;
+        } else {
+            const int it = n - A_IT, idx = tid + NT * it;
+            float* b = Bs + buf * B_FL;
             if (BL == B_NK)
                 *reinterpret_cast<f32x4*>(b + (idx >> 3) * LDK + (idx & 7) * 4) = sb[S][it];
             else
                 *reinterpret_cast<f32x4*>(b + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = sb[S][it];
         }
     };
-    // Fragments are double-buffered in registers and the loop is software-pipelined by hand: while the 4 k-steps of
-    // fragment set j are multiplied, set j+1 is already being read from LDS; the next K tile goes global -> registers
-    // at the top of the iteration, registers -> LDS behind the third MFMA group, and the workgroup barrier sits before
-    // the LAST group, whose operands are in registers by then -- so the first fragments of the next tile are fetched
-    // under that group's MFMAs and no ds_read latency, ds_write burst or barrier skew is exposed between tiles.
+    // Fragments: lane (li, lh) holds k = 8 j + 4 lh + t (t = 0..3) of fragment set j for its row / column -- one
+    // ds_read_b128 on a K-contiguous tile, four ds_read_b32 on a reduction-major one.  Two register sets.
     f32x4 fa[2][TM], fb[2][TN];
-    auto read_frags = [&](int buf, int j, f32x4 (&ra)[TM], f32x4 (&rb)[TN]) {
-        const float* a = AL == A_MK ? As + buf * A_FL + (wm0 + li) * LDK + 4 * lh
-                                    : As + buf * A_FL + (4 * lh) * BM + wm0 + li;
-        const float* b = BL == B_NK ? Bs + buf * B_FL + (wn0 + li) * LDK + 4 * lh
-                                    : Bs + buf * B_FL + (4 * lh) * BN + wn0 + li;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
+    auto read_piece = [&](int n, int buf, int j, f32x4 (&ra)[TM], f32x4 (&rb)[TN]) {
+        if (n < TM) {
+            const int i = n;
+            const float* a = AL == A_MK ? As + buf * A_FL + (wm0 + li) * LDK + 4 * lh
+                                        : As + buf * A_FL + (4 * lh) * BM + wm0 + li;
             if (AL == A_MK) {
                 ra[i] = *reinterpret_cast<const f32x4*>(a + i * 32 * LDK + 8 * j);
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) ra[i][t] = a[(8 * j + t) * BM + i * 32];
             }
-        }
-#pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
+        } else {
+            const int jn = n - TM;
+            const float* b = BL == B_NK ? Bs + buf * B_FL + (wn0 + li) * LDK + 4 * lh
+                                        : Bs + buf * B_FL + (4 * lh) * BN + wn0 + li;
             if (BL == B_NK) {
                 rb[jn] = *reinterpret_cast<const f32x4*>(b + jn * 32 * LDK + 8 * j);
             } else {
@@ -319,55 +268,100 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
             }
         }
     };
-    auto mfma_group = [&](const f32x4 (&ra)[TM], const f32x4 (&rb)[TN]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][t], rb[jn][t], acc[i][jn], 0, 0, 0);
+    // MFMA s of a fragment set: k-step t = s / (TM TN), accumulator (i, jn) = the rest.  The first TM TN MFMAs touch
+    // every fragment register of the set once.
+    constexpr int NMF = 4 * TM * TN, LEAD = TM * TN, NFR = NMF - LEAD;
+    auto mfma_one = [&](int s, const f32x4 (&ra)[TM], const f32x4 (&rb)[TN]) {
+        const int t = s / LEAD, i = (s % LEAD) / TN, jn = s % TN;
+        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][t], rb[jn][t], acc[i][jn], 0, 0, 0);
     };
 
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
     if (p.phase && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(32);   // de-phase the two workgroups of a CU
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, STG - 1>;
-    load_tiles(kbeg, S0{});
-    store_tiles(0, S0{});
-    if (STG == 2 && nk > 1) load_tiles(kbeg + BK, S1{});
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) load_piece(n, kbeg, S0{});
+#pragma unroll
+    for (int n = 0; n < NST; ++n) store_piece(n, 0, S0{});
+    if (STG == 2 && nk > 1) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + BK, S1{});
+    }
     lds_barrier();
-    read_frags(0, 0, fa[0], fb[0]);
-    // One K tile.  MORE: the next tile exists -- its global loads, LDS stores and first fragment reads are part of
-    // the body.  The steady-state body is branch-free, so the whole tile is one scheduling region per side of the
-    // barrier and the sched_group_barrier sequence below spreads the memory instructions between the MFMAs (one
-    // vector-memory load, LDS read or LDS write per couple of MFMAs) instead of leaving them in clumps during which
-    // the matrix pipe idles (r02d ablation: the clumped loads + stores cost 20 % of the kernel).
-    constexpr int NMF = 4 * TM * TN;                                         // MFMAs per fragment set
-    constexpr int NST = A_IT + B_IT;                                         // LDS stores per tile
-    constexpr int NLD = NST + (PRO ? A_IT + (AL == A_MK ? 5 : 0) : 0);       // global loads per tile
-    constexpr int NRD = (AL == A_MK ? TM : 4 * TM) + (BL == B_NK ? TN : 4 * TN);   // LDS reads per fragment set
-    // par_tag: parity of kt (static: it selects the staging set); more_tag: tile kt+1 exists (its LDS stores and first
-    // fragment reads are part of the body); load_tag: tile kt+STG exists (its global loads are issued here)
+#pragma unroll
+    for (int n = 0; n < NRP; ++n) read_piece(n, 0, 0, fa[0], fb[0]);
+    // One K tile = 4 fragment sets of NMF MFMAs each; the instruction order is written out and pinned (a
+    // sched_barrier after every MFMA: the scheduler otherwise re-sorts the reads and MFMAs by its own latency model):
+    //   set 0: [LEAD MFMAs] [all reads of set 1] then one MFMA per slot, the global loads of tile kt+STG in the first slots
+    //   set 1: [LEAD MFMAs] reads of set 2 in the first slots
+    //   set 2: [LEAD MFMAs] reads of set 3 in the first slots, the LDS stores of tile kt+1 in the LAST slots
+    //   barrier;  [reads of set 0 of tile kt+1]  set 3
+    // Every set starts with the LEAD MFMAs that touch all of its fragment registers: the waits on its reads (issued a
+    // whole set earlier) then sit in front of anything newly queued on the in-order LDS counter.  The stores come as
+    // late as possible (most time for the loads to land), the barrier before the LAST set, whose operands are in
+    // registers by then.  par_tag: parity of kt (static: it selects the staging set); more_tag: tile kt+1 exists;
+    // load_tag: tile kt+STG exists.
+    constexpr int CL = (NLD + NFR - 1) / NFR, CR = (NRP + NFR - 1) / NFR, CW = (NST + NFR - 1) / NFR;   // pieces per slot
+    constexpr int WSLOTS = (NST + CW - 1) / CW;                              // slots that carry stores
     auto tile_body = [&](int kt, auto par_tag, auto more_tag, auto load_tag) {
         constexpr bool MORE = decltype(more_tag)::value, LOAD = decltype(load_tag)::value;
         constexpr int PAR = decltype(par_tag)::value;
         using SL = std::integral_constant<int, STG == 2 ? PAR : 0>;          // set the new loads land in
         using SS = std::integral_constant<int, STG == 2 ? PAR ^ 1 : 0>;      // set holding tile kt+1
         const int cur = kt & 1;
-        if (LOAD) load_tiles(kbeg + (long)(kt + STG) * BK, SL{});
-        read_frags(cur, 1, fa[1], fb[1]);
-        mfma_group(fa[0], fb[0]);
-        read_frags(cur, 2, fa[0], fb[0]);
-        mfma_group(fa[1], fb[1]);
-        read_frags(cur, 3, fa[1], fb[1]);
-        if (MORE) store_tiles(cur ^ 1, SS{});
-        mfma_group(fa[0], fb[0]);
-        // desired order of the region above (SchedPlan: exact counts, no empty groups)
-        emit_sched<SchedPlan<NMF, NLD, NRD, NST, MORE, LOAD>>(std::make_integer_sequence<int, SchedPlan<NMF, NLD, NRD, NST, MORE, LOAD>::MAXG>{});
+        const long knext = kbeg + (long)(kt + STG) * BK;
+#pragma unroll
+        for (int s = 0; s < NMF; ++s) {                                      // ---- set 0
+            if (s == LEAD) {
+#pragma unroll
+                for (int n = 0; n < NRP; ++n) read_piece(n, cur, 1, fa[1], fb[1]);
+            }
+            if (LOAD && s >= LEAD) {
+#pragma unroll
+                for (int c = 0; c < CL; ++c)
+                    if ((s - LEAD) * CL + c < NLD) load_piece((s - LEAD) * CL + c, knext, SL{});
+            }
+            mfma_one(s, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < NMF; ++s) {                                      // ---- set 1
+            if (s >= LEAD) {
+#pragma unroll
+                for (int c = 0; c < CR; ++c)
+                    if ((s - LEAD) * CR + c < NRP) read_piece((s - LEAD) * CR + c, cur, 2, fa[0], fb[0]);
+            }
+            mfma_one(s, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < NMF; ++s) {                                      // ---- set 2
+            if (s >= LEAD) {
+#pragma unroll
+                for (int c = 0; c < CR; ++c)
+                    if ((s - LEAD) * CR + c < NRP) read_piece((s - LEAD) * CR + c, cur, 3, fa[1], fb[1]);
+                if (MORE && s - LEAD >= NFR - WSLOTS) {
+#pragma unroll
+                    for (int c = 0; c < CW; ++c)
+                        if ((s - LEAD - (NFR - WSLOTS)) * CW + c < NST)
+                            store_piece((s - LEAD - (NFR - WSLOTS)) * CW + c, cur ^ 1, SS{});
+                }
+            }
+            mfma_one(s, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         lds_barrier();     // tile `cur` is consumed (its last fragments are in registers), tile cur^1 is written
-        if (MORE) read_frags(cur ^ 1, 0, fa[0], fb[0]);
-        mfma_group(fa[1], fb[1]);
+        if (MORE) {
+#pragma unroll
+            for (int n = 0; n < NRP; ++n) read_piece(n, cur ^ 1, 0, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < NMF; ++s) {                                      // ---- set 3
+            mfma_one(s, fa[1], fb[1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     {
         using P0 = std::integral_constant<int, 0>;
