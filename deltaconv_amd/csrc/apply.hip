@@ -87,6 +87,24 @@ DC_T_ENTRY(dc_apply_grad_T, GradT, C, C)
 DC_T_ENTRY(dc_apply_div_T, DivT, C, C)
 DC_T_ENTRY(dc_apply_hodge_T, HodgeT, C, 2 * C)
 
+// out[n, C] = a (+ b) + grad^T dy: the transposed gradient apply with the accumulation of d x' folded in
+DC_EXPORT int dc_apply_grad_T_sum(const float* GT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k,
+                                  const float* dy, int32_t C, int64_t ldy, const float* a, int64_t lda, const float* b,
+                                  int64_t ldb, float* out, int64_t ldo, void* stream) {
+    if (int rc = check_common("dc_apply_grad_T_sum", GT, tptr, dy, out, n, k, C)) return rc;
+    DC_REQUIRE(tedge && a, "dc_apply_grad_T_sum: null pointer");
+    DC_REQUIRE(ldy >= C && lda >= C && ldo >= C && (!b || ldb >= C), "dc_apply_grad_T_sum: leading dimension smaller than the row");
+    if (n == 0 || C == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long ldb_ = b ? (long)ldb : (long)lda;
+    if (pick_v(C, {(long)ldy, (long)lda, ldb_, (long)ldo}, {dy, a, b ? b : a, out}) == 4)
+        launch_T<4>(n, C, GT, tptr, tedge, k, GradTSum<4>{dy, (long)ldy, a, (long)lda, b, (long)ldb, out, (long)ldo, C}, s);
+    else
+        launch_T<1>(n, C, GT, tptr, tedge, k, GradTSum<1>{dy, (long)ldy, a, (long)lda, b, (long)ldb, out, (long)ldo, C}, s);
+    DC_CHECK_LAUNCH("dc_apply_grad_T_sum");
+    return DC_OK;
+}
+
 DC_EXPORT int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, const int32_t* tedge, int32_t n,
                                        int32_t k, const float* dout, int32_t C, int64_t ldo, const float* v,
                                        int64_t ldv, float* dv, int64_t lddv, int32_t accumulate, void* stream) {

@@ -5,6 +5,7 @@
 //   sorted ascending so every transposed sum has a fixed order (bit-reproducible, no fp atomics).
 // Neighbours never leave their cloud, so the in-edges of cloud b total exactly N_b*k and the scan
 // base of cloud b is cloud_ptr[b]*k: the scan is local to a cloud (one block per cloud).
+#include <algorithm>
 #include "common.h"
 #include "ell_math.h"
 
@@ -53,17 +54,29 @@ __global__ void csc_fill_kernel(const int* __restrict__ nbr, long ne, int* __res
     if (e < ne) tedge[atomicAdd(cursor + nbr[e], 1)] = (int)e;
 }
 
-// Order every column by edge id without a serial sort: edge e counts the entries of its column that
-// are smaller (O(in-degree) reads, all E edges in parallel) and writes itself at that rank.
-__global__ void csc_rank_kernel(const int* __restrict__ nbr, long ne, const int* __restrict__ tptr,
-                                const int* __restrict__ unordered, int* __restrict__ tedge) {
-    const long e = (long)blockIdx.x * TPB + threadIdx.x;
-    if (e >= ne) return;
-    const int j = nbr[e];
-    const int lo = tptr[j], hi = tptr[j + 1];
-    int rank = 0;
-    for (int p = lo; p < hi; ++p) rank += unordered[p] < (int)e;
-    tedge[lo + rank] = (int)e;
+// Order every column by edge id without a serial sort: the rank of an entry = the number of smaller entries of its
+// column.  One wavefront per column: the lanes hold the column (64 entries at a time), every entry is broadcast
+// once (v_readlane) and compared by all lanes -- the column is read from memory once, not once per entry.
+__global__ __launch_bounds__(TPB) void csc_rank_kernel(int num_points, const int* __restrict__ tptr,
+                                                       const int* __restrict__ unordered, int* __restrict__ tedge) {
+    const int lane = threadIdx.x & 63;
+    // (readfirstlane: the wave id IS wave-uniform; this lets the compiler keep the column bounds in scalar registers)
+    const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (long)TPB + threadIdx.x) >> 6));
+    const int nwaves = (int)((gridDim.x * (long)TPB) >> 6);
+    for (int j = wave; j < num_points; j += nwaves) {
+        const int lo = tptr[j], deg = tptr[j + 1] - lo;
+        for (int ba = 0; ba < deg; ba += 64) {
+            const bool valid = ba + lane < deg;
+            const int mine = valid ? unordered[lo + ba + lane] : 0x7fffffff;
+            int rank = 0;
+            for (int bb = 0; bb < deg; bb += 64) {
+                const int other = bb == ba ? mine : (bb + lane < deg ? unordered[lo + bb + lane] : 0x7fffffff);
+                const int cnt = min(64, deg - bb);
+                for (int q = 0; q < cnt; ++q) rank += __builtin_amdgcn_readlane(other, q) < mine;
+            }
+            if (valid) tedge[lo + rank] = mine;
+        }
+    }
 }
 __global__ void csc_permute_kernel(const float2* __restrict__ coef, const int* __restrict__ tedge, long ne,
                                    float2* __restrict__ coefT) {
@@ -107,7 +120,8 @@ DC_EXPORT int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t
     hipLaunchKernelGGL(csc_scan_kernel, dim3(num_clouds), dim3(TPB), 0, s, cloud_ptr, k, num_clouds, cnt, tptr);
     int* unordered = cnt + num_points;
     hipLaunchKernelGGL(csc_fill_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, cnt, unordered);
-    hipLaunchKernelGGL(csc_rank_kernel, dim3(dc_cdiv(ne, TPB)), dim3(TPB), 0, s, nbr, ne, tptr, unordered, tedge);
+    hipLaunchKernelGGL(csc_rank_kernel, dim3(std::min<long>(dc_cdiv((long)num_points * 64, TPB), 256 * 16)), dim3(TPB), 0, s,
+                       num_points, tptr, unordered, tedge);
     DC_CHECK_LAUNCH("dc_csc_build");
     return DC_OK;
 }

@@ -229,6 +229,30 @@ struct GradT {
     DC_HD void finish(long j, int c0) { vout<V>(dx + j * ldx + c0, acc, accumulate); }
 };
 
+// grad^T with the gradient accumulation folded in: out[j, c] = a[j, c] (+ b[j, c]) + sum_e ...  (a, b = the gradients
+// of x' that reach a layer from its other consumers; the destination is a fresh tensor: no add pass, no clone)
+template <int V>
+struct GradTSum {
+    const float* dy; long ldy; const float* a; long lda; const float* b; long ldb; float* out; long ldo; int C;
+    Vec<V> acc;
+    DC_HD void init() { acc = vzero<V>(); }
+    DC_HD void step(long i, int, G2 g, int c0) {
+        vfma<V>(acc, g.a, vload<V>(dy + (2 * i) * ldy + c0));
+        vfma<V>(acc, g.b, vload<V>(dy + (2 * i + 1) * ldy + c0));
+    }
+    DC_HD void finish(long j, int c0) {
+        Vec<V> o = vload<V>(a + j * lda + c0);
+        if (b) {
+            const Vec<V> ob = vload<V>(b + j * ldb + c0);
+#pragma unroll
+            for (int q = 0; q < V; ++q) o.v[q] += ob.v[q];      // (a + b) + grad^T dy: the order of the separate passes
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) o.v[q] += acc.v[q];
+        vstore<V>(out + j * ldo + c0, o);
+    }
+};
+
 // div^T : dv[2j+a, c] (+)= sum_e D[e,a] * dy[i, c]
 template <int V>
 struct DivT {

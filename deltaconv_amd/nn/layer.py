@@ -263,8 +263,14 @@ class DeltaConvLayerFn(torch.autograd.Function):
         need_x, need_v, need_xmax = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gm_list, gs_list, gv_list = [None] * nm, [None] * ns, [None] * nv        # per block (dW, dgamma, dbeta)
 
-        # d x' arrives from the next layer (dx_new) and / or from the concatenated embedding input (dx_dup)
-        if dx_new is not None and dx_dup is not None:
+        # d x' arrives from the next layer (dx_new) and / or from the concatenated embedding input (dx_dup); with a
+        # vector stream, `grad^T d(grad @ x')` is a third term: all of them are summed by ONE kernel into a fresh
+        # tensor (dc_apply_grad_T_sum, below) -- no add pass and no clone of autograd's buffers
+        fold_sum = bool(nv and dv_new is not None and (dx_new is not None or dx_dup is not None))
+        if fold_sum:
+            dxn = lddx = None
+            private = True
+        elif dx_new is not None and dx_dup is not None:
             (dxn, lddx), private = _rows(dx_new + dx_dup), True
         elif dx_new is not None or dx_dup is not None:
             (dxn, lddx), private = _rows(dx_new if dx_new is not None else dx_dup), False
@@ -294,9 +300,16 @@ class DeltaConvLayerFn(torch.autograd.Function):
                     ldd = dcur.stride(0)
                 gv_list[j] = (dW, dg, db)
             # grad^T of the `grad @ x'` block accumulates into d x'
-            if not private:                    # accumulated into below: never touch autograd's buffer
-                dxn, lddx = (dxn.clone() if dxn.is_contiguous() else dxn.contiguous()), co
-            call("dc_apply_grad_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, dxn, lddx, 1)
+            if fold_sum:
+                ga, lda_ = _rows(dx_new if dx_new is not None else dx_dup)
+                gb, ldb_ = _rows(dx_dup) if (dx_new is not None and dx_dup is not None) else (None, 0)
+                dxn, lddx = torch.empty(n, co, **f32), co
+                call("dc_apply_grad_T_sum", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, ga, lda_, gb,
+                     ldb_, dxn, lddx)
+            else:
+                if not private:                # accumulated into below: never touch autograd's buffer
+                    dxn, lddx = (dxn.clone() if dxn.is_contiguous() else dxn.contiguous()), co
+                call("dc_apply_grad_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, dxn, lddx, 1)
 
         # ---- s_mlp blocks (residual: d x_max = d x')
         d_xcat = None

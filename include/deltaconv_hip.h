@@ -94,6 +94,12 @@ int dc_apply_hodge(const float* G, const int32_t* nbr, int32_t n, int32_t k, con
  * destination (gradient accumulation without a separate add). */
 int dc_apply_grad_T(const float* GT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
                     int32_t C, int64_t ldy, float* dx, int64_t ldx, int32_t accumulate, void* stream);
+/* out[n, C] = a (+ b when non-null) + grad^T dy: dc_apply_grad_T with the accumulation of the other gradients of x'
+ * (autograd's adds for a tensor with several consumers: the next layer and the concatenated embedding input,
+ * deltanet_base.py:82-87, deltanet_classification.py:42) folded into the store; `out` is a fresh tensor. */
+int dc_apply_grad_T_sum(const float* GT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k,
+                        const float* dy, int32_t C, int64_t ldy, const float* a, int64_t lda, const float* b,
+                        int64_t ldb, float* out, int64_t ldo, void* stream);
 int dc_apply_div_T(const float* DT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dy,
                    int32_t C, int64_t ldy, float* dv, int64_t ldv, int32_t accumulate, void* stream);
 int dc_apply_hodge_T(const float* GT, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dh,

@@ -172,6 +172,28 @@ def test_csc():
     assert torch.equal(t2[0].cpu(), tptr) and torch.equal(t2[1].cpu(), tedge)      # run-to-run identical
 
 
+def test_csc_high_in_degree():
+    """130 exact copies of one point: the tie rule sends all of them to the lowest-index copies, whose in-degree then
+    exceeds a wavefront (the rank kernel walks such a column in chunks of 64)."""
+    from deltaconv_amd.geometry import Graph
+    torch.manual_seed(5)
+    pos = torch.randn(600, 3)
+    pos[40:170] = pos[40]
+    batch = torch.zeros(600, dtype=torch.long)
+    gr = Graph.knn(pos.to(DEV), 20, batch.to(DEV))
+    tptr, tedge = (t.cpu() for t in gr.csc())
+    n, k = gr.n, gr.k
+    deg = tptr[1:] - tptr[:-1]
+    assert int(deg.max()) > 64
+    flat = gr.nbr.cpu().reshape(-1).long()
+    assert torch.equal(torch.bincount(flat, minlength=n).to(torch.int32), deg)
+    assert torch.equal(torch.sort(tedge).values, torch.arange(n * k, dtype=torch.int32))
+    assert bool((flat[tedge.long()] == torch.arange(n).repeat_interleave(deg.long())).all())
+    for j in torch.nonzero(deg > 64).flatten().tolist():
+        col = tedge[int(tptr[j]):int(tptr[j + 1])]
+        assert bool((col[1:] > col[:-1]).all())
+
+
 # ---------------------------------------------------------------------------------- applies
 @pytest.fixture(scope="module")
 def ops():
@@ -235,6 +257,28 @@ def test_max_ties_first_slot(ops):
     out, arg = _ops._KnnMax.apply(h.to(DEV), ops["graph"])
     o2, a2 = h[ops["nbr"]].max(dim=1)
     assert torch.equal(out.cpu(), o2) and torch.equal(arg.cpu().long(), a2)
+
+
+@pytest.mark.parametrize("C", [3, 64, 128])
+@pytest.mark.parametrize("two", [False, True])
+def test_grad_T_sum_matches_separate_passes(ops, C, two):
+    """dc_apply_grad_T_sum (gradient accumulation folded into the transposed apply) == (a + b) + grad^T dy of the
+    separate passes, bit for bit (same summation order), with strided operands."""
+    from deltaconv_amd._lib import lib
+    n, gr, grad = ops["n"], ops["graph"], ops["grad"]
+    tptr, tedge = gr.csc()
+    torch.manual_seed(C + two)
+    k = gr.k
+    wide = torch.randn(2 * n, 2 * C + 8, device=DEV)
+    dy = wide[:, 8:8 + C]                                   # a column block of a wider tensor (like d v_cat)
+    a = torch.randn(n, C, device=DEV)
+    b = torch.randn(n, C + 4, device=DEV)[:, :C] if two else None
+    ref = (a + b) if two else a.clone()
+    lib.call("dc_apply_grad_T", grad.coefT(), tptr, tedge, n, k, dy, C, dy.stride(0), ref, C, 1)
+    out = torch.empty(n, C, device=DEV)
+    lib.call("dc_apply_grad_T_sum", grad.coefT(), tptr, tedge, n, k, dy, C, dy.stride(0), a, C, b,
+             b.stride(0) if two else 0, out, C)
+    assert torch.equal(out, ref)
 
 
 def test_applies_deterministic(ops):
