@@ -71,23 +71,6 @@ struct GemmP {
     double* part; int chunks, stat_cols;   // statistics partials [2][stat_cols][chunks]
 };
 
-template <bool FAST>
-__device__ __forceinline__ f32x4 gload4(const float* base, long ld, long row, long nrows, long col, long ncols) {
-    if (FAST) return *reinterpret_cast<const f32x4*>(base + row * ld + col);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < nrows && col < ncols) {
-        const float* p = base + row * ld + col;
-        if (col + 3 < ncols && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-            v = *reinterpret_cast<const f32x4*>(p);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (col + e < ncols) v[e] = p[e];
-        }
-    }
-    return v;
-}
-
 // Fast-path load: buffer_load through a descriptor built from the wave-uniform tile origin (SGPRs), a wave-uniform
 // byte offset (soff: which of the thread's loads) and ONE 32-bit per-thread byte offset per operand (voff) -- no 64-bit
 // per-load address registers and no VALU address arithmetic in the K loop.  num_records = 2^31: no range clipping.
@@ -98,14 +81,29 @@ __device__ __forceinline__ f32x4 uload4(const float* ubase, unsigned voff, unsig
     return __builtin_bit_cast(f32x4, v);
 }
 
-template <bool FAST>
-__device__ __forceinline__ f32x4 cload4(const float* base, long col, long ncols) {      // 4 per-column coefficients
-    if (FAST) return *reinterpret_cast<const f32x4*>(base + col);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+// Guarded forms (ragged shapes): the SAME loads with the per-thread offset of an out-of-range element replaced by
+// 2^31 -- beyond num_records, so the hardware range check returns 0.0 without a memory access and the K loop stays
+// branch-free.  Vector form: all four elements in or out together (extents and leading dimensions multiples of 4,
+// 16-byte aligned bases); scalar form: four dword loads with one validity each (anything else).
+constexpr unsigned POISON = 0x80000000u;
+__device__ __forceinline__ f32x4 gload4v(const float* ubase, unsigned voff, unsigned soff, bool ok) {
+    return uload4(ubase, ok ? voff : POISON, soff);
+}
+__device__ __forceinline__ f32x4 gload4s(const float* ubase, unsigned voff, unsigned soff, bool ok_row, long col, long ncols) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ubase), 0, 0x7FFFFFFF, 0x00020000);
+    f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-        if (col + e < ncols) v[e] = base[col + e];
+        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                   r, (int)((ok_row && col + e < ncols) ? voff + 4u * e : POISON), (int)soff, 0));
     return v;
+}
+// one operand piece in any mode: MODE 0 = no guards, 1 = guarded vector, 2 = guarded scalar
+template <int MODE>
+__device__ __forceinline__ f32x4 pload4(const float* ubase, unsigned voff, unsigned soff, bool ok_row, long col, long ncols) {
+    if (MODE == 0) return uload4(ubase, voff, soff);
+    if (MODE == 1) return gload4v(ubase, voff, soff, ok_row && col < ncols);
+    return gload4s(ubase, voff, soff, ok_row, col, ncols);
 }
 
 __device__ __forceinline__ f32x4 bn_bwd_vec(const f32x4 dy, const f32x4 h, const f32x4 (&cf)[5], float slope) {
@@ -127,8 +125,12 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BM, int BN, int AL, int BL, bool FAST, int EPI, int PRO = 0>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workgroups per CU: <= 256 registers per lane
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
+    constexpr bool FAST = MODE == 0;               // no guards anywhere (loads, statistics, stores)
+    // guarded modes per operand: 1 = 16-byte loads, 2 = dword loads.  MODE 1: both vector, 2: both scalar, 3: A vector /
+    // B scalar, 4: A scalar / B vector
+    constexpr int MA = MODE == 0 ? 0 : (MODE == 1 || MODE == 3 ? 1 : 2), MB = MODE == 0 ? 0 : (MODE == 1 || MODE == 4 ? 1 : 2);       // 2 workgroups per CU: <= 256 registers per lane
     constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;      // 32 x 32 accumulators per wave
     constexpr int A_FL = AL == A_MK ? BM * LDK : BK * BM;
@@ -167,7 +169,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
     f32x4 sa2[PRO ? A_IT : 1], cf[5];          // prologue: h tile, per-column coefficients of this thread's 4 columns
     if (PRO && AL == A_KM) {                    // reduction-major A: the thread's columns never change
 #pragma unroll
-        for (int q = 0; q < 5; ++q) cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, m0 + (tid % (BM / 4)) * 4, p.M);
+        for (int q = 0; q < 5; ++q)
+            cf[q] = pload4<MODE == 0 ? 0 : 2>(p.pc + (long)q * p.pcn + m0, (unsigned)((tid % (BM / 4)) * 16), 0, true,
+                                              m0 + (tid % (BM / 4)) * 4, p.M);
     }
     // fast path: per-thread byte offsets inside a K tile (one per operand) and the row step between two loads
     const unsigned voa = AL == A_MK ? (unsigned)(((tid >> 3) * p.lda + (tid & 7) * 4) * 4)
@@ -186,40 +190,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {       // 2 workg
     // global load n of the K tile at k0 -> staging set S.  n: A pieces, B pieces, then (prologue) h pieces, coefficients
     auto load_piece = [&](int n, long k0, auto slot_tag) {
         constexpr int S = decltype(slot_tag)::value;
-        if (n < A_IT) {
-            const int it = n, idx = tid + NT * it;
-            if (FAST) {
-                const float* ua = AL == A_MK ? p.A + m0 * p.lda + k0 : p.A + k0 * p.lda + m0;      // wave-uniform
-                sa[S][it] = uload4(ua, voa, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda);
-            } else if (AL == A_MK) {
-                sa[S][it] = gload4<FAST>(p.A, p.lda, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
-            } else {
-                sa[S][it] = gload4<FAST>(p.A, p.lda, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
-            }
+        // (row, col) of the piece's first element; validity only matters in the guarded modes
+        if (n < A_IT || (PRO && n >= NST && n < NST + A_IT)) {
+            const bool second = n >= NST;                      // the prologue's h tile: same shape / layout as A
+            const int it = second ? n - NST : n, idx = tid + NT * it;
+            const float* base = second ? p.A2 : p.A;
+            const long ld = second ? p.lda2 : p.lda;
+            const float* ua = AL == A_MK ? base + m0 * ld + k0 : base + k0 * ld + m0;              // wave-uniform
+            const unsigned soff = (unsigned)(it * A_STEP * 4) * (unsigned)ld;
+            const long row = AL == A_MK ? m0 + (idx >> 3) : k0 + idx / (BM / 4);
+            const long col = AL == A_MK ? k0 + (idx & 7) * 4 : m0 + (idx % (BM / 4)) * 4;
+            const f32x4 v = pload4<MA>(ua, second ? voa2 : voa, soff, row < (AL == A_MK ? p.M : kend), col,
+                                         AL == A_MK ? kend : p.M);
+            if (second) sa2[it] = v;
+            else sa[S][it] = v;
         } else if (n < NST) {
             const int it = n - A_IT, idx = tid + NT * it;
-            if (FAST) {
-                const float* ub = BL == B_NK ? p.B + (long)n0 * p.ldb + k0 : p.B + k0 * p.ldb + n0;
-                sb[S][it] = uload4(ub, vob, (unsigned)(it * B_STEP * 4) * (unsigned)p.ldb);
-            } else if (BL == B_NK) {
-                sb[S][it] = gload4<FAST>(p.B, p.ldb, n0 + (idx >> 3), p.N, k0 + (idx & 7) * 4, kend);
-            } else {
-                sb[S][it] = gload4<FAST>(p.B, p.ldb, k0 + idx / (BN / 4), kend, n0 + (idx % (BN / 4)) * 4, p.N);
-            }
-        } else if (PRO && n < NST + A_IT) {
-            const int it = n - NST, idx = tid + NT * it;
-            if (FAST) {
-                const float* ua2 = AL == A_MK ? p.A2 + m0 * p.lda2 + k0 : p.A2 + k0 * p.lda2 + m0;
-                sa2[it] = uload4(ua2, voa2, (unsigned)(it * A_STEP * 4) * (unsigned)p.lda2);
-            } else if (AL == A_MK) {
-                sa2[it] = gload4<FAST>(p.A2, p.lda2, m0 + (idx >> 3), p.M, k0 + (idx & 7) * 4, kend);
-            } else {
-                sa2[it] = gload4<FAST>(p.A2, p.lda2, k0 + idx / (BM / 4), kend, m0 + (idx % (BM / 4)) * 4, p.M);
-            }
+            const float* ub = BL == B_NK ? p.B + (long)n0 * p.ldb + k0 : p.B + k0 * p.ldb + n0;
+            const long row = BL == B_NK ? n0 + (idx >> 3) : k0 + idx / (BN / 4);
+            const long col = BL == B_NK ? k0 + (idx & 7) * 4 : n0 + (idx % (BN / 4)) * 4;
+            sb[S][it] = pload4<MB>(ub, vob, (unsigned)(it * B_STEP * 4) * (unsigned)p.ldb,
+                                     row < (BL == B_NK ? (long)p.N : kend), col, BL == B_NK ? kend : (long)p.N);
         } else if (PRO && AL == A_MK) {         // K-contiguous A: the columns are the reduction index of this tile
             const int q = n - NST - A_IT;
-            if (FAST) cf[q] = uload4(p.pc + (long)q * p.pcn + k0, (unsigned)((tid & 7) * 16));
-            else cf[q] = cload4<FAST>(p.pc + (long)q * p.pcn, k0 + (tid & 7) * 4, kend);
+            cf[q] = pload4<MODE == 0 ? 0 : 2>(p.pc + (long)q * p.pcn + k0, (unsigned)((tid & 7) * 16), 0, true,
+                                              k0 + (tid & 7) * 4, kend);
         }
     };
     // LDS store n (A pieces, then B pieces) of staging set S -> buffer buf
@@ -522,31 +517,42 @@ size_t lds_bytes(int bm, int bn, int al, int bl) {
     return std::max(2 * (a + b), (size_t)bm * bn) * sizeof(float);      // operand ring | output staging
 }
 
-template <int BM, int BN, int AL, int BL, bool FAST, int EPI, int PRO>
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO>
 void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
     static bool configured = false;
     const size_t lds = lds_bytes(BM, BN, AL, BL);
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, FAST, EPI, PRO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, FAST, EPI, PRO>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
                        dim3(NT), lds, s, p);
 }
 
-template <int AL, int BL, bool FAST, int EPI, int PRO>
+template <int AL, int BL, int MODE, int EPI, int PRO>
 void launch_tile(const GemmP& p, Tile t, long tiles_m, int slabs, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
-    else if (t.bm == 128) launch_one<128, 64, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
-    else if (t.bn == 128) launch_one<64, 128, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
-    else launch_one<64, 64, AL, BL, FAST, EPI, PRO>(p, tiles_m, slabs, s);
+    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
+    else if (t.bm == 128) launch_one<128, 64, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
+    else if (t.bn == 128) launch_one<64, 128, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
+    else launch_one<64, 64, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
 }
 
 template <int AL, int BL, int EPI, int PRO = 0>
-void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, bool fast, hipStream_t s) {
-    if (fast) launch_tile<AL, BL, true, EPI, PRO>(p, t, tiles_m, slabs, s);
-    else launch_tile<AL, BL, false, EPI, PRO>(p, t, tiles_m, slabs, s);
+void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, int mode, hipStream_t s) {
+    if (mode == 0) launch_tile<AL, BL, 0, EPI, PRO>(p, t, tiles_m, slabs, s);
+    else if (mode == 1) launch_tile<AL, BL, 1, EPI, PRO>(p, t, tiles_m, slabs, s);
+    else if (mode == 2) launch_tile<AL, BL, 2, EPI, PRO>(p, t, tiles_m, slabs, s);
+    else if (mode == 3) launch_tile<AL, BL, 3, EPI, PRO>(p, t, tiles_m, slabs, s);
+    else launch_tile<AL, BL, 4, EPI, PRO>(p, t, tiles_m, slabs, s);
+}
+
+// operand-load mode: 0 = no guards (whole tiles, aligned: every hot shape of the reference models); otherwise per
+// operand guarded 16-byte loads (ragged tile edges, but its extents / leading dimension multiples of 4 and an aligned
+// base) or guarded dword loads (anything): 1 = both vector, 2 = both scalar, 3 = A vector / B scalar, 4 = A scalar / B vector
+int load_mode(bool whole_tiles, bool a4, bool b4) {
+    if (whole_tiles && a4 && b4) return 0;
+    return a4 && b4 ? 1 : (a4 ? 3 : (b4 ? 4 : 2));
 }
 
 bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -570,21 +576,26 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
     p.A2 = nullptr; p.lda2 = 0; p.pc = nullptr; p.pcn = 0; p.slope = 0.f;
-    // fast path: no guards at all (every hot shape of the reference models)
-    bool fast = M % t.bm == 0 && N % t.bn == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 &&
-                lda < (1 << 21) && ldb < (1 << 21) &&      // 32-bit in-tile byte offsets (uload4)
-                al16p(A) && al16p(B) && al16p(C);
+    if (lda >= (1 << 21) || ldb >= (1 << 21) || (pro && pro->ldh >= (1 << 21))) {     // 32-bit in-tile byte offsets
+        dc_set_error("%s: leading dimension above 2^21 elements", name);
+        return DC_ERR_ARG;
+    }
+    const bool whole = M % t.bm == 0 && N % t.bn == 0 && K % BK == 0 && ldc % 4 == 0 && al16p(C);
+    bool a4 = K % 4 == 0 && lda % 4 == 0 && al16p(A);                       // 4-vectors run along K
+    const bool b4 = (bl == B_NK ? K % 4 == 0 : N % 4 == 0) && ldb % 4 == 0 && al16p(B);
     if (pro) {
         p.A2 = pro->h; p.lda2 = pro->ldh; p.pc = pro->coefs; p.pcn = pro->ncoef; p.slope = pro->slope;
-        fast = fast && pro->ldh % 4 == 0 && pro->ldh < (1 << 21) && al16p(pro->h) && al16p(pro->coefs) && pro->ncoef % 4 == 0;
+        a4 = a4 && pro->ldh % 4 == 0 && al16p(pro->h);
+        const int fast = load_mode(whole && al16p(pro->coefs) && pro->ncoef % 4 == 0, a4, b4);
         launch_fast<A_MK, B_KN, EPI_NONE, 1>(p, t, tiles_m, 1, fast, s);
     } else if (bl == B_NK) {
+        const int fast = load_mode(whole, a4, b4);
         if (epi == EPI_COLSTATS) launch_fast<A_MK, B_NK, EPI_COLSTATS>(p, t, tiles_m, 1, fast, s);
         else if (epi == EPI_VNSTATS) launch_fast<A_MK, B_NK, EPI_VNSTATS>(p, t, tiles_m, 1, fast, s);
         else if (epi == EPI_VNSTATS0) launch_fast<A_MK, B_NK, EPI_VNSTATS0>(p, t, tiles_m, 1, fast, s);
         else launch_fast<A_MK, B_NK, EPI_NONE>(p, t, tiles_m, 1, fast, s);
     } else {
-        launch_fast<A_MK, B_KN, EPI_NONE>(p, t, tiles_m, 1, fast, s);
+        launch_fast<A_MK, B_KN, EPI_NONE>(p, t, tiles_m, 1, load_mode(whole, a4, b4), s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -612,6 +623,8 @@ DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     const bool small = (long)M * N < 65536;
     pl.bm = (M > 64 && !small) ? 128 : 64;
     pl.bn = (N > 64 && !small) ? 128 : 64;
+    if (M % pl.bm != 0 && M % 64 == 0) pl.bm = 64;        // a tile that divides the output runs the unguarded loads
+    if (N % pl.bn != 0 && N % 64 == 0) pl.bn = 64;        // (e.g. N = 448 = 7 x 64)
     if (const int t = dc_option(DC_OPT_TN_TILE)) {
         pl.bm = (t == 1 || t == 2) ? 128 : 64;
         pl.bn = (t == 1 || t == 4) ? 128 : 64;
@@ -641,14 +654,16 @@ int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R,
     p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
     p.A2 = h; p.lda2 = ldh; p.pc = coefs; p.pcn = M; p.slope = slope;
-    bool fast = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && lda % 4 == 0 &&
-                lda < (1 << 21) && ldb < (1 << 21) &&
-                ldb % 4 == 0 && N % 4 == 0 && al16p(A) && al16p(B) && al16p(partial);
+    if (lda >= (1 << 21) || ldb >= (1 << 21) || ldh >= (1 << 21)) return -1;      // 32-bit in-tile byte offsets
+    const bool whole = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && N % 4 == 0 &&
+                       al16p(partial);
+    bool a4 = M % 4 == 0 && lda % 4 == 0 && al16p(A);                       // reduction-major: 4-vectors run along M / N
+    const bool b4 = N % 4 == 0 && ldb % 4 == 0 && al16p(B);
     if (h) {
-        fast = fast && ldh % 4 == 0 && ldh < (1 << 21) && al16p(h) && al16p(coefs);
-        launch_fast<A_KM, B_KN, EPI_NONE, 1>(p, t, tiles_m, pl.slabs, fast, s);
+        a4 = a4 && ldh % 4 == 0 && al16p(h);
+        launch_fast<A_KM, B_KN, EPI_NONE, 1>(p, t, tiles_m, pl.slabs, load_mode(whole && al16p(coefs), a4, b4), s);
     } else {
-        launch_fast<A_KM, B_KN, EPI_NONE>(p, t, tiles_m, pl.slabs, fast, s);
+        launch_fast<A_KM, B_KN, EPI_NONE>(p, t, tiles_m, pl.slabs, load_mode(whole, a4, b4), s);
     }
     return pl.slabs;
 }

@@ -188,6 +188,7 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     DC_REQUIRE(A && B && C, "dc_gemm_tn: null pointer");
     DC_REQUIRE(R >= 1 && M >= 1 && N >= 1, "dc_gemm_tn: bad size");
     DC_REQUIRE(lda >= M && ldb >= N && ldc >= N, "dc_gemm_tn: leading dimension smaller than the row");
+    DC_REQUIRE(lda < (1 << 21) && ldb < (1 << 21), "dc_gemm_tn: leading dimension above 2^21 elements");
     if (!workspace || workspace_bytes < dc_gemm_tn_workspace_bytes(R, M, N)) {
         dc_set_error("dc_gemm_tn: workspace too small");
         return DC_ERR_WORKSPACE;
@@ -232,6 +233,8 @@ DC_EXPORT int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const 
     DC_REQUIRE(dy && h && coefs && X && dW, "dc_linear_bn_backward_weight: null pointer");
     DC_REQUIRE(R >= 1 && N >= 1 && K >= 1 && lddy >= N && ldh >= N && ldx >= K && lddw >= K,
                "dc_linear_bn_backward_weight: bad size");
+    DC_REQUIRE(lddy < (1 << 21) && ldh < (1 << 21) && ldx < (1 << 21),
+               "dc_linear_bn_backward_weight: leading dimension above 2^21 elements");
     if (!workspace || workspace_bytes < dc_gemm_tn_workspace_bytes(R, N, K)) {
         dc_set_error("dc_linear_bn_backward_weight: workspace too small");
         return DC_ERR_WORKSPACE;

@@ -243,7 +243,8 @@ def test_fused_layer_matches_composed(centralized, vector, ci, co, train, depth)
 
 @pytest.mark.parametrize("R,M,N", [(32768, 64, 64), (32768, 256, 128), (65536, 128, 192), (65536, 256, 256),
                                    (32768, 256, 512), (10000, 96, 32), (8193, 32, 160),
-                                   (32768, 128, 70), (9000, 64, 12), (4097, 64, 3), (65536, 70, 128), (33, 5, 7)])
+                                   (32768, 128, 70), (9000, 64, 12), (4097, 64, 3), (65536, 70, 128), (33, 5, 7), (8192, 256, 448),
+                                   (20480, 50, 128)])
 def test_mfma_gemm_tn(R, M, N):
     """Hand-written fp32-MFMA tall-skinny weight-gradient GEMM vs fp64 matmul (exact fp32 fma chain:
     error of the fp32 class, ~1e-7 * sum|a b|), strided operands (column blocks of concat buffers),
