@@ -117,7 +117,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
                        "v_mfma_f32_32x32x2, LDS-staged)",
                 us=round(te * 1e6, 1), achieved=round(2.0 * Me * Ne * Ke / te / 1e12, 1), peak=157.3, unit="TFLOP/s",
                 frac=round(2.0 * Me * Ne * Ke / te / 1e12 / 157.3, 3),
-                weight_gradient=dict(kernel=f"gemm_tn_kernel<2,2> + reduce (dW = dY^T X, {R}x{M}x{N})",
+                weight_gradient=dict(kernel=f"gemm_kernel<128,128, A_KM, B_KN> over row slabs + ordered reduce (dW = dY^T X, {R}x{M}x{N})",
                                      us=round(tg * 1e6, 1), achieved=round(2.0 * R * M * N / tg / 1e12, 1),
                                      frac=round(2.0 * R * M * N / tg / 1e12 / 157.3, 3)))
     head = fam["div_curl_norm"]
