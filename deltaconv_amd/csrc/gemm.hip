@@ -61,8 +61,6 @@ struct GemmP {
     long M; int N; long K;
     int tiles_n, remap, accumulate;
     long k_per_slab, slab_stride;          // split reduction: blockIdx.y = slab, C += slab * slab_stride
-    int phase;                             // experiment: delay every other resident workgroup by half a K tile
-    int ablate;                            // (unused)
     // BatchNorm-backward prologue (PRO): the A operand is dh = bn_act_backward(dy, h), formed while staging:
     //   dz = dy * (c_sc h + c_sh > 0 ? 1 : slope);   dh = c_g dz + c_a h + c_b     (dc_bn_act_backward_reduce)
     const float* A2; long lda2;            // h, same shape / layout as A (= dy)
@@ -272,7 +270,6 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     };
 
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
-    if (p.phase && ((blockIdx.x >> 8) & 1)) __builtin_amdgcn_s_sleep(32);   // de-phase the two workgroups of a CU
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, STG - 1>;
 #pragma unroll
@@ -572,8 +569,6 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.remap = dc_option(DC_OPT_XCD_REMAP);
     p.accumulate = accumulate;
     p.k_per_slab = K; p.slab_stride = 0;
-    p.phase = dc_option(DC_OPT_GEMM_PHASE);
-    p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
     p.A2 = nullptr; p.lda2 = 0; p.pc = nullptr; p.pcn = 0; p.slope = 0.f;
     if (lda >= (1 << 21) || ldb >= (1 << 21) || (pro && pro->ldh >= (1 << 21))) {     // 32-bit in-tile byte offsets
@@ -650,8 +645,6 @@ int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R,
     p.remap = 0;                       // tiles x slabs: every workgroup streams its own rows, nothing to co-locate
     p.accumulate = 0;
     p.k_per_slab = pl.rows_per_slab; p.slab_stride = (long)M * N;
-    p.phase = dc_option(DC_OPT_GEMM_PHASE);
-    p.ablate = dc_option(DC_OPT_GEMM_ABLATE);
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
     p.A2 = h; p.lda2 = ldh; p.pc = coefs; p.pcn = M; p.slope = slope;
     if (lda >= (1 << 21) || ldb >= (1 << 21) || ldh >= (1 << 21)) return -1;      // 32-bit in-tile byte offsets

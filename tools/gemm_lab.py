@@ -65,9 +65,6 @@ TN = [  # dW[M,N] = dY[R,M]^T X[R,N]
 
 def main():
     torch.manual_seed(0)
-    if len(sys.argv) > 1:
-        lib.raw("dc_set_option")(3, int(sys.argv[1]))       # GEMM phase-offset experiment
-        print("phase option", sys.argv[1])
     from deltaconv_amd.tuning import enable_tuned_gemms
     enable_tuned_gemms()           # the library column = the shipped per-shape tuned solutions (what r01 ran)
     print(f"{'shape':<34}{'library':>10}" + "".join(f"{TILES[t]:>10}" for t in TILES) + "   best TF/s (lib TF/s)")
