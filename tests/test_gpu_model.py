@@ -164,6 +164,53 @@ def test_model_step_vs_oracle(B, N, k):
     assert worst_hip < 3 * worst_ref + 1e-3
 
 
+def test_training_trajectory_vs_oracle():
+    """Five SGD steps (momentum / weight decay of train_modelnet.py:67; a tenth of its learning rate, so that fp32
+    rounding noise is not amplified into O(1) weight differences by the chaotic early steps -- at lr = 0.1 the
+    reference's own fp32 run ends 2.0 away from its fp64 run; a new batch every step) from identical weights: the loss
+    trajectory and the weights after the last step, HIP path vs the oracle in fp64 ("truth"), with the oracle in fp32
+    (= the reference's numerics) as the yardstick: BatchNorm running statistics, momentum buffers and the weight decay
+    all take part, so an error in any update rule compounds over the steps."""
+    k, steps = 20, 5
+    torch.manual_seed(1)
+    ref32 = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=k).train())
+    ref64 = _no_dropout(oracle.models.DeltaNetClassification(3, 40, num_neighbors=k).double().train())
+    ref64.load_state_dict(ref32.state_dict())
+    model = _model("cls", dict(in_channels=3, num_classes=40), k, 1e-3)
+    model.load_state_dict(ref32.state_dict())
+    model = _no_dropout(model.to(DEV).train())
+    mk = lambda m: torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    o32, o64, od = mk(ref32), mk(ref64), mk(model)
+    losses = []
+    for i in range(steps):
+        b = synthetic_batch(4, 512, seed=60 + i)
+        b64 = Batch(b.pos.double(), b.batch, b.norm.double(), None, b.y)
+        row = []
+        for m, o, bb in ((ref64, o64, b64), (ref32, o32, b), (model, od, b.to(DEV))):
+            o.zero_grad()
+            loss = oracle.loss.calc_loss(m(bb), bb.y)
+            loss.backward()
+            o.step()
+            row.append(float(loss.detach()))
+        losses.append(row)
+    l64, l32, lhip = (torch.tensor([r[j] for r in losses], dtype=torch.float64) for j in range(3))
+    e_ref, e_hip = float((l32 - l64).abs().max()), float((lhip - l64).abs().max())
+    print(f"loss trajectory {lhip.tolist()}: hip-vs-f64 {e_hip:.2e}  oracle32-vs-f64 {e_ref:.2e}")
+    assert e_hip < 3 * e_ref + 2e-3 * float(l64.abs().max())
+    worst_hip = worst_ref = 0.0
+    for (n1, p1), (n2, p2), (n3, p3) in zip(model.state_dict().items(), ref32.state_dict().items(),
+                                            ref64.state_dict().items()):
+        assert n1 == n2 == n3
+        if not p3.dtype.is_floating_point:
+            assert int(p1) == int(p3), n1                    # num_batches_tracked
+            continue
+        scale = max(float(p3.abs().max()), 1e-3)
+        worst_hip = max(worst_hip, float((p1.cpu().double() - p3).abs().max()) / scale)
+        worst_ref = max(worst_ref, float((p2.double() - p3).abs().max()) / scale)
+    print(f"weights / buffers after {steps} steps: hip-vs-f64 {worst_hip:.2e}  oracle32-vs-f64 {worst_ref:.2e}")
+    assert worst_hip < 3 * worst_ref + 2e-3
+
+
 def test_eval_mode_and_determinism():
     b = synthetic_batch(2, 512, seed=41).to(DEV)
     model = _model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).eval()
