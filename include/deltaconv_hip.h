@@ -34,7 +34,9 @@ extern "C" {
 
 int32_t dc_version(void);
 const char* dc_last_error(void);
-/* Experiment switch for A/B measurements.  key 0: XCD-aware block remap (default 1). */
+/* Experiment switches for A/B measurements (product defaults: all 0 except key 0).  key 0: XCD-aware block remap
+ * (default 1); 1: edge-at-a-time max-aggregation backward; 2: value 2 = weight gradients through the round-1
+ * direct-load kernel; 5 / 6: force the weight-gradient tile (1..4) / slab count (lab sweeps). */
 int dc_set_option(int32_t key, int32_t value);
 
 /* ---- graph ------------------------------------------------------------------------------- */
@@ -186,9 +188,9 @@ int dc_edge_max_backward(const float* dout, int64_t lddo, const float* y, int64_
 
 /* ---- weight-gradient GEMM on the fp32 matrix cores ---------------------------------------------------
  * C[M,N] (+)= A^T B,  A [R,M], B [R,N], R >> M,N  (dW = dY^T X of every per-point Linear layer: ATen mm in the
- * autograd of deltaconv/nn/mlp.py:9,15).  v_mfma_f32_32x32x2_f32, split over row slabs, ordered reduction (two
- * kernels: direct global->register operand loads for multiples of 32 with 16K..256K outputs, LDS-staged for any
- * other M, N).  Workspace: dc_gemm_tn_workspace_bytes. */
+ * autograd of deltaconv/nn/mlp.py:9,15).  v_mfma_f32_32x32x2_f32 through the LDS-staged kernel (any M, N, leading
+ * dimension < 2^21), reduction split over row slabs (one resident wave of workgroups), ordered reduction kernel:
+ * deterministic.  Workspace: dc_gemm_tn_workspace_bytes. */
 size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N);
 int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N, float* C,
                int64_t ldc, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
