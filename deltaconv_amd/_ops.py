@@ -125,6 +125,46 @@ class _KnnMax(torch.autograd.Function):
         return dh, None
 
 
+class _KnnSum(torch.autograd.Function):
+    """out[i,c] = scale * sum over the k neighbours of h[.,c] (aggr = 'sum' / 'add' / 'mean'); slots in order,
+    backward over the CSC in ascending edge order."""
+
+    @staticmethod
+    def forward(ctx, h, graph, scale):
+        h = _f32c(h)
+        n, k, c = graph.n, graph.k, h.shape[1]
+        assert h.shape[0] == n
+        out = torch.empty(n, c, dtype=torch.float32, device=h.device)
+        lib.call("dc_knn_sum", graph.nbr, n, k, h, c, c, float(scale), out, c)
+        ctx.graph, ctx.scale = graph, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        g, c = ctx.graph, dout.shape[1]
+        tptr, tedge = g.csc()
+        dh = torch.empty(g.n, c, dtype=torch.float32, device=dout.device)
+        lib.call("dc_knn_sum_backward", tptr, tedge, g.n, g.k, dout, c, c, ctx.scale, dh, c, 0)
+        return dh, None, None
+
+
+AGGREGATIONS = ("max", "min", "sum", "add", "mean")      # torch_scatter reduce names DeltaConv(aggr=...) accepts
+
+
+def knn_aggregate(h, graph, aggr):
+    """torch_scatter.scatter(h[col], row, dim=0, reduce=aggr) over the kNN graph (nn/deltaconv.py:52,54)."""
+    if aggr == "max":
+        return knn_max(h, graph)
+    if aggr == "min":
+        return -knn_max(-h, graph)
+    if aggr in ("sum", "add"):
+        return _KnnSum.apply(h, graph, 1.0)
+    if aggr == "mean":
+        return _KnnSum.apply(h, graph, 1.0 / graph.k)
+    raise ValueError(f"aggr must be one of {AGGREGATIONS}, got {aggr!r}")
+
+
 def apply_op(x, op):
     return _Apply.apply(x, op, op.graph, op.kind)
 

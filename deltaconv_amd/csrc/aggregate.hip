@@ -26,6 +26,12 @@ struct KnnMaxAffineF {
     }
 };
 
+template <int V>
+struct KnnSumF {
+    const float* h; long ldh; float scale; float* out; long ldo;
+    __device__ void operator()(long i, int c0, Row r, int k) const { knn_sum_fwd<V>(i, c0, r.ids, k, h, ldh, scale, out, ldo); }
+};
+
 // ---- backward: dh[j,c] (+)= sum over in-edges (i,s) of j with arg[i,c] == s of dout[i,c] -----------------------------
 // Same sums in the same (ascending edge) order as the generic transposed skeleton, but the loop over the in-edge list
 // runs in batches of KB edges: all KB slot words arg[i, c0:c0+4] are loaded first (independent 4-byte loads), then the
@@ -163,5 +169,39 @@ DC_EXPORT int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int
         launch_knn_max_bwd<1>(n, C, tptr, tedge, k, arg, dout, (long)ldo, dh, (long)ldh, accumulate, s);
     }
     DC_CHECK_LAUNCH("dc_knn_max_backward");
+    return DC_OK;
+}
+
+// out[i,c] = scale * sum_s h[nbr[i,s],c]  (aggr = 'sum' / 'add': scale 1; 'mean': 1/k -- every point has exactly k
+// neighbours incl. itself): torch_scatter.scatter(reduce=...) at nn/deltaconv.py:52,54.  Fixed slot order.
+DC_EXPORT int dc_knn_sum(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float scale,
+                         float* out, int64_t ldo, void* stream) {
+    DC_REQUIRE(nbr && h && out, "dc_knn_sum: null pointer");
+    DC_REQUIRE(n >= 0 && k >= 1 && k <= 255 && C >= 0, "dc_knn_sum: bad size (k <= 255)");
+    DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_sum: leading dimension smaller than the row");
+    if (n == 0 || C == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pick_v(C, {(long)ldh, (long)ldo}, {h, out}) == 4)
+        launch_fwd<4>(n, C, nullptr, nbr, k, KnnSumF<4>{h, (long)ldh, scale, out, (long)ldo}, s);
+    else
+        launch_fwd<1>(n, C, nullptr, nbr, k, KnnSumF<1>{h, (long)ldh, scale, out, (long)ldo}, s);
+    DC_CHECK_LAUNCH("dc_knn_sum");
+    return DC_OK;
+}
+
+// dh[j,c] (+)= scale * sum over the in-edges (i,s) of j of dout[i,c], ascending edge id (CSC of dc_csc_build)
+DC_EXPORT int dc_knn_sum_backward(const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dout,
+                                  int32_t C, int64_t ldo, float scale, float* dh, int64_t ldh, int32_t accumulate,
+                                  void* stream) {
+    DC_REQUIRE(tptr && tedge && dout && dh, "dc_knn_sum_backward: null pointer");
+    DC_REQUIRE(n >= 0 && k >= 1 && k <= 255 && C >= 0, "dc_knn_sum_backward: bad size (k <= 255)");
+    DC_REQUIRE(ldo >= C && ldh >= C, "dc_knn_sum_backward: leading dimension smaller than the row");
+    if (n == 0 || C == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pick_v(C, {(long)ldo, (long)ldh}, {dout, dh}) == 4)
+        launch_T<4>(n, C, nullptr, tptr, tedge, k, KnnSumT<4>{dout, (long)ldo, dh, (long)ldh, scale, accumulate, C}, s);
+    else
+        launch_T<1>(n, C, nullptr, tptr, tedge, k, KnnSumT<1>{dout, (long)ldo, dh, (long)ldh, scale, accumulate, C}, s);
+    DC_CHECK_LAUNCH("dc_knn_sum_backward");
     return DC_OK;
 }

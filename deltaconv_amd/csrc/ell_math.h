@@ -175,6 +175,22 @@ DC_HD void knn_max_fwd(long i, int c0, const int* ids, int k, const float* h, lo
     for (int q = 0; q < V; ++q) arg[i * lda + c0 + q] = slot[q];
 }
 
+// sum / mean aggregation (torch_scatter reduce = 'sum' | 'add' | 'mean', nn/deltaconv.py:52,54 with aggr != 'max'):
+// out[i,c] = scale * sum_s h[nbr[i,s], c], slots in order (fixed association); scale = 1 or 1/k
+template <int V>
+DC_HD void knn_sum_fwd(long i, int c0, const int* ids, int k, const float* h, long ldh, float scale, float* out, long ldo) {
+    Vec<V> acc = vload<V>(h + (long)ids[0] * ldh + c0);
+#pragma unroll 4
+    for (int s = 1; s < k; ++s) {
+        const Vec<V> hv = vload<V>(h + (long)ids[s] * ldh + c0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc.v[q] += hv.v[q];
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc.v[q] *= scale;
+    vstore<V>(out + i * ldo + c0, acc);
+}
+
 // Same with the BatchNorm + activation of the producing MLP block folded in:
 //   out[i,c] = max_s y[nbr[i,s], c],  y = act(scale_c * h + shift_c)   (nn/mlp.py:9 + nn/deltaconv.py:54)
 // y is evaluated per candidate (2 flops on top of a 16-byte gather), so values, ties and the first-maximal-slot
@@ -352,6 +368,24 @@ struct KnnMaxT {
         }
     }
     DC_HD void finish(long j, int c0) { vout<V>(dh + j * ldh + c0, acc, accumulate); }
+};
+
+// sum / mean aggregation backward: dh[j,c] (+)= scale * sum over in-edges (i,s) of j of dout[i,c]  (ascending edge id)
+template <int V>
+struct KnnSumT {
+    const float* dout; long ldo; float* dh; long ldh; float scale; int accumulate; int C;
+    Vec<V> acc;
+    DC_HD void init() { acc = vzero<V>(); }
+    DC_HD void step(long i, int, G2, int c0) {
+        const Vec<V> g = vload<V>(dout + i * ldo + c0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc.v[q] += g.v[q];
+    }
+    DC_HD void finish(long j, int c0) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc.v[q] *= scale;
+        vout<V>(dh + j * ldh + c0, acc, accumulate);
+    }
 };
 
 // Host-side / reference walk of one column (no staging): coefT is in CSC order, tedge gives (i, s).

@@ -17,8 +17,8 @@ from ..geometry.graph import as_graph
 class DeltaConv(torch.nn.Module):
     def __init__(self, in_channels, out_channels, depth=1, centralized=False, vector=True, aggr='max'):
         super().__init__()
-        if aggr != 'max':
-            raise NotImplementedError("only aggr='max' (the reference default, used by every model)")
+        if aggr not in _ops.AGGREGATIONS:
+            raise ValueError(f"aggr must be one of {_ops.AGGREGATIONS} (torch_scatter reduce names), got {aggr!r}")
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.centralized = centralized
@@ -64,7 +64,9 @@ class DeltaConv(torch.nn.Module):
         (x' as that column block, v', x' as the view inside the next layer's operand buffer)."""
         graph = as_graph(edge_index, grad.graph)
         # synchronised BatchNorm (dp.py) runs through the composed blocks: their statistics kernels have the split form
-        slopes = self._fusable() if (self.fuse_layer and fused.sync_group() is None and x.is_cuda) else None
+        # (the fused node is the max-aggregation layer of every reference model; other aggregations run composed)
+        slopes = (self._fusable() if (self.fuse_layer and self.aggr == 'max' and fused.sync_group() is None and x.is_cuda)
+                  else None)
         if slopes is None:
             return self.forward_composed(x, v, grad, div, graph)
         slopes_m, slopes_s = slopes
@@ -101,11 +103,11 @@ class DeltaConv(torch.nn.Module):
         graph = as_graph(edge_index, grad.graph)
         n, k, ci = graph.n, graph.k, self.in_channels
 
-        # scalar stream: max aggregation over the k neighbours (deltaconv.py:50-54)
+        # scalar stream: aggregation over the k neighbours, maximum by default (deltaconv.py:50-54)
         if self.centralized:
             x_max = self._centralized_max(x, graph)
         else:
-            x_max = _ops.knn_max(self.s_mlp_max(x), graph)
+            x_max = _ops.knn_aggregate(self.s_mlp_max(x), graph, self.aggr)
 
         # [x, div v, curl v, |v|] -> MLP (deltaconv.py:57-59)
         dcn = _ops.div_curl_norm(v, div)
@@ -126,13 +128,19 @@ class DeltaConv(torch.nn.Module):
         blocks = list(self.s_mlp_max)
         blk = blocks[0]
         slope = fused.slope_of(blk[2]) if isinstance(blk, MLPBlock) else None
-        if len(blocks) == 1 and slope is not None and slope >= 0 and blk[0].bias is None and fused.sync_group() is None:
+        if (self.aggr == 'max' and len(blocks) == 1 and slope is not None and slope >= 0 and blk[0].bias is None
+                and fused.sync_group() is None):
             y = F.linear(x, blk[0].weight)
             return fused.edge_max_bn(y, graph, blk[1].bn, slope)
         n, k = graph.n, graph.k
         nbr = graph.nbr.long()
         x_edge = (x[nbr] - x.unsqueeze(1)).reshape(n * k, x.shape[1])
-        return self.s_mlp_max(x_edge).view(n, k, -1).max(dim=1).values
+        h = self.s_mlp_max(x_edge).view(n, k, -1)                   # edges are centre-major, k contiguous
+        if self.aggr == 'max':
+            return h.max(dim=1).values
+        if self.aggr == 'min':
+            return h.min(dim=1).values
+        return h.mean(dim=1) if self.aggr == 'mean' else h.sum(dim=1)
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels})'

@@ -123,6 +123,14 @@ int dc_knn_max_affine(const int32_t* nbr, int32_t n, int32_t k, const float* h, 
 int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const uint8_t* arg,
                         const float* dout, int32_t C, int64_t ldo, float* dh, int64_t ldh, int32_t accumulate,
                         void* stream);
+/* The other aggregations of DeltaConv(aggr=...) -- torch_scatter.scatter(reduce='sum' | 'add' | 'mean') at
+ * nn/deltaconv.py:52,54: out[i,c] = scale * sum_s h[nbr[i,s],c] (scale = 1, or 1/k for the mean: every point has
+ * exactly k neighbours incl. itself), slots in order; backward over the CSC in ascending edge order (no atomics).
+ * ('min' runs as -max(-h) through dc_knn_max.) */
+int dc_knn_sum(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float scale, float* out,
+               int64_t ldo, void* stream);
+int dc_knn_sum_backward(const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const float* dout, int32_t C,
+                        int64_t ldo, float scale, float* dh, int64_t ldh, int32_t accumulate, void* stream);
 
 /* ---- scalar / vector MLP stream around the dense GEMM -------------------------------------------
  * Linear -> BatchNorm1d(over rows) -> LeakyReLU(0.2)   deltaconv/nn/mlp.py:7-11, nn/nonlin.py:11-35

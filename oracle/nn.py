@@ -69,19 +69,28 @@ class DeltaConv(tnn.Module):
 
     def __init__(self, in_channels, out_channels, depth=1, centralized=False, vector=True, aggr='max'):
         super().__init__()
-        assert aggr == 'max'
+        assert aggr in ('max', 'min', 'sum', 'add', 'mean')            # torch_scatter reduce names (deltaconv.py:52,54)
+        self.aggr = aggr
         self.in_channels, self.out_channels, self.centralized = in_channels, out_channels, centralized
         self.s_mlp_max = MLP([in_channels] + [out_channels] * depth)
         self.s_mlp = MLP([in_channels * 4] + [out_channels] * depth)
         self.v_mlp = VectorMLP([in_channels * 4 + out_channels * 2] + [out_channels] * depth) if vector else None
 
+    def _reduce(self, h):
+        """scatter(..., reduce=aggr) over the k contiguous edges of every centre point: h [Nt, k, C] -> [Nt, C]."""
+        if self.aggr == 'max':
+            return h.max(dim=1).values
+        if self.aggr == 'min':
+            return h.min(dim=1).values
+        return h.mean(dim=1) if self.aggr == 'mean' else h.sum(dim=1)
+
     def forward(self, x, v, grad, div, nbr):
         nt, k = nbr.shape
         if self.centralized:                                          # deltaconv.py:50-52
             edge = (x[nbr] - x[:, None, :]).reshape(nt * k, -1)
-            x_max = self.s_mlp_max(edge).view(nt, k, -1).max(dim=1).values
+            x_max = self._reduce(self.s_mlp_max(edge).view(nt, k, -1))
         else:                                                         # deltaconv.py:54
-            x_max = self.s_mlp_max(x)[nbr].max(dim=1).values
+            x_max = self._reduce(self.s_mlp_max(x)[nbr])
         x_cat = torch.cat([x, div @ v, geo.curl(v, div), geo.norm(v)], 1)      # deltaconv.py:57
         x = x_max + self.s_mlp(x_cat)                                 # deltaconv.py:59
         if self.v_mlp is not None:                                    # deltaconv.py:64-68

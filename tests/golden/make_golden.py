@@ -74,7 +74,12 @@ def geometry_case(name, data, k, lam, h, use_normals, seed):
     save(name, **out)
 
 
-def nn_case(name, seed):
+AGGR_CFGS = {"mean": dict(ci=8, co=16, centralized=False, vector=True, aggr="mean"),
+             "min": dict(ci=8, co=8, centralized=False, vector=False, aggr="min"),
+             "sumc": dict(ci=3, co=8, centralized=True, vector=True, aggr="sum")}
+
+
+def nn_case(name, seed, cfgs=None):
     """DeltaConv layers (centralized / plain / scalar-only) fwd + input & parameter grads."""
     from deltaconv.nn import DeltaConv
     data = synthetic_batch(2, 96, seed=seed)
@@ -82,16 +87,17 @@ def nn_case(name, seed):
     ei = knn_graph(data.pos, k, data.batch, loop=True, flow='target_to_source')
     out = dict(pos=data.pos, normal=data.norm, batch=data.batch, k=k, lam=lam, edge_index=ei)
     g = torch.Generator().manual_seed(seed)
-    cfgs = {"cent": dict(ci=3, co=8, centralized=True, vector=True),
-            "plain": dict(ci=8, co=16, centralized=False, vector=True),
-            "last": dict(ci=8, co=8, centralized=False, vector=False)}
+    cfgs = cfgs or {"cent": dict(ci=3, co=8, centralized=True, vector=True),
+                    "plain": dict(ci=8, co=16, centralized=False, vector=True),
+                    "last": dict(ci=8, co=8, centralized=False, vector=False)}
     for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
         pos, normal = data.pos.to(dt), data.norm.to(dt)
         xb, yb = R.build_tangent_basis(normal)
         grad, div = R.build_grad_div(pos, normal, xb, yb, ei.clone(), data.batch, regularizer=lam)
         for cname, c in cfgs.items():
             torch.manual_seed(100 + seed)
-            conv = DeltaConv(c["ci"], c["co"], depth=1, centralized=c["centralized"], vector=c["vector"]).to(dt)
+            conv = DeltaConv(c["ci"], c["co"], depth=1, centralized=c["centralized"], vector=c["vector"],
+                             aggr=c.get("aggr", "max")).to(dt)
             # non-trivial BN affine so that the test sees gamma/beta
             with torch.no_grad():
                 for n_, p_ in conv.named_parameters():
@@ -177,6 +183,7 @@ if __name__ == "__main__":
     geometry_case("geom_nonormals_N200_k10", synthetic_batch(1, 200, seed=5, normals=False, jitter=0.005),
                   10, 1e-2, 1.0, False, 5)
     nn_case("deltaconv_layers", 6)
+    nn_case("deltaconv_layers_aggr", 10, AGGR_CFGS)        # DeltaConv(aggr='mean' | 'min' | 'sum')
     model_case("model_cls_B4_N256_k20", "cls", 7, 4, 256, 20, 1e-3, in_channels=3, num_classes=40)
     model_case("model_seg_B2_N256_k20", "seg", 8, 2, 256, 20, 1e-3, in_channels=3, num_classes=50,
                categorical_vector=True)

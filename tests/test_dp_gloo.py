@@ -29,8 +29,9 @@ def _worker(rank, world, port, q):
     out = ddp(shard.pos).view(shard.num_graphs, 32, 4).mean(1)
     torch.nn.functional.cross_entropy(out, shard.y).backward()
     ddp.reduce_gradients()
-    q.put((rank, [p.detach().clone() for p in net.parameters()], [p.grad.clone() for p in net.parameters()],
-           shard.pos.clone(), shard.y.clone()))
+    # numpy payloads: pickled by value (torch tensors travel as file descriptors the exiting worker may close first)
+    q.put((rank, [p.detach().numpy().copy() for p in net.parameters()], [p.grad.numpy().copy() for p in net.parameters()],
+           shard.pos.numpy().copy(), shard.y.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -46,7 +47,8 @@ def test_flat_allreduce_matches_global_batch():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, w0, g0, pos0, y0), (_, w1, g1, pos1, y1) = res
+    tt = lambda t: [torch.from_numpy(a) for a in t] if isinstance(t, list) else torch.from_numpy(t)
+    (_, w0, g0, pos0, y0), (_, w1, g1, pos1, y1) = [(r[0],) + tuple(tt(a) for a in r[1:]) for r in res]
     for a, b in zip(w0, w1):
         assert torch.equal(a, b)                         # broadcast made the replicas identical
     for a, b in zip(g0, g1):

@@ -19,19 +19,27 @@ DEV = "cuda"
 
 CONV_CFGS = {"cent": dict(ci=3, co=8, centralized=True, vector=True),
              "plain": dict(ci=8, co=16, centralized=False, vector=True),
-             "last": dict(ci=8, co=8, centralized=False, vector=False)}
+             "last": dict(ci=8, co=8, centralized=False, vector=False),
+             # DeltaConv(aggr=...) other than the default (fixture deltaconv_layers_aggr.npz)
+             "mean": dict(ci=8, co=16, centralized=False, vector=True, aggr="mean"),
+             "min": dict(ci=8, co=8, centralized=False, vector=False, aggr="min"),
+             "sumc": dict(ci=3, co=8, centralized=True, vector=True, aggr="sum")}
+
+
+def _layer_fixture(cname):
+    return load_golden("deltaconv_layers_aggr" if "aggr" in CONV_CFGS[cname] else "deltaconv_layers")
 
 
 @pytest.mark.parametrize("cname", list(CONV_CFGS))
 def test_deltaconv_layer_golden(cname):
     import deltaconv_amd as dc
-    g = load_golden("deltaconv_layers")
+    g = _layer_fixture(cname)
     cfg = CONV_CFGS[cname]
     pos, normal, batch = g["pos"].to(DEV), g["normal"].to(DEV), g["batch"].to(DEV)
     ei = g["edge_index"].to(DEV)
     xb, yb = dc.geometry.build_tangent_basis(normal)
     grad, div = dc.geometry.build_grad_div(pos, normal, xb, yb, ei, batch, regularizer=g["lam"])
-    conv = dc.nn.DeltaConv(cfg["ci"], cfg["co"], 1, cfg["centralized"], cfg["vector"])
+    conv = dc.nn.DeltaConv(cfg["ci"], cfg["co"], 1, cfg["centralized"], cfg["vector"], cfg.get("aggr", "max"))
     assert repr(conv) == f'DeltaConv({cfg["ci"]}, {cfg["co"]})'
     sd = {k[len(cname) + 4:]: v for k, v in g.items() if k.startswith(cname + "_sd_")}
     res = conv.load_state_dict(sd, strict=False)

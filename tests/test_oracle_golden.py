@@ -68,7 +68,7 @@ def test_geometry_stages(name, tag, tol):
 
 
 def _load_conv(g, cname, cfg, dt):
-    conv = oracle.nn.DeltaConv(cfg["ci"], cfg["co"], 1, cfg["centralized"], cfg["vector"])
+    conv = oracle.nn.DeltaConv(cfg["ci"], cfg["co"], 1, cfg["centralized"], cfg["vector"], cfg.get("aggr", "max"))
     sd = {k[len(cname) + 4:]: v for k, v in g.items() if k.startswith(cname + "_sd_")}
     missing = conv.load_state_dict(sd, strict=False)
     assert all("num_batches" in m for m in missing.missing_keys) and not missing.unexpected_keys
@@ -77,13 +77,21 @@ def _load_conv(g, cname, cfg, dt):
 
 CONV_CFGS = {"cent": dict(ci=3, co=8, centralized=True, vector=True),
              "plain": dict(ci=8, co=16, centralized=False, vector=True),
-             "last": dict(ci=8, co=8, centralized=False, vector=False)}
+             "last": dict(ci=8, co=8, centralized=False, vector=False),
+             # DeltaConv(aggr=...) other than the default (fixture deltaconv_layers_aggr.npz)
+             "mean": dict(ci=8, co=16, centralized=False, vector=True, aggr="mean"),
+             "min": dict(ci=8, co=8, centralized=False, vector=False, aggr="min"),
+             "sumc": dict(ci=3, co=8, centralized=True, vector=True, aggr="sum")}
+
+
+def _layer_fixture(cname):
+    return load_golden("deltaconv_layers_aggr" if "aggr" in CONV_CFGS[cname] else "deltaconv_layers")
 
 
 @pytest.mark.parametrize("cname", list(CONV_CFGS))
 @pytest.mark.parametrize("tag,tol", [("f32", 2e-3), ("f64", 1e-6)])
 def test_deltaconv_layer(cname, tag, tol):
-    g = load_golden("deltaconv_layers")
+    g = _layer_fixture(cname)
     dt = torch.float32 if tag == "f32" else torch.float64
     cfg = CONV_CFGS[cname]
     pos, normal = g["pos"].to(dt), g["normal"].to(dt)

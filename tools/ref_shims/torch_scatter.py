@@ -51,4 +51,6 @@ def scatter(src, index, dim=0, out=None, dim_size=None, reduce='sum'):
         return scatter_mean(src, index, dim, dim_size=dim_size)
     if reduce == 'max':
         return scatter_max(src, index, dim, dim_size=dim_size)[0]
+    if reduce == 'min':
+        return -scatter_max(-src, index, dim, dim_size=dim_size)[0]
     raise NotImplementedError(reduce)
