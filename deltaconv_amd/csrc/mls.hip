@@ -41,10 +41,11 @@ __global__ __launch_bounds__(AVG_THREADS) void mls_avgdist_kernel(const float* _
     }
 }
 
+template <bool SHAPE>
 __global__ __launch_bounds__(128) void mls_fit_kernel(const float* __restrict__ pos, const float* __restrict__ normal,
                                                       const float* __restrict__ xb, const float* __restrict__ yb,
                                                       const int* __restrict__ nbr, const int* __restrict__ cloud_ptr,
-                                                      int k, double kernel_width, double lambda,
+                                                      int k, double kernel_width, double lambda, double lambda_shape,
                                                       const double* __restrict__ avg, float* __restrict__ G,
                                                       double* __restrict__ coef, unsigned* __restrict__ inf_bits) {
     const int cloud = blockIdx.y;
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(128) void mls_fit_kernel(const float* __restrict__ 
     float rownorm = 0.f;
     if (q < n) {
         const long i = begin + q;
-        rownorm = dcmath::mls_fit_point(pos, normal, xb, yb, nbr + i * k, i, k, avg[cloud], kernel_width, lambda,
-                                        G + i * k * 2, coef + i * 6);
+        rownorm = dcmath::mls_fit_point<SHAPE>(pos, normal, xb, yb, nbr + i * k, i, k, avg[cloud], kernel_width, lambda,
+                                               G + i * k * 2, coef + i * 6, lambda_shape);
     }
     rownorm = dc_wave_max(rownorm);  // non-negative floats order like their bit patterns
     if ((threadIdx.x & 63) == 0 && rownorm > 0.f) atomicMax(inf_bits + cloud, __float_as_uint(rownorm));
@@ -94,16 +95,23 @@ DC_EXPORT size_t dc_mls_workspace_bytes(int32_t num_clouds, int32_t num_points) 
     return align_up((size_t)num_clouds * 8, 256) + align_up((size_t)num_clouds * 4, 256) + (size_t)num_points * 48;
 }
 
-DC_EXPORT int dc_mls_assemble(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
-                              const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
-                              int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer,
-                              int32_t normalized, float* G, float* D, void* workspace, size_t workspace_bytes,
-                              void* stream) {
-    DC_REQUIRE(pos && normal && x_basis && y_basis && nbr && cloud_ptr && G && D, "dc_mls_assemble: null pointer");
-    DC_REQUIRE(k >= 1 && num_clouds >= 0 && num_points >= 0 && max_cloud_size >= 0, "dc_mls_assemble: bad size");
+namespace {
+int mls_assemble(const char* name, const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                 const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
+                 int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer, bool shape,
+                 float shape_regularizer, int32_t normalized, float* G, float* D, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+    if (!(pos && normal && x_basis && y_basis && nbr && cloud_ptr && G && D)) {
+        dc_set_error("%s: null pointer", name);
+        return DC_ERR_ARG;
+    }
+    if (!(k >= 1 && num_clouds >= 0 && num_points >= 0 && max_cloud_size >= 0)) {
+        dc_set_error("%s: bad size", name);
+        return DC_ERR_ARG;
+    }
     if (num_clouds == 0 || num_points == 0) return DC_OK;
     if (!workspace || workspace_bytes < dc_mls_workspace_bytes(num_clouds, num_points)) {
-        dc_set_error("dc_mls_assemble: workspace too small (%zu < %zu)", workspace_bytes,
+        dc_set_error("%s: workspace too small (%zu < %zu)", name, workspace_bytes,
                      dc_mls_workspace_bytes(num_clouds, num_points));
         return DC_ERR_WORKSPACE;
     }
@@ -115,11 +123,42 @@ DC_EXPORT int dc_mls_assemble(const float* pos, const float* normal, const float
                                              align_up((size_t)num_clouds * 4, 256));
     dc_zero_words(inf_bits, num_clouds, s);
     hipLaunchKernelGGL(mls_avgdist_kernel, dim3(num_clouds), dim3(AVG_THREADS), 0, s, pos, nbr, cloud_ptr, k, avg);
-    hipLaunchKernelGGL(mls_fit_kernel, dim3(dc_cdiv(max_cloud_size, 128), num_clouds), dim3(128), 0, s, pos, normal,
-                       x_basis, y_basis, nbr, cloud_ptr, k, (double)kernel_width, (double)regularizer, avg, G, coef,
-                       inf_bits);
+    const dim3 grid(dc_cdiv(max_cloud_size, 128), num_clouds);
+    if (shape)
+        hipLaunchKernelGGL(mls_fit_kernel<true>, grid, dim3(128), 0, s, pos, normal, x_basis, y_basis, nbr, cloud_ptr, k,
+                           (double)kernel_width, (double)regularizer, (double)shape_regularizer, avg, G, coef, inf_bits);
+    else
+        hipLaunchKernelGGL(mls_fit_kernel<false>, grid, dim3(128), 0, s, pos, normal, x_basis, y_basis, nbr, cloud_ptr, k,
+                           (double)kernel_width, (double)regularizer, 0.0, avg, G, coef, inf_bits);
     hipLaunchKernelGGL(mls_div_kernel, dim3(dc_cdiv((long long)max_cloud_size * k, 256), num_clouds), dim3(256), 0, s,
                        pos, normal, x_basis, y_basis, nbr, cloud_ptr, k, normalized, coef, inf_bits, G, D);
-    DC_CHECK_LAUNCH("dc_mls_assemble");
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dc_set_error("%s: %s", name, hipGetErrorString(e));
+        return DC_ERR_LAUNCH;
+    }
     return DC_OK;
+}
+}  // namespace
+
+DC_EXPORT int dc_mls_assemble(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                              const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
+                              int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer,
+                              int32_t normalized, float* G, float* D, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    return mls_assemble("dc_mls_assemble", pos, normal, x_basis, y_basis, nbr, cloud_ptr, num_clouds, num_points,
+                        max_cloud_size, k, kernel_width, regularizer, false, 0.f, normalized, G, D, workspace,
+                        workspace_bytes, stream);
+}
+
+// build_grad_div(..., shape_regularizer=s) (grad_div_mls.py:241-244,266-267): the gradient rows come from the fit with
+// `regularizer`, the surface (height-field) coefficients behind the divergence rows from a fit with `shape_regularizer`
+DC_EXPORT int dc_mls_assemble_shape(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                                    const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
+                                    int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer,
+                                    float shape_regularizer, int32_t normalized, float* G, float* D, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return mls_assemble("dc_mls_assemble_shape", pos, normal, x_basis, y_basis, nbr, cloud_ptr, num_clouds, num_points,
+                        max_cloud_size, k, kernel_width, regularizer, true, shape_regularizer, normalized, G, D,
+                        workspace, workspace_bytes, stream);
 }

@@ -161,9 +161,12 @@ DC_HD double point_dist_sum(const float* pos, const int* nbr_i, long i, int k) {
 //   g_out[k][2]  un-normalised gradient rows  (wls[e,1], wls[e,2])
 //   coef[6]      quadratic height-field coefficients c = sum_e wls[e,:] * height_e
 //   returns      ||(sum_e |g_u|, sum_e |g_v|)||_2  (this row's contribution to the infinity norm)
+//   SHAPE: the surface fit uses its own regulariser lambda_shape (build_grad_div(shape_regularizer=...), :241-244,
+//   266-267): a second factorisation of B^T W B + lambda_shape I for the height-field coefficients only
+template <bool SHAPE = false>
 DC_HD float mls_fit_point(const float* pos, const float* normal, const float* xb, const float* yb,
                           const int* nbr_i, long i, int k, double avg_dist, double kernel_width, double lambda,
-                          float* g_out, double* coef) {
+                          float* g_out, double* coef, double lambda_shape = 0.0) {
     const Frame f = load_frame(pos, normal, xb, yb, i);
     const double inv_h2 = 1.0 / ((kernel_width * avg_dist) * (kernel_width * avg_dist));
     double M[6][6];
@@ -194,8 +197,51 @@ DC_HD float mls_fit_point(const float* pos, const float* normal, const float* xb
         rhs[a] *= inv_w;
 #pragma unroll
         for (int c = a; c < 6; ++c) M[a][c] *= inv_w;
-        M[a][a] += lambda;  // B^T W B + lambda I (:141-143)
     }
+    if (SHAPE) {   // surface coefficients from (B^T W B + lambda_shape I) c = B^T W f   (:146-150)
+        double S[6][6], c[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            c[a] = rhs[a];
+#pragma unroll
+            for (int b = a; b < 6; ++b) S[a][b] = M[a][b];
+            S[a][a] += lambda_shape;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {                       // Cholesky, as below
+            double d = S[j][j];
+#pragma unroll
+            for (int p = 0; p < j; ++p) d -= S[j][p] * S[j][p];
+            const double ljj = sqrt(fmax(d, 1e-300));
+            const double inv_l = 1.0 / ljj;
+#pragma unroll
+            for (int r = j + 1; r < 6; ++r) {
+                double t = S[j][r];
+#pragma unroll
+                for (int p = 0; p < j; ++p) t -= S[r][p] * S[j][p];
+                S[r][j] = t * inv_l;
+            }
+            S[j][j] = ljj;
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            double t = c[r];
+#pragma unroll
+            for (int p = 0; p < r; ++p) t -= S[r][p] * c[p];
+            c[r] = t / S[r][r];
+        }
+#pragma unroll
+        for (int r = 5; r >= 0; --r) {
+            double t = c[r];
+#pragma unroll
+            for (int p = r + 1; p < 6; ++p) t -= S[p][r] * c[p];
+            c[r] = t / S[r][r];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) coef[a] = c[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) M[a][a] += lambda;  // B^T W B + lambda I (:141-143)
     // Cholesky M = L L^T (L stored in the lower triangle of M; upper triangle holds M)
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -239,8 +285,10 @@ DC_HD float mls_fit_point(const float* pos, const float* normal, const float* xb
         const double inv_l = 1.0 / M[r][r];
         z1[r] = t1 * inv_l; z2[r] = t2 * inv_l; rhs[r] = t3 * inv_l;
     }
+    if (!SHAPE) {
 #pragma unroll
-    for (int a = 0; a < 6; ++a) coef[a] = rhs[a];
+        for (int a = 0; a < 6; ++a) coef[a] = rhs[a];
+    }
     // second sweep over the neighbours: gradient rows wls[e,1], wls[e,2] = w_e * (z . b_e)
     double au = 0, av = 0;
     for (int e = 0; e < k; ++e) {

@@ -88,8 +88,6 @@ def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel
                    normalized=True, shape_regularizer=None):
     """grad_div_mls.py:197-277 -> (grad, div) as SparseOp."""
     require_gpu()
-    if shape_regularizer is not None:
-        raise NotImplementedError("shape_regularizer is unused by every reference model/experiment")
     pos = pos.contiguous().float()
     n = pos.shape[0]
     g = _graph_from(edge_index, n, batch=batch)
@@ -99,7 +97,12 @@ def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel
     D = torch.empty(n, g.k, 2, dtype=torch.float32, device=pos.device)
     nbytes = lib.raw("dc_mls_workspace_bytes")(g.num_clouds, n)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=pos.device)
-    lib.call("dc_mls_assemble", pos, normal.contiguous().float(), x_basis.contiguous().float(),
-             y_basis.contiguous().float(), g.nbr, g.ptr, g.num_clouds, n, g.max_cloud, g.k, float(kernel_width),
-             float(regularizer), int(bool(normalized)), G, D, ws, ws.numel() * 8)
+    if shape_regularizer is None:
+        lib.call("dc_mls_assemble", pos, normal.contiguous().float(), x_basis.contiguous().float(),
+                 y_basis.contiguous().float(), g.nbr, g.ptr, g.num_clouds, n, g.max_cloud, g.k, float(kernel_width),
+                 float(regularizer), int(bool(normalized)), G, D, ws, ws.numel() * 8)
+    else:       # the surface fit with its own regulariser (grad_div_mls.py:241-244,266-267)
+        lib.call("dc_mls_assemble_shape", pos, normal.contiguous().float(), x_basis.contiguous().float(),
+                 y_basis.contiguous().float(), g.nbr, g.ptr, g.num_clouds, n, g.max_cloud, g.k, float(kernel_width),
+                 float(regularizer), float(shape_regularizer), int(bool(normalized)), G, D, ws, ws.numel() * 8)
     return SparseOp("grad", g, G), SparseOp("div", g, D)

@@ -75,6 +75,14 @@ int dc_mls_assemble(const float* pos, const float* normal, const float* x_basis,
                     const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
                     int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer, int32_t normalized,
                     float* G, float* D, void* workspace, size_t workspace_bytes, void* stream);
+/* build_grad_div(..., shape_regularizer=s) -- grad_div_mls.py:241-244,266-267 (weighted_least_squares :146-150): the
+ * gradient rows come from the fit regularised by `regularizer`, the surface coefficients behind the divergence rows
+ * (fit_vector_mapping) from a second fit regularised by `shape_regularizer`. */
+int dc_mls_assemble_shape(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                          const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
+                          int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer,
+                          float shape_regularizer, int32_t normalized, float* G, float* D, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ---- operator applies (SparseTensor @ dense: deltanet_base.py:78; deltaconv.py:57,66;
  *      operators.py:27,33,40,43) ------------------------------------------------------------- */

@@ -189,7 +189,7 @@ class EllOp:
 
 
 def build_grad_div(pos, normal, x_basis, y_basis, nbr, ptr, kernel_width=1.0, regularizer=1e-3,
-                   normalized=True, return_parts=False):
+                   normalized=True, return_parts=False, shape_regularizer=None):
     """grad_div_mls.py:197-277 -> (grad: EllOp, div: EllOp)."""
     coords = coords_projected(pos, normal, x_basis, y_basis, nbr)
     dist = (pos[nbr] - pos[:, None, :]).norm(dim=-1)
@@ -202,6 +202,8 @@ def build_grad_div(pos, normal, x_basis, y_basis, nbr, ptr, kernel_width=1.0, re
             m = rowsum[ptr[b]:ptr[b + 1]].max()
             if m > 1e-5:
                 G[ptr[b]:ptr[b + 1]] = G[ptr[b]:ptr[b + 1]] / m
+    if shape_regularizer is not None:                                 # grad_div_mls.py:241-244,266-267
+        wls = weighted_least_squares(coords, weights, shape_regularizer)
     vmap = fit_vector_mapping(pos, normal, x_basis, y_basis, nbr, wls, coords)
     D = (G[..., None, :] @ vmap).squeeze(-2)                          # grad_div_mls.py:271-272
     grad, div = EllOp("grad", nbr, G), EllOp("div", nbr, D.contiguous())

@@ -74,6 +74,21 @@ def geometry_case(name, data, k, lam, h, use_normals, seed):
     save(name, **out)
 
 
+def shape_reg_case(name, data, k, lam, lam_shape, seed):
+    """build_grad_div(..., shape_regularizer=lam_shape): operator values, fp32 and fp64."""
+    out = dict(pos=data.pos, normal=data.norm, batch=data.batch, k=k, lam=lam, lam_shape=lam_shape)
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        pos, normal = data.pos.to(dt), data.norm.to(dt)
+        ei = knn_graph(pos, k, data.batch, loop=True, flow='target_to_source')
+        if tag == "f32":
+            out["edge_index"] = ei
+        xb, yb = R.build_tangent_basis(normal)
+        grad, div = R.build_grad_div(pos, normal, xb, yb, ei.clone(), data.batch, regularizer=lam,
+                                     shape_regularizer=lam_shape)
+        out.update({f"grad_val_{tag}": grad.value, f"div_val_{tag}": div.value})
+    save(name, **out)
+
+
 AGGR_CFGS = {"mean": dict(ci=8, co=16, centralized=False, vector=True, aggr="mean"),
              "min": dict(ci=8, co=8, centralized=False, vector=False, aggr="min"),
              "sumc": dict(ci=3, co=8, centralized=True, vector=True, aggr="sum")}
@@ -184,6 +199,7 @@ if __name__ == "__main__":
                   10, 1e-2, 1.0, False, 5)
     nn_case("deltaconv_layers", 6)
     nn_case("deltaconv_layers_aggr", 10, AGGR_CFGS)        # DeltaConv(aggr='mean' | 'min' | 'sum')
+    shape_reg_case("geom_shape_regularizer", synthetic_batch(2, 96, seed=11), 16, 1e-3, 5e-2, 11)
     model_case("model_cls_B4_N256_k20", "cls", 7, 4, 256, 20, 1e-3, in_channels=3, num_classes=40)
     model_case("model_seg_B2_N256_k20", "seg", 8, 2, 256, 20, 1e-3, in_channels=3, num_classes=50,
                categorical_vector=True)

@@ -152,6 +152,22 @@ def test_build_grad_div_vs_oracle_fp64(lam, normalized, B, N, k):
     assert not torch.isnan(grad.coef).any() and not torch.isnan(div.coef).any()
 
 
+def test_build_grad_div_shape_regularizer_golden():
+    """build_grad_div(shape_regularizer=...) on the GPU against the reference's fp32 / fp64 values."""
+    import deltaconv_amd as dc
+    g = load_golden("geom_shape_regularizer")
+    pos, normal, batch = g["pos"].to(DEV), g["normal"].to(DEV), g["batch"].to(DEV)
+    ei = g["edge_index"].to(DEV)
+    xb, yb = dc.geometry.build_tangent_basis(normal)
+    grad, div = dc.geometry.build_grad_div(pos, normal, xb, yb, ei, batch, regularizer=float(g["lam"]),
+                                           shape_regularizer=float(g["lam_shape"]))
+    for tag, tol in (("f32", 2e-3), ("f64", 2e-5)):
+        assert rel_err(grad.coef.reshape(-1), g[f"grad_val_{tag}"]) < tol
+        assert rel_err(div.coef.reshape(-1), g[f"div_val_{tag}"]) < tol
+    grad0, div0 = dc.geometry.build_grad_div(pos, normal, xb, yb, ei, batch, regularizer=float(g["lam"]))
+    assert torch.equal(grad0.coef, grad.coef) and rel_err(div0.coef.reshape(-1), g["div_val_f64"]) > 1e-3
+
+
 # ---------------------------------------------------------------------------------- CSC
 def test_csc():
     from deltaconv_amd.geometry import Graph

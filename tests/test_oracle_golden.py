@@ -67,6 +67,24 @@ def test_geometry_stages(name, tag, tol):
         assert rel_err(val, g[f"{key}_{tag}"]) < (1e-5 if tag == "f32" else 1e-12), key
 
 
+@pytest.mark.parametrize("tag,tol", [("f32", 2e-3), ("f64", 1e-7)])
+def test_build_grad_div_shape_regularizer(tag, tol):
+    """build_grad_div(shape_regularizer=...) (grad_div_mls.py:241-244,266-267) against the reference's values."""
+    g = load_golden("geom_shape_regularizer")
+    dt = torch.float32 if tag == "f32" else torch.float64
+    pos, normal = g["pos"].to(dt), g["normal"].to(dt)
+    nt, k = pos.shape[0], int(g["k"])
+    ptr = geo.cloud_ptr(g["batch"])
+    nbr = geo.nbr_from_edge_index(g["edge_index"], k)
+    xb, yb = geo.build_tangent_basis(normal)
+    grad, div = geo.build_grad_div(pos, normal, xb, yb, nbr, ptr, 1.0, float(g["lam"]),
+                                   shape_regularizer=float(g["lam_shape"]))
+    assert rel_err(grad.coef.reshape(-1), g[f"grad_val_{tag}"]) < tol
+    assert rel_err(div.coef.reshape(-1), g[f"div_val_{tag}"]) < tol
+    _, div0 = geo.build_grad_div(pos, normal, xb, yb, nbr, ptr, 1.0, float(g["lam"]))
+    assert rel_err(div0.coef.reshape(-1), g[f"div_val_{tag}"]) > 1e-3          # the second regulariser matters here
+
+
 def _load_conv(g, cname, cfg, dt):
     conv = oracle.nn.DeltaConv(cfg["ci"], cfg["co"], 1, cfg["centralized"], cfg["vector"], cfg.get("aggr", "max"))
     sd = {k[len(cname) + 4:]: v for k, v in g.items() if k.startswith(cname + "_sd_")}
