@@ -1,5 +1,7 @@
-"""Fused blocks of the scalar / vector MLP stream: library GEMM + hand-written HIP BatchNorm /
-activation / vector non-linearity kernels (deltaconv_amd/csrc/nn.hip), each with its own backward.
+"""Fused blocks of the scalar / vector MLP stream: hand-written fp32-MFMA products (deltaconv_amd/csrc/gemm.hip, with
+the BatchNorm statistics in their epilogue and the BatchNorm backward in their operand loaders) + hand-written HIP
+BatchNorm / activation / vector non-linearity kernels (deltaconv_amd/csrc/nn.hip), each with its own backward.  Only
+per-cloud products (the 32-row classification head) go to the vendor library.
 
 Reference semantics: deltaconv/nn/mlp.py:7-17 and nn/nonlin.py:11-86 (Linear(no bias) ->
 BatchNorm1d over rows -> LeakyReLU(0.2);  Linear(no bias) -> VectorNonLin(BatchNorm1d))."""

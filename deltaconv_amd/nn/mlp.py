@@ -1,6 +1,7 @@
 """Scalar / vector MLP builders (reference: deltaconv/nn/mlp.py:7-46).  Same Sequential nesting
-(hence the same state_dict keys: ``0.0.weight``, ``0.1.bn.weight`` ...); each inner block runs as
-library GEMM + one fused HIP BatchNorm/activation kernel instead of three ATen ops."""
+(hence the same state_dict keys: ``0.0.weight``, ``0.1.bn.weight`` ...); each inner block runs as one hand-written
+fp32-MFMA product with the BatchNorm statistics in its epilogue + one fused HIP BatchNorm/activation kernel instead of
+three ATen ops (nn/fused.py)."""
 import torch
 from torch.nn import Sequential as Seq, LeakyReLU
 
