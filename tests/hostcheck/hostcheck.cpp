@@ -54,6 +54,37 @@ void hc_mls_assemble(const float* pos, const float* normal, const float* xb, con
     }
 }
 
+// dc_mls_assemble_shape: the surface fit with its own regulariser (mls_fit_point<true>)
+void hc_mls_assemble_shape(const float* pos, const float* normal, const float* xb, const float* yb, const int* nbr,
+                           const int* cloud_ptr, int num_clouds, int k, float kernel_width, float regularizer,
+                           float shape_regularizer, int normalized, float* G, float* D) {
+    for (int c = 0; c < num_clouds; ++c) {
+        const int begin = cloud_ptr[c], n = cloud_ptr[c + 1] - begin;
+        double acc = 0;
+        for (int q = 0; q < n; ++q) {
+            const long i = begin + q;
+            acc += dcmath::point_dist_sum(pos, nbr + i * k, i, k) / k;
+        }
+        const double avg = n > 0 ? acc / n : 0.0;
+        std::vector<double> coef((size_t)n * 6);
+        float inf_norm = 0.f;
+        for (int q = 0; q < n; ++q) {
+            const long i = begin + q;
+            inf_norm = std::max(inf_norm, dcmath::mls_fit_point<true>(pos, normal, xb, yb, nbr + i * k, i, k, avg,
+                                                                      (double)kernel_width, (double)regularizer,
+                                                                      G + i * k * 2, coef.data() + (size_t)q * 6,
+                                                                      (double)shape_regularizer));
+        }
+        for (long le = 0; le < (long)n * k; ++le) {
+            const long e = (long)begin * k + le, i = e / k, j = nbr[e];
+            const dcmath::Frame fi = dcmath::load_frame(pos, normal, xb, yb, i);
+            dcmath::mls_div_edge(fi, coef.data() + (size_t)(i - begin) * 6, dcmath::ld3(pos + 3 * j),
+                                 dcmath::ld3(xb + 3 * j), dcmath::ld3(yb + 3 * j), normalized ? inf_norm : 0.f,
+                                 G + 2 * e, D + 2 * e);
+        }
+    }
+}
+
 // ---- ELL applies / aggregation: loop the per-thread bodies of ell_math.h over all threads ----
 // CSC build: same result as csc.hip (count -> per-cloud scan -> fill -> sort); the fill walks the
 // edges in REVERSE so that sort_column has real work to do.
@@ -139,6 +170,39 @@ void hc_knn_max_bwd(int V, const int* tptr, const int* tedge, int n, int k, cons
         for (int c0 = 0; c0 < C; c0 += V) {
             if (V == 4) walk_column(KnnMaxT<4>{arg, (long)C, dout, ldo, dh, ldh, acc, C}, j, c0, nullptr, tptr, tedge, k);
             else walk_column(KnnMaxT<1>{arg, (long)C, dout, ldo, dh, ldh, acc, C}, j, c0, nullptr, tptr, tedge, k);
+        }
+}
+
+// sum / mean aggregation (dc_knn_sum, dc_knn_sum_backward) and the transposed gradient apply with the folded
+// accumulation (dc_apply_grad_T_sum)
+void hc_knn_sum(int V, const int* nbr, int n, int k, const float* h, int C, long ldh, float scale, float* out, long ldo) {
+    using namespace dcell;
+    for (long i = 0; i < n; ++i)
+        for (int c0 = 0; c0 < C; c0 += V) {
+            if (V == 4) knn_sum_fwd<4>(i, c0, nbr + i * k, k, h, ldh, scale, out, ldo);
+            else knn_sum_fwd<1>(i, c0, nbr + i * k, k, h, ldh, scale, out, ldo);
+        }
+}
+
+void hc_knn_sum_bwd(int V, const int* tptr, const int* tedge, int n, int k, const float* dout, int C, long ldo, float scale,
+                    float* dh, long ldh, int acc) {
+    using namespace dcell;
+    for (long j = 0; j < n; ++j)
+        for (int c0 = 0; c0 < C; c0 += V) {
+            if (V == 4) walk_column(KnnSumT<4>{dout, ldo, dh, ldh, scale, acc, C}, j, c0, nullptr, tptr, tedge, k);
+            else walk_column(KnnSumT<1>{dout, ldo, dh, ldh, scale, acc, C}, j, c0, nullptr, tptr, tedge, k);
+        }
+}
+
+void hc_grad_T_sum(int V, const float* coef, const int* tptr, const int* tedge, int n, int k, const float* dy, int C,
+                   long ldy, const float* a, long lda, const float* b, long ldb, float* out, long ldo) {
+    using namespace dcell;
+    std::vector<float> coefT((size_t)n * k * 2);
+    for (long t = 0; t < (long)n * k; ++t) { coefT[2 * t] = coef[2 * (long)tedge[t]]; coefT[2 * t + 1] = coef[2 * (long)tedge[t] + 1]; }
+    for (long j = 0; j < n; ++j)
+        for (int c0 = 0; c0 < C; c0 += V) {
+            if (V == 4) walk_column(GradTSum<4>{dy, ldy, a, lda, b, ldb, out, ldo, C}, j, c0, coefT.data(), tptr, tedge, k);
+            else walk_column(GradTSum<1>{dy, ldy, a, lda, b, ldb, out, ldo, C}, j, c0, coefT.data(), tptr, tedge, k);
         }
 }
 

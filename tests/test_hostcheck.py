@@ -63,6 +63,27 @@ def test_mls_vs_reference_and_oracle(hc, name):
     assert rel_err(G, Go.coef) < 1e-6 and rel_err(D, Do.coef) < 1e-6
 
 
+def test_mls_shape_regularizer_vs_reference(hc):
+    """mls_fit_point<true> (dc_mls_assemble_shape): build_grad_div(shape_regularizer=...) of the reference."""
+    g = load_golden("geom_shape_regularizer")
+    pos, k = g["pos"].contiguous(), int(g["k"])
+    nt = pos.shape[0]
+    ptr = geo.cloud_ptr(g["batch"], nt)
+    nbr = geo.nbr_from_edge_index(g["edge_index"], k)
+    normal = g["normal"].contiguous()
+    xb, yb = geo.build_tangent_basis(normal)
+    G, D = torch.zeros(nt, k, 2), torch.zeros(nt, k, 2)
+    nbr32 = nbr.to(torch.int32).contiguous()
+    ptr32 = torch.tensor(ptr, dtype=torch.int32)
+    hc.hc_mls_assemble_shape(fptr(pos), fptr(normal), fptr(xb.contiguous()), fptr(yb.contiguous()), fptr(nbr32),
+                             fptr(ptr32), len(ptr) - 1, k, ctypes.c_float(1.0), ctypes.c_float(float(g["lam"])),
+                             ctypes.c_float(float(g["lam_shape"])), 1, fptr(G), fptr(D))
+    assert rel_err(G.reshape(-1), g["grad_val_f64"]) < 2e-5 and rel_err(D.reshape(-1), g["div_val_f64"]) < 2e-5
+    assert rel_err(G.reshape(-1), g["grad_val_f32"]) < 2e-3 and rel_err(D.reshape(-1), g["div_val_f32"]) < 2e-3
+    G0, D0 = run_mls(hc, pos, normal, xb.contiguous(), yb.contiguous(), nbr, ptr, k, 1.0, float(g["lam"]))
+    assert torch.equal(G0, G) and rel_err(D0.reshape(-1), g["div_val_f64"]) > 1e-3
+
+
 @pytest.mark.parametrize("lam,normalized", [(1e-8, False), (1e-8, True), (0.0, False)])
 def test_mls_small_lambda(hc, lam, normalized):
     """The reference's tests use regularizer=1e-8 (test_grad_div_mls.py:332,390): ill-conditioned in

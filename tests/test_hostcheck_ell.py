@@ -26,6 +26,9 @@ def hc():
     lib.hc_knn_max.argtypes = [ci, vp, ci, ci, vp, ci, cl, vp, cl, vp]
     lib.hc_knn_max_bwd.argtypes = [ci, vp, vp, ci, ci, vp, vp, ci, cl, vp, cl, ci]
     lib.hc_knn_max_affine.argtypes = [ci, vp, ci, ci, vp, ci, cl, vp, vp, ctypes.c_float, vp, cl, vp]
+    lib.hc_knn_sum.argtypes = [ci, vp, ci, ci, vp, ci, cl, ctypes.c_float, vp, cl]
+    lib.hc_knn_sum_bwd.argtypes = [ci, vp, vp, ci, ci, vp, ci, cl, ctypes.c_float, vp, cl, ci]
+    lib.hc_grad_T_sum.argtypes = [ci, vp, vp, vp, ci, ci, vp, ci, cl, vp, cl, vp, cl, vp, cl]
     return lib
 
 
@@ -175,3 +178,39 @@ def test_forward_and_transposed(hc, graph, C, pad):
     arg2 = torch.zeros(n, C, dtype=torch.uint8)
     hc.hc_knn_max_affine(V, P(nbr32), n, k, P(hb2), C, ld, P(sc.contiguous()), P(sh.contiguous()), 0.25, P(out2), ld, P(arg2))
     assert torch.equal(out2[:, :C], mx) and torch.equal(arg2.long(), slot)
+
+
+@pytest.mark.parametrize("C,pad", [(8, 0), (8, 4), (5, 0)])
+def test_sum_aggregation_and_folded_accumulation(hc, graph, C, pad):
+    """dc_knn_sum / dc_knn_sum_backward (DeltaConv(aggr='sum' | 'mean')) and dc_apply_grad_T_sum (transposed gradient
+    apply + the other gradients of x') on the CPU build of their per-thread bodies."""
+    torch.manual_seed(C + pad)
+    n, k, nbr32, G = graph["n"], graph["k"], graph["nbr32"], graph["G"]
+    Gc = G.coef.contiguous()
+    tptr, tedge = csc(hc, graph)
+    V = 4 if (C % 4 == 0 and pad % 4 == 0) else 1
+    ld = C + pad
+    h = torch.randn(n, C, requires_grad=True)
+    hb = torch.zeros(n, ld); hb[:, :C] = h.detach()
+    for scale in (1.0, 1.0 / k):
+        out = torch.full((n, ld), 7.0)
+        hc.hc_knn_sum(V, P(nbr32), n, k, P(hb), C, ld, scale, P(out), ld)
+        ref = h[graph["nbr"]].sum(1) * scale
+        assert rel_err(out[:, :C], ref) < 1e-6 and bool((out[:, C:] == 7).all())
+        dy = torch.randn(n, C)
+        (dh_ref,) = torch.autograd.grad(ref, h, dy)
+        dyb = torch.zeros(n, ld); dyb[:, :C] = dy
+        dh = torch.full((n, ld), 7.0)
+        hc.hc_knn_sum_bwd(V, P(tptr), P(tedge), n, k, P(dyb), C, ld, scale, P(dh), ld, 0)
+        assert rel_err(dh[:, :C], dh_ref) < 1e-6
+    # out = (a + b) + grad^T dy, and with b absent
+    x = torch.randn(n, C, requires_grad=True)
+    dy = torch.randn(2 * n, C)
+    (gt,) = torch.autograd.grad(G @ x, x, dy)
+    dyb = torch.zeros(2 * n, ld); dyb[:, :C] = dy
+    a, b = torch.randn(n, ld), torch.randn(n, ld)
+    out = torch.full((n, ld), 7.0)
+    hc.hc_grad_T_sum(V, P(Gc), P(tptr), P(tedge), n, k, P(dyb), C, ld, P(a), ld, P(b), ld, P(out), ld)
+    assert rel_err(out[:, :C], a[:, :C] + b[:, :C] + gt) < 1e-5 and bool((out[:, C:] == 7).all())
+    hc.hc_grad_T_sum(V, P(Gc), P(tptr), P(tedge), n, k, P(dyb), C, ld, P(a), ld, None, 0, P(out), ld)
+    assert rel_err(out[:, :C], a[:, :C] + gt) < 1e-5
