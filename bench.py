@@ -64,28 +64,43 @@ def apply_roofline(graph, grad, div, C, iters=200):
     y1 = torch.empty(n, C, device=dev)
     y2 = torch.empty(2 * n, C, device=dev)
     y3 = torch.empty(n, 3 * C, device=dev)
+    from deltaconv_amd import _ops
+    from deltaconv_amd.geometry import graph as _G
+    arg = torch.empty(n, C, dtype=torch.uint8, device=dev)
+    # the product's dispatch (deltaconv_amd/_ops.py): from the graph's tile plan (neighbour rows in LDS, csrc/ell_tile.h)
+    # when it applies, else through the gather path
     cases = {
-        "div_curl_norm": (lambda: lib.call("dc_apply_div_curl_norm", div.coef, graph.nbr, n, k, v, C, C, y3, 3 * C),
-                          20 * C * n + 12 * E),
-        "grad": (lambda: lib.call("dc_apply_grad", grad.coef, graph.nbr, n, k, x, C, C, y2, C), 12 * C * n + 12 * E),
-        "div": (lambda: lib.call("dc_apply_div", div.coef, graph.nbr, n, k, v, C, C, y1, C), 12 * C * n + 12 * E),
-        "hodge": (lambda: lib.call("dc_apply_hodge", grad.coef, graph.nbr, n, k, dcn, C, 3 * C, y2, C),
-                  16 * C * n + 12 * E),
+        "div_curl_norm": (lambda: _ops.fwd_apply("div_curl_norm", div, v, C, C, y3, 3 * C), 20 * C * n + 12 * E),
+        "grad": (lambda: _ops.fwd_apply("grad", grad, x, C, C, y2, C), 12 * C * n + 12 * E),
+        "div": (lambda: _ops.fwd_apply("div", div, v, C, C, y1, C), 12 * C * n + 12 * E),
+        "hodge": (lambda: _ops.fwd_apply("hodge", grad, dcn, C, 3 * C, y2, C), 16 * C * n + 12 * E),
+        "knn_max": (lambda: _ops.fwd_knn_max(graph, x, C, C, y1, C, arg), 9 * C * n + 4 * E),
     }
-    fam = {}
-    for name, (fn, nbytes) in cases.items():
-        for _ in range(10):
-            fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / iters * 1e-3
-        fam[name] = dict(us=round(t * 1e6, 2), bytes=nbytes, GBs=round(nbytes / t / 1e9, 1),
-                         frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4))
+
+    def measure():
+        out = {}
+        for name, (fn, nbytes) in cases.items():
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / iters * 1e-3
+            out[name] = dict(us=round(t * 1e6, 2), bytes=nbytes, GBs=round(nbytes / t / 1e9, 1),
+                             frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4))
+        return out
+
+    tiled = graph.tile_plan() is not None
+    fam = measure()
+    fam_gather = None
+    if tiled:                                   # the same applies through the gather path (A/B, same results)
+        plan, graph._tile_plan = graph._tile_plan, False
+        fam_gather = measure()
+        graph._tile_plan = plan
     # the hand-written fp32-MFMA GEMMs (csrc/gemm.hip, gemm_tn.hip): forward product of the embedding MLP with the
     # BatchNorm-statistics epilogue (the largest GEMM of the step) and the layer-2 v_mlp weight gradient
     def _time(fn, it=30):
@@ -134,16 +149,21 @@ def apply_roofline(graph, grad, div, C, iters=200):
     # Second bound, the one that actually limits the kernel: every neighbour row is gathered
     # through the vector-memory (texture addresser / L1) path, 64 B/clk/CU.  Gathered bytes = 2 rows x 4C bytes per edge.
     gathered = 2 * 4 * C * E
+    gh = (fam_gather or fam)["div_curl_norm"]           # the gather-path kernel this bound applies to
     l1_peak = 64.0 * 256 * 2.4e9 / 1e9                      # GB/s: 64 B/clk/CU x 256 CUs x 2.4 GHz
-    l1 = dict(gathered_bytes=gathered, achieved=round(gathered / (head["us"] * 1e-6) / 1e9, 1), peak=round(l1_peak, 1),
-              unit="GB/s", frac=round(gathered / (head["us"] * 1e-6) / 1e9 / l1_peak, 4))
+    l1 = dict(gathered_bytes=gathered, achieved=round(gathered / (gh["us"] * 1e-6) / 1e9, 1), peak=round(l1_peak, 1),
+              unit="GB/s", frac=round(gathered / (gh["us"] * 1e-6) / 1e9 / l1_peak, 4),
+              note="gather-path kernel (dc_apply_div_curl_norm); the tiled kernel moves ~1/7 of these bytes through this path")
     return dict(bound="hbm", achieved=head["GBs"], peak=HBM_PEAK_GBS, unit="GB/s", frac=head["frac"],
                 traffic=traffic, traffic_tag=traffic_tag,
                 cache_level="Infinity-Cache resident (working set ~50 MB per launch < 256 MB L3): `achieved` is "
                             "algorithmic bytes / time against the HBM peak, the data mostly streams from L3 / fabric",
                 l1_gather=l1,
-                kernel="divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)", channels=C,
-                bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam, mfma=mfma)
+                kernel=("tile_fwd_kernel<DivCurlNormB> (dc_apply_div_curl_norm_tiled: fused ELL SpMM, neighbour rows in LDS "
+                        "from the per-batch tile plan)" if tiled else
+                        "divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)"), channels=C,
+                bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam, family_gather_path=fam_gather,
+                mfma=mfma)
 
 
 def _physical_cores():

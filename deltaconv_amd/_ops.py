@@ -13,6 +13,44 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
 
 
+# ---- forward applies / max aggregation: from the graph's tile plan when it applies (neighbour rows in LDS,
+# csrc/ell_tile.h), else through the gather path.  Same results bit for bit; `a`, `out` may be column blocks of wider
+# buffers (leading dimensions lda / ldo).
+def _tiled(graph, c, *tensors_lds):
+    """The graph's TilePlan if the 16-byte tiled path applies to these operands, else None."""
+    if c <= 0 or c % 64:
+        return None
+    for t, ld in tensors_lds:
+        if ld % 4 or t.data_ptr() % 16:
+            return None
+    return graph.tile_plan()
+
+
+def fwd_apply(name, op, a, c, lda, out, ldo):
+    """name in {'grad', 'div', 'div_curl_norm', 'hodge'}: dc_apply_<name>[_tiled](op, a[., c] -> out)."""
+    g = op.graph
+    plan = _tiled(g, c, (a, lda), (out, ldo))
+    if plan is not None:
+        lib.call(f"dc_apply_{name}_tiled", op.coefP(plan), plan.blob, g.nbr, *plan.args, a, c, lda, out, ldo)
+    else:
+        lib.call(f"dc_apply_{name}", op.coef, g.nbr, g.n, g.k, a, c, lda, out, ldo)
+
+
+def fwd_knn_max(g, h, c, ldh, out, ldo, arg, affine=None):
+    """max over the k neighbours (+ first maximal slot); affine = (scale, shift, slope) folds BatchNorm + activation."""
+    plan = _tiled(g, c, (h, ldh), (out, ldo), (arg, 4))
+    if plan is not None:
+        if affine is None:
+            lib.call("dc_knn_max_tiled", plan.blob, g.nbr, *plan.args, h, c, ldh, out, ldo, arg)
+        else:
+            lib.call("dc_knn_max_affine_tiled", plan.blob, g.nbr, *plan.args, h, c, ldh, affine[0], affine[1], affine[2],
+                     out, ldo, arg)
+    elif affine is None:
+        lib.call("dc_knn_max", g.nbr, g.n, g.k, h, c, ldh, out, ldo, arg)
+    else:
+        lib.call("dc_knn_max_affine", g.nbr, g.n, g.k, h, c, ldh, affine[0], affine[1], affine[2], out, ldo, arg)
+
+
 class _Apply(torch.autograd.Function):
     """kind in {'grad','div'}: y = A @ x with A in ELL form."""
 
@@ -25,11 +63,11 @@ class _Apply(torch.autograd.Function):
         if kind == 'grad':
             assert x.shape[0] == n, f"grad @ x: x has {x.shape[0]} rows, graph has {n} points"
             out = torch.empty(2 * n, c, dtype=torch.float32, device=x.device)
-            lib.call("dc_apply_grad", coef, graph.nbr, n, k, x, c, c, out, c)
+            fwd_apply("grad", op, x, c, c, out, c)
         else:
             assert x.shape[0] == 2 * n, f"div @ v: v has {x.shape[0]} rows, graph has {n} points"
             out = torch.empty(n, c, dtype=torch.float32, device=x.device)
-            lib.call("dc_apply_div", coef, graph.nbr, n, k, x, c, c, out, c)
+            fwd_apply("div", op, x, c, c, out, c)
         return out
 
     @staticmethod
@@ -56,7 +94,7 @@ class _DivCurlNorm(torch.autograd.Function):
         n, k, c = graph.n, graph.k, v.shape[1]
         assert v.shape[0] == 2 * n
         out = torch.empty(n, 3 * c, dtype=torch.float32, device=v.device)
-        lib.call("dc_apply_div_curl_norm", coef, graph.nbr, n, k, v, c, c, out, 3 * c)
+        fwd_apply("div_curl_norm", op, v, c, c, out, 3 * c)
         ctx.graph, ctx.op = graph, op
         ctx.save_for_backward(v)
         return out
@@ -83,7 +121,7 @@ class _Hodge(torch.autograd.Function):
         ld = dcn.shape[1]
         assert dcn.shape[0] == n and ld >= 2 * c
         out = torch.empty(2 * n, c, dtype=torch.float32, device=dcn.device)
-        lib.call("dc_apply_hodge", coef, graph.nbr, n, k, dcn, c, ld, out, c)
+        fwd_apply("hodge", op, dcn, c, ld, out, c)
         ctx.graph, ctx.op, ctx.c, ctx.ld = graph, op, c, ld
         return out
 
@@ -108,7 +146,7 @@ class _KnnMax(torch.autograd.Function):
         assert h.shape[0] == n
         out = torch.empty(n, c, dtype=torch.float32, device=h.device)
         arg = torch.empty(n, c, dtype=torch.uint8, device=h.device)
-        lib.call("dc_knn_max", graph.nbr, n, k, h, c, c, out, c, arg)
+        fwd_knn_max(graph, h, c, c, out, c, arg)
         ctx.graph = graph
         ctx.save_for_backward(arg)
         ctx.mark_non_differentiable(arg)

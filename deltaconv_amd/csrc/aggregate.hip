@@ -6,6 +6,7 @@
 #include <initializer_list>
 #include "common.h"
 #include "ell_stage.h"
+#include "ell_tile.h"
 
 namespace {
 using namespace dcell;
@@ -203,5 +204,39 @@ DC_EXPORT int dc_knn_sum_backward(const int32_t* tptr, const int32_t* tedge, int
     else
         launch_T<1>(n, C, nullptr, tptr, tedge, k, KnnSumT<1>{dout, (long)ldo, dh, (long)ldh, scale, accumulate, C}, s);
     DC_CHECK_LAUNCH("dc_knn_sum_backward");
+    return DC_OK;
+}
+
+// ---- max aggregation from a tile plan (tile_plan.h, ell_tile.h): same values and slots, rows from LDS ---------------
+DC_EXPORT int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k, int32_t P,
+                               const float* h, int32_t C, int64_t ldh, float* out, int64_t ldo, uint8_t* arg, void* stream) {
+    DC_REQUIRE(plan && nbr && h && out && arg, "dc_knn_max_tiled: null pointer");
+    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 1 && k <= 255 && (P == 32 || P == 64) && P * k <= 2048 && (P * k) % 8 == 0,
+               "dc_knn_max_tiled: bad size");
+    DC_REQUIRE(dctile::eligible(C, {(long)ldh, (long)ldo}, {h, out, arg}), "dc_knn_max_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
+    DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_max_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlan L = dc_tile_plan_layout(n, num_clouds, k, P);
+    dctile::launch<1>(L, plan, nullptr, nbr, C,
+                      dctile::KnnMaxB<false>{h, (long)ldh, 0, nullptr, nullptr, 0.f, out, (long)ldo, arg, (long)C},
+                      static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_knn_max_tiled");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k,
+                                      int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale,
+                                      const float* shift, float slope, float* out, int64_t ldo, uint8_t* arg, void* stream) {
+    DC_REQUIRE(plan && nbr && h && scale && shift && out && arg, "dc_knn_max_affine_tiled: null pointer");
+    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 1 && k <= 255 && (P == 32 || P == 64) && P * k <= 2048 && (P * k) % 8 == 0,
+               "dc_knn_max_affine_tiled: bad size");
+    DC_REQUIRE(dctile::eligible(C, {(long)ldh, (long)ldo}, {h, out, arg}), "dc_knn_max_affine_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
+    DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_max_affine_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlan L = dc_tile_plan_layout(n, num_clouds, k, P);
+    dctile::launch<1>(L, plan, nullptr, nbr, C,
+                      dctile::KnnMaxB<true>{h, (long)ldh, 0, scale, shift, slope, out, (long)ldo, arg, (long)C},
+                      static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_knn_max_affine_tiled");
     return DC_OK;
 }

@@ -12,6 +12,7 @@
 #include <initializer_list>
 #include "common.h"
 #include "ell_stage.h"
+#include "ell_tile.h"
 
 namespace {
 using namespace dcell;
@@ -122,3 +123,48 @@ DC_EXPORT int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, con
     DC_CHECK_LAUNCH("dc_apply_div_curl_norm_T");
     return DC_OK;
 }
+
+// ---- forward, from a tile plan (tile_plan.h, ell_tile.h) ---------------------------------------------------------
+// Same results bit for bit as the entry points above (same FMAs, same slot order); the neighbour rows come from LDS.
+// coefP = the operator's coefficients in tile order (dc_tile_permute_coef); nbr is read only by tiles whose unique rows
+// exceed the LDS capacity.  C must be a multiple of 64 and rows 16-byte aligned (otherwise DC_ERR_ARG: use the entry
+// points above).
+namespace {
+int check_tiled(const char* name, const void* a, const void* b, const void* c, const void* d, const void* e, int n, int nc,
+                int k, int P, int C, bool ok16) {
+    if (!a || !b || !c || !d || !e) {
+        dc_set_error("%s: null pointer", name);
+        return DC_ERR_ARG;
+    }
+    if (n < 0 || nc < 0 || k < 1 || (P != 32 && P != 64) || P * k > 2048 || (P * k) % 8) {
+        dc_set_error("%s: bad size n=%d num_clouds=%d k=%d P=%d", name, n, nc, k, P);
+        return DC_ERR_ARG;
+    }
+    if (!ok16) {
+        dc_set_error("%s: needs C %% 64 == 0 and 16-byte aligned rows (C=%d)", name, C);
+        return DC_ERR_ARG;
+    }
+    return DC_OK;
+}
+}  // namespace
+
+#define DC_TILED_ENTRY(FN, BODY, R, LDJ, HS, MINLDI, MINLDO, ...)                                                     \
+    DC_EXPORT int FN(const float* coefP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,     \
+                     int32_t k, int32_t P, const float* in, int32_t C, int64_t ldi, float* out, int64_t ldo,          \
+                     void* stream) {                                                                                 \
+        if (int rc = check_tiled(#FN, coefP, plan, nbr, in, out, n, num_clouds, k, P, C,                              \
+                                 dctile::eligible(C, {(long)ldi, (long)ldo}, {in, out, coefP})))                      \
+            return rc;                                                                                               \
+        DC_REQUIRE(ldi >= (MINLDI) && ldo >= (MINLDO), #FN ": leading dimension smaller than the row");              \
+        if (n == 0) return DC_OK;                                                                                    \
+        const DcTilePlan L = dc_tile_plan_layout(n, num_clouds, k, P);                                               \
+        dctile::launch<R>(L, plan, coefP, nbr, C, dctile::BODY{in, (long)(LDJ), (long)(HS), out, (long)ldo __VA_ARGS__}, \
+                          static_cast<hipStream_t>(stream));                                                         \
+        DC_CHECK_LAUNCH(#FN);                                                                                        \
+        return DC_OK;                                                                                                \
+    }
+
+DC_TILED_ENTRY(dc_apply_grad_tiled, GradB, 1, ldi, 0, C, C)
+DC_TILED_ENTRY(dc_apply_div_tiled, DivB, 2, 2 * ldi, ldi, C, C)
+DC_TILED_ENTRY(dc_apply_div_curl_norm_tiled, DivCurlNormB, 2, 2 * ldi, ldi, C, 3 * C, , C)
+DC_TILED_ENTRY(dc_apply_hodge_tiled, HodgeB, 2, ldi, C, 2 * C, C)

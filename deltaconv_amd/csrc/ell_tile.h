@@ -1,0 +1,285 @@
+// Forward ELL applies / max-aggregation from a tile plan (tile_plan.h): the unique neighbour rows of a tile of P
+// points are brought into LDS once by LDS-DMA, the k-loop reads LDS only.
+//
+// Measured on MI355X (tools/tile_lab.hip, profiles/r03*_tile_lab*.txt), B = 32 x 1024 points, k = 20, C = 64:
+//   [div|curl|norm] 17.7 us staged -> 12.4 us (0.35 -> 0.50 of 8 TB/s), grad 10.0 -> 6.8 us (0.41 -> 0.60); texture-
+//   addresser busy cycles 38.5 k -> 14.5 k per launch, LDS bank conflicts 0.
+// Mapping: workgroup = (tile, 64-channel slab), thread = (point of the tile, 4 channels); 16 lanes per point.
+//   * every lane group of a ds_read_b128 covers the 16 different 16-byte columns of 256-byte rows, so random rows are
+//     bank-conflict free (MI355X_MICROARCH.md, LDS table: 256 B/clk/CU; the gather path delivers ~49);
+//   * rows, coefficients (tile order: dc_tile_permute_coef) and local indices arrive by `global_load_lds_dwordx4`
+//     (no staging registers, no ds_write: a register-staged variant of the same kernel ran 2x slower, r03a);
+//   * all row ids are loaded before the first DMA piece is issued (hipcc waits vmcnt(0) at the first use of an
+//     ordinary load's result while DMA pieces are in flight, which would serialise the pieces);
+//   * outputs leave with non-temporal stores: a plain store leaves the whole output dirty in the per-XCD L2 until the
+//     end-of-kernel write-back; streaming it out during the kernel is worth 1.5 - 3.5 us per launch (r03e);
+//   * tiles whose unique rows exceed the LDS capacity (or the plan's list) fetch the excess rows from global memory by
+//     neighbour id -- correct for any graph, fast for the spatially coherent ones a kNN graph gives.
+// Same FMAs in the same slot order as the staged kernels (ell_math.h): results are bit-identical (tests/test_gpu_tile.py).
+#pragma once
+#include <initializer_list>
+#include "common.h"
+#include "ell_math.h"
+#include "tile_plan.h"
+
+namespace dctile {
+using dcell::G2;
+using dcell::Vec;
+using dcell::vfma;
+using dcell::vzero;
+
+constexpr int CS = 64;        // channels per slab: 16 lanes x 4
+constexpr int CAP = 248;      // unique rows of a tile kept in LDS
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void store_nt(float* p, const Vec<4>& a) {
+    __builtin_nontemporal_store(*reinterpret_cast<const f4v*>(&a), reinterpret_cast<f4v*>(p));
+}
+__device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int R, int P>
+struct Geom {
+    static constexpr int NT = P * 16, NW = NT / 64;
+    static constexpr int CAPR = (CAP * R + 4 * NW - 1) / (4 * NW) * (4 * NW);   // capacity in 256-byte pieces
+    static constexpr int RIT = CAPR / (4 * NW);                                  // DMA instructions per wave
+};
+inline size_t chunk1k(size_t bytes) { return (bytes + 1023) / 1024 * 1024; }
+template <int R, int P>
+inline size_t lds_bytes(int k, bool coef) {
+    return (size_t)Geom<R, P>::CAPR * 256 + (coef ? chunk1k((size_t)P * k * 8) : 0) + chunk1k((size_t)P * k * 2) + P * 4 + P * 2 + 16;
+}
+
+// BODY: per-thread accumulator object, copied from the kernel argument
+//   static constexpr bool COEF, SELF;
+//   const float* in; long ldj, hs;             piece h of row j = in + j * ldj + h * hs
+//   void init(int c);  void step(int s, G2 g, const Vec<4>& p0, const Vec<4>& p1);
+//   void finish(long i, int c, const Vec<4>& s0, const Vec<4>& s1);
+template <int R, int P, class BODY>
+__global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const int* __restrict__ plan,
+                                                          const float* __restrict__ coefP, const int* __restrict__ nbr,
+                                                          int slabs, int remap, BODY body) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using GM = Geom<R, P>;
+    constexpr int NW = GM::NW, CAPR = GM::CAPR, RIT = GM::RIT;
+    const long b = dc_xcd_block(remap);
+    const long tile = b / slabs;
+    const int cb = (int)(b - tile * slabs) * CS;
+    const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+    const int wave = tid >> 6, lane64 = tid & 63;
+    const int k = L.k, PK = L.PK;
+    const size_t cfb_bytes = BODY::COEF ? (size_t)((PK * 8 + 1023) / 1024 * 1024) : 0;
+    float* rows = reinterpret_cast<float*>(smem);                         // [CAPR][64]
+    char* cfb = smem + (size_t)CAPR * 256;                                // [PK] G2
+    char* lcb = cfb + cfb_bytes;                                          // [PK] u16
+    int* pts = reinterpret_cast<int*>(lcb + (PK * 2 + 1023) / 1024 * 1024);   // [P]
+    unsigned short* sl = reinterpret_cast<unsigned short*>(pts + P);     // [P]
+    const int* uq = plan + L.o_uniq + tile * PK;
+    // row ids: one round trip; the unique count is read beside them, not before them (the list's tail repeats its last id)
+    int rid[RIT];
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+        const int r = min((wave + it * NW) * 4 + (lane64 >> 4), PK * R - 1);
+        rid[it] = uq[r / R];
+    }
+    const int U = plan[L.o_nu + tile];
+    if (U == 0) return;                                                   // empty tile (block-uniform)
+    const int UL = min(U, CAP), nrow = UL * R;
+    int mypt = -1;
+    unsigned short mysl = 0;
+    if (tid < P) {
+        mypt = plan[L.o_pts + tile * P + tid];
+        mysl = reinterpret_cast<const unsigned short*>(plan + L.o_self)[tile * P + tid];
+    }
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) asm volatile("" : "+v"(rid[it]));   // the id waits end here, before the first DMA piece
+    asm volatile("" : "+v"(mypt));
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+        const int r0 = (wave + it * NW) * 4;
+        if (r0 < nrow) {
+            const int h = R == 2 ? (lane64 >> 4) & 1 : 0;                 // piece of the row this lane group loads
+            dma16(body.in + (long)rid[it] * body.ldj + h * body.hs + cb + l16 * 4, rows + r0 * 64);
+        }
+    }
+    {   // coefficients and local indices of the tile: contiguous -> whole 1-KiB chunks (tail lanes re-read the end)
+        if (BODY::COEF) {
+            const char* g = reinterpret_cast<const char*>(coefP) + (size_t)tile * PK * 8;
+            for (int c = wave; c * 1024 < PK * 8; c += NW) dma16(g + min(c * 1024 + lane64 * 16, PK * 8 - 16), cfb + c * 1024);
+        }
+        const char* g = reinterpret_cast<const char*>(plan + L.o_loc) + (size_t)tile * PK * 2;
+        for (int c = wave; c * 1024 < PK * 2; c += NW) dma16(g + min(c * 1024 + lane64 * 16, PK * 2 - 16), lcb + c * 1024);
+    }
+    if (tid < P) {
+        pts[tid] = mypt;
+        sl[tid] = mysl;
+    }
+    __syncthreads();
+    const long i = pts[grp];
+    if (i < 0) return;
+    const G2* cp = reinterpret_cast<const G2*>(cfb) + grp * k;
+    const unsigned short* lp = reinterpret_cast<const unsigned short*>(lcb) + grp * k;
+    const int c = cb + l16 * 4;
+    body.init(c);
+    Vec<4> s0 = vzero<4>(), s1 = vzero<4>();
+    if (U <= CAP) {
+#pragma unroll 4
+        for (int s = 0; s < k; ++s) {
+            const int l = lp[s];
+            const Vec<4> p0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
+            const Vec<4> p1 = R == 2 ? *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4) : p0;
+            body.step(s, BODY::COEF ? cp[s] : G2{0.f, 0.f}, p0, p1);
+        }
+        if (BODY::SELF) {
+            const int l = sl[grp];
+            s0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
+            s1 = *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4);
+        }
+    } else {                                                              // more unique rows than LDS holds: the rest by id
+#pragma unroll 1
+        for (int s = 0; s < k; ++s) {
+            const int l = lp[s];
+            Vec<4> p0, p1;
+            if (l < CAP) {
+                p0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
+                p1 = R == 2 ? *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4) : p0;
+            } else {
+                const float* g = body.in + (long)nbr[i * k + s] * body.ldj + c;
+                p0 = dcell::vload<4>(g);
+                p1 = R == 2 ? dcell::vload<4>(g + body.hs) : p0;
+            }
+            body.step(s, BODY::COEF ? cp[s] : G2{0.f, 0.f}, p0, p1);
+        }
+        if (BODY::SELF) {
+            const float* g = body.in + i * body.ldj + c;
+            s0 = dcell::vload<4>(g);
+            s1 = dcell::vload<4>(g + body.hs);
+        }
+    }
+    body.finish(i, c, s0, s1);
+}
+
+// ---- bodies (the arithmetic of ell_math.h, slot by slot) ---------------------------------------------------------
+// grad @ x (ell_math.h: grad_fwd)
+struct GradB {
+    static constexpr bool COEF = true, SELF = false;
+    const float* in; long ldj, hs; float* out; long ldo;
+    Vec<4> au, av;
+    __device__ void init(int) { au = vzero<4>(); av = vzero<4>(); }
+    __device__ void step(int, G2 g, const Vec<4>& x, const Vec<4>&) { vfma<4>(au, g.a, x); vfma<4>(av, g.b, x); }
+    __device__ void finish(long i, int c, const Vec<4>&, const Vec<4>&) {
+        store_nt(out + (2 * i) * ldo + c, au);
+        store_nt(out + (2 * i + 1) * ldo + c, av);
+    }
+};
+// div @ v (div_fwd)
+struct DivB {
+    static constexpr bool COEF = true, SELF = false;
+    const float* in; long ldj, hs; float* out; long ldo;
+    Vec<4> acc;
+    __device__ void init(int) { acc = vzero<4>(); }
+    __device__ void step(int, G2 d, const Vec<4>& vu, const Vec<4>& vv) { vfma<4>(acc, d.a, vu); vfma<4>(acc, d.b, vv); }
+    __device__ void finish(long i, int c, const Vec<4>&, const Vec<4>&) { store_nt(out + i * ldo + c, acc); }
+};
+// [div v | curl v | norm v] (divcurlnorm_fwd)
+struct DivCurlNormB {
+    static constexpr bool COEF = true, SELF = true;
+    const float* in; long ldj, hs; float* out; long ldo; int C;
+    Vec<4> dv, cv;
+    __device__ void init(int) { dv = vzero<4>(); cv = vzero<4>(); }
+    __device__ void step(int, G2 d, const Vec<4>& vu, const Vec<4>& vv) {
+        vfma<4>(dv, d.a, vu);
+        vfma<4>(dv, d.b, vv);
+        vfma<4>(cv, d.a, vv);
+        vfma<4>(cv, -d.b, vu);
+    }
+    __device__ void finish(long i, int c, const Vec<4>& ou, const Vec<4>& ov) {
+        Vec<4> nv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nv.v[q] = sqrtf(fmaf(ou.v[q], ou.v[q], ov.v[q] * ov.v[q]));
+        store_nt(out + i * ldo + c, dv);
+        store_nt(out + i * ldo + C + c, cv);
+        store_nt(out + i * ldo + 2 * C + c, nv);
+    }
+};
+// hodge Laplacian from [div v | curl v] (hodge_fwd): pieces = the two column blocks of one row
+struct HodgeB {
+    static constexpr bool COEF = true, SELF = false;
+    const float* in; long ldj, hs; float* out; long ldo;
+    Vec<4> hu, hv;
+    __device__ void init(int) { hu = vzero<4>(); hv = vzero<4>(); }
+    __device__ void step(int, G2 g, const Vec<4>& dv, const Vec<4>& cv) {
+        vfma<4>(hu, -g.a, dv);
+        vfma<4>(hu, g.b, cv);
+        vfma<4>(hv, -g.b, dv);
+        vfma<4>(hv, -g.a, cv);
+    }
+    __device__ void finish(long i, int c, const Vec<4>&, const Vec<4>&) {
+        store_nt(out + (2 * i) * ldo + c, hu);
+        store_nt(out + (2 * i + 1) * ldo + c, hv);
+    }
+};
+// max over the k neighbours, first maximal slot (knn_max_fwd / knn_max_affine_fwd); AFFINE: y = act(scale * h + shift)
+template <bool AFFINE>
+struct KnnMaxB {
+    static constexpr bool COEF = false, SELF = false;
+    const float* in; long ldj, hs; const float *scale, *shift; float slope; float* out; long ldo; unsigned char* arg; long lda;
+    Vec<4> best; unsigned slot[4]; float sc[4], sh[4];
+    __device__ void init(int c) {
+        if (AFFINE)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { sc[q] = scale[c + q]; sh[q] = shift[c + q]; }
+    }
+    __device__ void step(int s, G2, const Vec<4>& h, const Vec<4>&) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float y = h.v[q];
+            if (AFFINE) {
+                const float z = fmaf(sc[q], y, sh[q]);
+                y = z > 0.f ? z : slope * z;
+            }
+            const bool up = s == 0 || y > best.v[q];
+            best.v[q] = up ? y : best.v[q];
+            slot[q] = up ? (unsigned)s : slot[q];
+        }
+    }
+    __device__ void finish(long i, int c, const Vec<4>&, const Vec<4>&) {
+        store_nt(out + i * ldo + c, best);
+        // the four slot bytes as one 32-bit store (c and lda are multiples of 4)
+        const unsigned w = slot[0] | (slot[1] << 8) | (slot[2] << 16) | (slot[3] << 24);
+        __builtin_nontemporal_store(w, reinterpret_cast<unsigned*>(arg + i * lda + c));
+    }
+};
+
+template <int R, int P, class BODY>
+inline void launch_one(const DcTilePlan& L, const int* plan, const float* coefP, const int* nbr, int C, BODY body, hipStream_t s) {
+    const int slabs = C / CS;
+    const size_t lds = lds_bytes<R, P>(L.k, BODY::COEF);
+    static bool attr_set = false;                       // > 64 KiB of dynamic LDS needs the attribute once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fwd_kernel<R, P, BODY>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((tile_fwd_kernel<R, P, BODY>), dim3((unsigned)L.T * slabs), dim3(P * 16), lds, s, L, plan, coefP, nbr, slabs,
+                       dc_option(DC_OPT_XCD_REMAP), body);
+}
+template <int R, class BODY>
+inline void launch(const DcTilePlan& L, const int* plan, const float* coefP, const int* nbr, int C, BODY body, hipStream_t s) {
+    if (L.P == 64) launch_one<R, 64, BODY>(L, plan, coefP, nbr, C, body, s);
+    else launch_one<R, 32, BODY>(L, plan, coefP, nbr, C, body, s);
+}
+
+// 16-byte path only: channels a multiple of the slab, leading dimensions and bases 16-byte aligned
+inline bool eligible(int C, std::initializer_list<long> lds, std::initializer_list<const void*> ptrs) {
+    if (C <= 0 || C % CS) return false;
+    for (long l : lds)
+        if (l % 4) return false;
+    for (const void* p : ptrs)
+        if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+    return true;
+}
+
+}  // namespace dctile

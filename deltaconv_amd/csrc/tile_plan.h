@@ -1,0 +1,52 @@
+// Tile plan of a kNN graph: the per-batch structure behind the LDS-deduplicated forward applies (ell_tile.h).
+//
+// Why.  A forward apply gathers k neighbour rows per point: k = 20 times the compulsory read volume, all of it
+// through the texture addresser / L1 path, which -- not HBM -- bounds the staged kernels (profiles/r02n, r03b).
+// Points that are close in space share most of their neighbours, so the points of a cloud are cut into TILES of P
+// consecutive points of a Morton (Z-curve) order of their positions; the UNIQUE neighbour rows of a tile (~170 for
+// P = 64 instead of 1280) are brought into LDS once by LDS-DMA and the k-loop reads LDS only (conflict-free: 16
+// lanes x 16 bytes per 256-byte row).  Tensors keep their point order: a tile is a LIST of point ids.
+//
+// The plan depends only on positions + graph, is built once per batch beside the CSC (tileplan.hip) and is one
+// int32 device blob whose section offsets follow from (num_points, num_clouds, k, P):
+//   pts  [T][P]     int32   point ids of the tile in Morton order, -1 = padding (last tile of a cloud / unused tile)
+//   nu   [T]        int32   number of unique rows U of the tile (0 = empty tile)
+//   uniq [T][P*k]   int32   the unique row ids, ascending (the tile's own points are members); tail = last id
+//   loc  [T][P*k]   uint16  tile-local index of neighbour (p, s) in uniq
+//   self [T][P]     uint16  tile-local index of the point itself
+// T = ceil(num_points / P) + num_clouds is an upper bound known on the host without a sync (ragged clouds: cloud b
+// owns the tiles floor(ptr[b] / P) + b + [0, ceil(N_b / P)); tile ids in between stay empty).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define DC_TP_HD __host__ __device__ __forceinline__
+#else
+#define DC_TP_HD inline
+#endif
+
+struct DcTilePlan {
+    int T, P, k, PK;
+    long o_pts, o_nu, o_uniq, o_loc, o_self, words;   // section offsets in int32 words (multiples of 4: 16-byte aligned)
+};
+
+DC_TP_HD long dc_tp_round4(long w) { return (w + 3) & ~3L; }
+
+DC_TP_HD DcTilePlan dc_tile_plan_layout(int num_points, int num_clouds, int k, int P) {
+    DcTilePlan p;
+    p.P = P;
+    p.k = k;
+    p.PK = P * k;
+    p.T = (num_points + P - 1) / P + num_clouds;
+    long w = 0;
+    p.o_pts = w;   w = dc_tp_round4(w + (long)p.T * P);
+    p.o_nu = w;    w = dc_tp_round4(w + p.T);
+    p.o_uniq = w;  w = dc_tp_round4(w + (long)p.T * p.PK);
+    p.o_loc = w;   w = dc_tp_round4(w + ((long)p.T * p.PK + 1) / 2);
+    p.o_self = w;  w = dc_tp_round4(w + ((long)p.T * P + 1) / 2);
+    p.words = w + 64;                                 // slack: clamped tail chunks of the LDS-DMA copies stay inside
+    return p;
+}
+
+// first tile of cloud b (ptr_b = first point of the cloud)
+DC_TP_HD int dc_tile_base(int ptr_b, int b, int P) { return ptr_b / P + b; }

@@ -102,7 +102,8 @@ def convert_sync_batchnorm(module):
     for name, child in list(module.named_children()):
         if type(child) is torch.nn.BatchNorm1d:
             new = SyncBatchNorm1d(child.num_features, child.eps, child.momentum, child.affine, child.track_running_stats)
-            new.load_state_dict(child.state_dict())
+            for key, buf in child._buffers.items():          # the SAME tensors (device, dtype, identity), not copies
+                new._buffers[key] = buf
             if child.affine:
                 new.weight, new.bias = child.weight, child.bias
             new.train(child.training)

@@ -22,6 +22,15 @@ class SparseOp:
         assert kind in ("grad", "div")
         self.kind, self.graph, self.coef = kind, graph, coef
         self._coefT = None
+        self._coefP = None
+
+    def coefP(self, plan):
+        """Coefficients in the tile order of `plan` (graph.tile_plan()) for the tiled forward applies; built once."""
+        if self._coefP is None or self._coefP[0] is not plan:
+            out = torch.empty(plan.tiles, plan.P * plan.k, 2, dtype=torch.float32, device=self.coef.device)
+            lib.call("dc_tile_permute_coef", self.coef, plan.blob, *plan.args, out)
+            self._coefP = (plan, out)
+        return self._coefP[1]
 
     def coefT(self):
         """Coefficients in CSC order (for the transposed applies of the backward pass); built once."""
@@ -93,6 +102,8 @@ def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel
     g = _graph_from(edge_index, n, batch=batch)
     if batch is not None and g.num_clouds == 1 and not isinstance(edge_index, Graph):
         g.ptr, g.num_clouds, g.max_cloud = _ptr_from_batch(batch, n, pos.device)
+    if g.pos is None:
+        g.pos = pos           # the tile plan of the forward applies orders the points along a Morton curve
     G = torch.empty(n, g.k, 2, dtype=torch.float32, device=pos.device)
     D = torch.empty(n, g.k, 2, dtype=torch.float32, device=pos.device)
     nbytes = lib.raw("dc_mls_workspace_bytes")(g.num_clouds, n)

@@ -43,13 +43,72 @@ def _min_cloud(ptr_info):
     return mn
 
 
+class TilePlan:
+    """Per-batch tile plan of a graph (deltaconv_amd/csrc/tile_plan.h): tiles of P points that are consecutive on a
+    Morton curve, the unique neighbour rows of each tile and tile-local neighbour indices.  The forward applies and the
+    max-aggregation run from it with their neighbour rows in LDS (csrc/ell_tile.h)."""
+
+    def __init__(self, graph, blob, P):
+        self.blob, self.P = blob, P
+        self.n, self.k, self.num_clouds = graph.n, graph.k, graph.num_clouds
+        self.tiles = int(lib.raw("dc_tile_plan_tiles")(graph.n, graph.num_clouds, P))
+
+    @property
+    def args(self):
+        """(n, num_clouds, k, P): the size arguments every tiled entry point takes after (plan, nbr)."""
+        return self.n, self.num_clouds, self.k, self.P
+
+    def section(self, name):
+        """View of one section of the blob (tests / debugging): 'pts' [T,P], 'nu' [T], 'uniq' [T,P*k] int32;
+        'loc' [T,P*k], 'self' [T,P] uint16 (as int32 tensors)."""
+        T, P, PK = self.tiles, self.P, self.P * self.k
+        r4 = lambda w: (w + 3) & ~3
+        o_pts = 0
+        o_nu = r4(o_pts + T * P)
+        o_uniq = r4(o_nu + T)
+        o_loc = r4(o_uniq + T * PK)
+        o_self = r4(o_loc + (T * PK + 1) // 2)
+        if name == "pts":
+            return self.blob[o_pts:o_pts + T * P].view(T, P)
+        if name == "nu":
+            return self.blob[o_nu:o_nu + T]
+        if name == "uniq":
+            return self.blob[o_uniq:o_uniq + T * PK].view(T, PK)
+        if name == "loc":
+            return self.blob[o_loc:o_loc + (T * PK + 1) // 2].view(torch.int16)[:T * PK].view(T, PK).to(torch.int32) & 0xffff
+        if name == "self":
+            return self.blob[o_self:o_self + (T * P + 1) // 2].view(torch.int16)[:T * P].view(T, P).to(torch.int32) & 0xffff
+        raise KeyError(name)
+
+
+# Forward applies / max-aggregation from a tile plan (True) or through the gather path (False): A/B switch, same results.
+USE_TILE_PLAN = [True]
+
+
 class Graph:
-    def __init__(self, nbr, ptr, num_clouds, max_cloud):
+    def __init__(self, nbr, ptr, num_clouds, max_cloud, pos=None):
         self.nbr = nbr                                    # [Nt,k] int32, global ids
         self.n, self.k = int(nbr.shape[0]), int(nbr.shape[1])
         self.ptr, self.num_clouds, self.max_cloud = ptr, num_clouds, max_cloud
+        self.pos = pos                                    # positions the graph was built on (tile plan: Morton order)
         self._csc = None
         self._edge_index = None
+        self._tile_plan = None
+
+    def tile_plan(self):
+        """TilePlan of this graph, built once (stream-ordered kernels: capturable), or None when the plan does not
+        apply: positions unknown, clouds beyond the builder's limit, or the switch is off."""
+        if self._tile_plan is None:
+            self._tile_plan = False
+            P = 64 if self.k <= 24 else 32
+            if (USE_TILE_PLAN[0] and self.pos is not None and self.nbr.is_cuda and self.n > 0
+                    and self.max_cloud <= int(lib.raw("dc_tile_plan_max_cloud")()) and P * self.k <= 2048):
+                words = int(lib.raw("dc_tile_plan_words")(self.n, self.num_clouds, self.k, P))
+                blob = torch.empty(words, dtype=torch.int32, device=self.nbr.device)
+                lib.call("dc_tile_plan_build", self.pos, self.nbr, self.ptr, self.num_clouds, self.n, self.max_cloud,
+                         self.k, P, blob)
+                self._tile_plan = TilePlan(self, blob, P)
+        return self._tile_plan or None
 
     @staticmethod
     def knn(pos, k, batch=None, ptr_info=None, lanes_per_query=0):
@@ -67,7 +126,7 @@ class Graph:
             raise ValueError(f"knn graph: every cloud needs at least k = {k} points, the smallest has {mn}")
         nbr = torch.empty(n, k, dtype=torch.int32, device=pos.device)
         lib.call("dc_knn", pos, ptr, nc, mx, k, lanes_per_query, nbr)
-        return Graph(nbr, ptr, nc, mx)
+        return Graph(nbr, ptr, nc, mx, pos=pos)
 
     @staticmethod
     def from_edge_index(edge_index, num_points, k=None, batch=None, ptr_info=None):

@@ -24,6 +24,8 @@ import os
 
 import torch
 
+from .nn.fused import invalidate_eval_coeffs
+
 _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 
 
@@ -55,6 +57,7 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.loss, self.out = self._step()
         torch.cuda.synchronize()
+        invalidate_eval_coeffs()
         self.grads = [(p, p.grad) for p in self.params if p.grad is not None]   # rewritten by every replay
 
     def _zero(self):
@@ -84,6 +87,7 @@ class GraphedTrainStep:
         if batch is not None:
             self.load(batch)
         self.graph.replay()
+        invalidate_eval_coeffs()      # the replay moved running statistics (and parameters) without a version bump
         for p, g in self.grads:       # a gradient reducer may have re-pointed .grad at its own buffer
             p.grad = g
         return self.loss

@@ -70,13 +70,23 @@ def _sync_stats(kernel_args, c, rows, dev, group):
     return dp.all_reduce_stats(local.clone(), group), local
 
 
+_EVAL_EPOCH = [0]
+
+
+def invalidate_eval_coeffs():
+    """Drop every cached inference-mode BatchNorm map.  Needed whenever parameters / running statistics change through
+    raw pointers, i.e. without a tensor version bump: a HIP-graph replay of a training step (graph_step.py)."""
+    _EVAL_EPOCH[0] += 1
+
+
 def eval_coeffs(gamma, beta, rm, rv, eps, c):
     """-> coef[4, c] = (mean, invstd, scale, shift) of an inference-mode BatchNorm: the layer folded to ONE per-channel
     affine map (scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale) that the CONSUMING kernel
     applies (max-aggregation gather, activation + residual, pooling) -- in eval mode no BatchNorm pass exists.  The
     rows depend only on the checkpoint: under torch.no_grad() they are computed once and kept on the running-mean
-    buffer until any of the tensors changes (in-place update = version bump, .to(device) / load = new storage)."""
-    key = (rm._version, rv._version, rm.data_ptr(), rv.data_ptr(), float(eps),
+    buffer until any of the tensors changes (in-place update = version bump, .to(device) / load = new storage, graph
+    replay of a training step = invalidate_eval_coeffs(): a replay writes through raw pointers, no version moves)."""
+    key = (_EVAL_EPOCH[0], rm._version, rv._version, rm.data_ptr(), rv.data_ptr(), float(eps),
            None if gamma is None else (gamma._version, gamma.data_ptr()),
            None if beta is None else (beta._version, beta.data_ptr()))
     cacheable = not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing()
@@ -94,6 +104,14 @@ def check_bn_rows(bn, rows):
     """torch.nn.functional.batch_norm refuses a train-mode batch with one value per channel (the reference
     hits this at B = 1 in its head: deltaconv/nn/nonlin.py:29-30, SURVEY.md section 8(d) C1 caveat); same here."""
     if bn.training and int(rows) <= 1:
+        group = sync_group()
+        if group is not None:
+            # synchronised statistics span the GLOBAL batch: a rank may hold a single row (one cloud per rank in the
+            # categorical head of the segmentation net, deltaconv_amd/dp.py); the all-reduced count is on the device,
+            # so only the case that is decidable without a host sync is refused here
+            import torch.distributed as dist
+            if dist.get_world_size(group) > 1:
+                return
         raise ValueError(f"Expected more than 1 value per channel when training, got input size [1, "
                          f"{bn.num_features}, {int(rows)}]")
 

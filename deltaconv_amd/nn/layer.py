@@ -29,6 +29,7 @@ BatchNorm statistics of the block in their epilogue; csrc/gemm_tn.hip weight gra
 import torch
 
 from .._lib import lib
+from .. import _ops
 from . import fused
 
 _F32 = torch.float32
@@ -59,11 +60,14 @@ class LayerCfg:
 
 def _adopt(t, rows, cols, width):
     """The buffer [rows, width] whose left `cols` columns ARE `t` (t was produced by the previous layer inside this
-    layer's operand buffer), or None."""
+    layer's operand buffer), or None.  Only buffers that the previous layer created FOR chaining qualify (they carry
+    the `_dc_chain` mark set in forward): a user tensor that merely looks like the left columns of a wider buffer is
+    copied, never overwritten in place."""
     buf = t._base
-    if (buf is not None and buf.dim() == 2 and tuple(buf.shape) == (rows, width) and tuple(t.shape) == (rows, cols)
+    if (buf is not None and getattr(buf, "_dc_chain", False) and buf.dim() == 2 and tuple(buf.shape) == (rows, width) and tuple(t.shape) == (rows, cols)
             and t.stride(0) == width and t.stride(1) == 1 and t.dtype == _F32 and buf.dtype == _F32
             and buf.is_contiguous() and buf.data_ptr() == t.data_ptr()):
+        buf._dc_chain = False      # one adoption only: a second consumer of the same x' / v' gets its own copy
         return buf
     return None
 
@@ -120,7 +124,6 @@ class DeltaConvLayerFn(torch.autograd.Function):
         ci = x.shape[1]
         f32 = dict(dtype=_F32, device=dev)
         call = lib.call
-        G, D = cfg.grad.coef, cfg.div.coef
         nm = 0 if cfg.bns_m is None else len(cfg.bns_m)
         ns = len(cfg.bns_s)
         nv = len(cfg.bns_v) if cfg.vector else 0
@@ -163,7 +166,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
             else:
                 hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
                 arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
-                call("dc_knn_max_affine", g.nbr, n, k, hm, co, co, coef_m[2], coef_m[3], slope_m, x_max, co, arg)
+                _ops.fwd_knn_max(g, hm, co, co, x_max, co, arg, affine=(coef_m[2], coef_m[3], slope_m))
                 max_saved = (arg,)
                 saved_m.append((inp, hm, coef_m, use_m))
 
@@ -172,7 +175,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
         if x_cat is None:
             x_cat = torch.empty(n, 4 * ci, **f32)
             x_cat[:, :ci].copy_(x)
-        call("dc_apply_div_curl_norm", D, g.nbr, n, k, v, ci, ldv, x_cat[:, ci:], 4 * ci)
+        _ops.fwd_apply("div_curl_norm", cfg.div, v, ci, ldv, x_cat[:, ci:], 4 * ci)
         inp = x_cat
         for (W, gs, bs), bn, slope in zip(ps[:-1], cfg.bns_s[:-1], cfg.slopes_s[:-1]):
             h, coef, use = fused.linear_stats(inp, W, bn, gs, bs)
@@ -185,6 +188,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
         saved_s.append((inp, hs, coef_s, use_s))
         if cfg.chain is not None:
             xbuf = torch.empty(n, cfg.chain[0], **f32)
+            xbuf._dc_chain = True
             x_new = xbuf[:, :co]
         else:
             x_new = torch.empty(n, co, **f32)
@@ -203,10 +207,11 @@ class DeltaConvLayerFn(torch.autograd.Function):
             if v_cat is None:
                 v_cat = torch.empty(2 * n, K, **f32)
                 v_cat[:, :ci].copy_(v)
-            call("dc_apply_hodge", G, g.nbr, n, k, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
-            call("dc_apply_grad", G, g.nbr, n, k, x_new, co, ldxn, v_cat[:, 2 * ci:], K)
+            _ops.fwd_apply("hodge", cfg.grad, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
+            _ops.fwd_apply("grad", cfg.grad, x_new, co, ldxn, v_cat[:, 2 * ci:], K)
             if cfg.chain is not None and cfg.chain[1] is not None:
                 vbuf = torch.empty(2 * n, cfg.chain[1], **f32)
+                vbuf._dc_chain = True
                 v_new = vbuf[:, :co]
             else:
                 v_new = torch.empty(2 * n, co, **f32)

@@ -118,6 +118,41 @@ int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, const int32_t
                              const float* dout, int32_t C, int64_t ldo, const float* v, int64_t ldv, float* dv,
                              int64_t lddv, int32_t accumulate, void* stream);
 
+/* ---- forward applies / max aggregation from a TILE PLAN --------------------------------------------------------
+ * Same operations as dc_apply_{grad,div,div_curl_norm,hodge} / dc_knn_max[_affine] (same reference call sites:
+ * deltanet_base.py:78; nn/deltaconv.py:52-57,66; geometry/operators.py:27-43), results identical bit for bit; the
+ * neighbour rows come from LDS instead of the gather path.  The plan groups the points of every cloud into tiles of
+ * P (32 or 64) points that are consecutive on a Morton curve through the positions and lists the unique neighbour
+ * rows of each tile (layout: deltaconv_amd/csrc/tile_plan.h); it depends on positions + graph only and is built once
+ * per batch, like the CSC.  The reference has no counterpart (torch_sparse / torch_scatter gather from global memory).
+ * Restrictions: clouds of at most dc_tile_plan_max_cloud() points, P * k <= 2048, P * k % 8 == 0; the apply entry
+ * points need C % 64 == 0 and 16-byte aligned rows and return DC_ERR_ARG otherwise (use the plain entry points). */
+int32_t dc_tile_plan_tiles(int32_t num_points, int32_t num_clouds, int32_t P);     /* number of tile ids T */
+size_t dc_tile_plan_words(int32_t num_points, int32_t num_clouds, int32_t k, int32_t P);   /* plan size in int32 words */
+int32_t dc_tile_plan_max_cloud(void);
+int dc_tile_plan_build(const float* pos, const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds,
+                       int32_t num_points, int32_t max_cloud, int32_t k, int32_t P, int32_t* plan, void* stream);
+/* coefP[T, P*k, 2] = an operator's coefficients in tile order (zeros for padding); once per batch and operator */
+int dc_tile_permute_coef(const float* coef, const int32_t* plan, int32_t num_points, int32_t num_clouds, int32_t k,
+                         int32_t P, float* coefP, void* stream);
+int dc_apply_grad_tiled(const float* GP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+                        int32_t k, int32_t P, const float* x, int32_t C, int64_t ldx, float* out, int64_t ldo,
+                        void* stream);
+int dc_apply_div_tiled(const float* DP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+                       int32_t k, int32_t P, const float* v, int32_t C, int64_t ldv, float* out, int64_t ldo,
+                       void* stream);
+int dc_apply_div_curl_norm_tiled(const float* DP, const int32_t* plan, const int32_t* nbr, int32_t n,
+                                 int32_t num_clouds, int32_t k, int32_t P, const float* v, int32_t C, int64_t ldv,
+                                 float* out, int64_t ldo, void* stream);
+int dc_apply_hodge_tiled(const float* GP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+                         int32_t k, int32_t P, const float* dc, int32_t C, int64_t lddc, float* out, int64_t ldo,
+                         void* stream);
+int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k, int32_t P,
+                     const float* h, int32_t C, int64_t ldh, float* out, int64_t ldo, uint8_t* arg, void* stream);
+int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k,
+                            int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale, const float* shift,
+                            float slope, float* out, int64_t ldo, uint8_t* arg, void* stream);
+
 /* ---- max aggregation (torch_scatter.scatter(reduce='max'): deltaconv/nn/deltaconv.py:52,54) -- */
 /* out[i,c] = max_s h[nbr[i,s],c]; arg[Nt,C] = first maximal slot (k <= 255) */
 int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float* out,

@@ -515,3 +515,34 @@ def test_eval_coefficient_cache_follows_the_checkpoint():
     fresh.load_state_dict(model.state_dict())
     with torch.no_grad():
         assert torch.equal(model(b), fresh(b))
+
+
+def test_eval_coefficient_cache_survives_graph_replays():
+    """A HIP-graph replay of a training step (optimizer captured) moves parameters and running statistics through raw
+    pointers: no tensor version changes.  train (replay) -> eval -> train (replay) -> eval must not serve the second
+    eval from the first one's cached BatchNorm maps (round-2 advisor finding): compare with a fresh model loaded from
+    the state_dict."""
+    from deltaconv_amd.graph_step import GraphedTrainStep
+    from deltaconv_amd.utils import calc_loss
+    b = synthetic_batch(4, 256, seed=91).to(DEV)
+    torch.manual_seed(7)
+    model = _no_dropout(_model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).train())
+    opt = torch.optim.SGD(model.parameters(), lr=0.05, momentum=0.9)
+    step = GraphedTrainStep(model, calc_loss, synthetic_batch(4, 256, seed=91).to(DEV), optimizer=opt, warmup=2)
+
+    def eval_pair():
+        model.eval()
+        fresh = _model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).eval()
+        fresh.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            got, want = model(b), fresh(b)
+        model.train()
+        return got, want
+
+    step(b)
+    g1, w1 = eval_pair()
+    assert torch.equal(g1, w1)
+    step(b)
+    g2, w2 = eval_pair()
+    assert torch.equal(g2, w2)
+    assert not torch.equal(g1, g2)                                         # the checkpoint did move
