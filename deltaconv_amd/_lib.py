@@ -10,7 +10,8 @@ import re
 import torch  # must be imported first: the HIP runtime already loaded by torch is reused
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libdeltaconv_hip.so")
+# DELTACONV_HIP_LIB: another build of the same library (A/B runs of compile-time switches, e.g. -DDC_NT_STORES=0)
+LIB_PATH = os.environ.get("DELTACONV_HIP_LIB") or os.path.join(_PKG, "lib", "libdeltaconv_hip.so")
 # the declared ABI: include/deltaconv_hip.h of the source tree; `make -C deltaconv_amd/csrc` copies it next to
 # the library (deltaconv_amd/lib/), so an installed / copied package without the repository root still imports
 _HEADERS = (os.path.join(os.path.dirname(_PKG), "include", "deltaconv_hip.h"),

@@ -19,7 +19,10 @@ struct alignas(4 * V) FV {
 template <int V>
 __device__ __forceinline__ FV<V> ldv(const float* p) { return *reinterpret_cast<const FV<V>*>(p); }
 template <int V>
-__device__ __forceinline__ void stv(float* p, const FV<V>& a) { *reinterpret_cast<FV<V>*>(p) = a; }
+__device__ __forceinline__ void stv(float* p, const FV<V>& a) {
+    if constexpr (V == 4) dc_store16<DC_ST_NN>(p, *reinterpret_cast<const dc_f32x4*>(&a));   // streamed out (common.h)
+    else *reinterpret_cast<FV<V>*>(p) = a;
+}
 
 // ---- generic ordered column reduction: NQ quantities per element ------------------------------
 // grid = (row_chunks, col_tiles); partial[(chunk*NQ + q)*C + col] (double)

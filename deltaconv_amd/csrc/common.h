@@ -38,6 +38,24 @@ int dc_option(int key);
 
 static inline int dc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Output stores ----------------------------------------------------------------------------------------------------
+// A plain store leaves a kernel's output dirty in the per-XCD L2 until the end-of-kernel write-back, which is then
+// exposed in full; a non-temporal store streams it out while the kernel still runs (measured alone, r03e: a 42 MB
+// stream copy 8.98 -> 5.76 us, the tiled div|curl|norm apply 16.0 -> 12.4 us).  Inside a step the picture is mixed: the
+// consumer of a streamed-out tensor no longer finds it in L2, so the policy is chosen per kernel family from A/B runs
+// of the whole step (profiles/r03*_store_policy.txt); DC_NT_MASK holds the families that stream.  16-byte stores only.
+enum { DC_ST_TILE = 1 /* ell_tile.h */, DC_ST_ELL = 2 /* ell_math.h: staged applies, transposes, edge kernels */,
+       DC_ST_NN = 4 /* colreduce.h stv: BatchNorm / activation / vector non-linearity passes */, DC_ST_GEMM = 8 /* gemm.hip */ };
+#ifndef DC_NT_MASK
+#define DC_NT_MASK (DC_ST_TILE)
+#endif
+typedef float dc_f32x4 __attribute__((ext_vector_type(4)));
+template <int FAMILY>
+__device__ __forceinline__ void dc_store16(float* p, dc_f32x4 v) {
+    if constexpr ((DC_NT_MASK & FAMILY) != 0) __builtin_nontemporal_store(v, reinterpret_cast<dc_f32x4*>(p));
+    else *reinterpret_cast<dc_f32x4*>(p) = v;
+}
+
 // Wave-level helpers -------------------------------------------------------------------------
 // Stream-ordered zero fill as a kernel (not hipMemsetAsync: a memset node inside a captured HIP graph
 // is a different code path from a kernel node; every entry point enqueues kernels only).

@@ -27,6 +27,12 @@ DC_HD Vec<V> vload(const float* p) {
 }
 template <int V>
 DC_HD void vstore(float* p, const Vec<V>& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (V == 4) {                               // results are streamed out (common.h: dc_store16)
+        dc_store16<DC_ST_ELL>(p, *reinterpret_cast<const dc_f32x4*>(&a));
+        return;
+    }
+#endif
     *reinterpret_cast<Vec<V>*>(p) = a;
 }
 template <int V>

@@ -30,11 +30,7 @@ using dcell::vzero;
 
 constexpr int CS = 64;        // channels per slab: 16 lanes x 4
 constexpr int CAP = 248;      // unique rows of a tile kept in LDS
-typedef float f4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void store_nt(float* p, const Vec<4>& a) {
-    __builtin_nontemporal_store(*reinterpret_cast<const f4v*>(&a), reinterpret_cast<f4v*>(p));
-}
+__device__ __forceinline__ void store_nt(float* p, const Vec<4>& a) { dc_store16<DC_ST_TILE>(p, *reinterpret_cast<const dc_f32x4*>(&a)); }
 __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

@@ -471,14 +471,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
                 const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
                 v += o;
             }
-            *reinterpret_cast<f32x4*>(dst) = v;
+            dc_store16<DC_ST_GEMM>(dst, v);
         } else if (row < p.M) {
             if (col + 3 < p.N && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
                 if (p.accumulate) {
                     const f32x4 o = *reinterpret_cast<const f32x4*>(dst);
                     v += o;
                 }
-                *reinterpret_cast<f32x4*>(dst) = v;
+                dc_store16<DC_ST_GEMM>(dst, v);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
