@@ -31,7 +31,7 @@ def fwd_apply(name, op, a, c, lda, out, ldo):
     g = op.graph
     plan = _tiled(g, c, (a, lda), (out, ldo))
     if plan is not None:
-        lib.call(f"dc_apply_{name}_tiled", op.coefP(plan), plan.blob, g.nbr, *plan.args, a, c, lda, out, ldo)
+        lib.call(f"dc_apply_{name}_tiled", op.coef, plan.blob, g.nbr, *plan.args, a, c, lda, out, ldo)
     else:
         lib.call(f"dc_apply_{name}", op.coef, g.nbr, g.n, g.k, a, c, lda, out, ldo)
 

@@ -211,7 +211,7 @@ DC_EXPORT int dc_knn_sum_backward(const int32_t* tptr, const int32_t* tedge, int
 DC_EXPORT int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k, int32_t P,
                                const float* h, int32_t C, int64_t ldh, float* out, int64_t ldo, uint8_t* arg, void* stream) {
     DC_REQUIRE(plan && nbr && h && out && arg, "dc_knn_max_tiled: null pointer");
-    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 1 && k <= 255 && (P == 32 || P == 64) && P * k <= 2048 && (P * k) % 8 == 0,
+    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
                "dc_knn_max_tiled: bad size");
     DC_REQUIRE(dctile::eligible(C, {(long)ldh, (long)ldo}, {h, out, arg}), "dc_knn_max_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
     DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_max_tiled: leading dimension smaller than the row");
@@ -228,7 +228,7 @@ DC_EXPORT int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, i
                                       int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale,
                                       const float* shift, float slope, float* out, int64_t ldo, uint8_t* arg, void* stream) {
     DC_REQUIRE(plan && nbr && h && scale && shift && out && arg, "dc_knn_max_affine_tiled: null pointer");
-    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 1 && k <= 255 && (P == 32 || P == 64) && P * k <= 2048 && (P * k) % 8 == 0,
+    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
                "dc_knn_max_affine_tiled: bad size");
     DC_REQUIRE(dctile::eligible(C, {(long)ldh, (long)ldo}, {h, out, arg}), "dc_knn_max_affine_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
     DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_max_affine_tiled: leading dimension smaller than the row");

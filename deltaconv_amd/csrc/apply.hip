@@ -126,8 +126,7 @@ DC_EXPORT int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, con
 
 // ---- forward, from a tile plan (tile_plan.h, ell_tile.h) ---------------------------------------------------------
 // Same results bit for bit as the entry points above (same FMAs, same slot order); the neighbour rows come from LDS.
-// coefP = the operator's coefficients in tile order (dc_tile_permute_coef); nbr is read only by tiles whose unique rows
-// exceed the LDS capacity.  C must be a multiple of 64 and rows 16-byte aligned (otherwise DC_ERR_ARG: use the entry
+// coef = the operator as for the plain entry points; nbr is read only by tiles whose unique rows exceed the LDS capacity.  C must be a multiple of 64 and rows 16-byte aligned (otherwise DC_ERR_ARG: use the entry
 // points above).
 namespace {
 int check_tiled(const char* name, const void* a, const void* b, const void* c, const void* d, const void* e, int n, int nc,
@@ -136,7 +135,7 @@ int check_tiled(const char* name, const void* a, const void* b, const void* c, c
         dc_set_error("%s: null pointer", name);
         return DC_ERR_ARG;
     }
-    if (n < 0 || nc < 0 || k < 1 || (P != 32 && P != 64) || P * k > 2048 || (P * k) % 8) {
+    if (n < 0 || nc < 0 || k < 2 || k % 2 || k > 64 || (P != 32 && P != 64) || P * k > 2048) {
         dc_set_error("%s: bad size n=%d num_clouds=%d k=%d P=%d", name, n, nc, k, P);
         return DC_ERR_ARG;
     }
@@ -149,16 +148,16 @@ int check_tiled(const char* name, const void* a, const void* b, const void* c, c
 }  // namespace
 
 #define DC_TILED_ENTRY(FN, BODY, R, LDJ, HS, MINLDI, MINLDO, ...)                                                     \
-    DC_EXPORT int FN(const float* coefP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,     \
+    DC_EXPORT int FN(const float* coef, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,     \
                      int32_t k, int32_t P, const float* in, int32_t C, int64_t ldi, float* out, int64_t ldo,          \
                      void* stream) {                                                                                 \
-        if (int rc = check_tiled(#FN, coefP, plan, nbr, in, out, n, num_clouds, k, P, C,                              \
-                                 dctile::eligible(C, {(long)ldi, (long)ldo}, {in, out, coefP})))                      \
+        if (int rc = check_tiled(#FN, coef, plan, nbr, in, out, n, num_clouds, k, P, C,                              \
+                                 dctile::eligible(C, {(long)ldi, (long)ldo}, {in, out, coef})))                      \
             return rc;                                                                                               \
         DC_REQUIRE(ldi >= (MINLDI) && ldo >= (MINLDO), #FN ": leading dimension smaller than the row");              \
         if (n == 0) return DC_OK;                                                                                    \
         const DcTilePlan L = dc_tile_plan_layout(n, num_clouds, k, P);                                               \
-        dctile::launch<R>(L, plan, coefP, nbr, C, dctile::BODY{in, (long)(LDJ), (long)(HS), out, (long)ldo __VA_ARGS__}, \
+        dctile::launch<R>(L, plan, coef, nbr, C, dctile::BODY{in, (long)(LDJ), (long)(HS), out, (long)ldo __VA_ARGS__}, \
                           static_cast<hipStream_t>(stream));                                                         \
         DC_CHECK_LAUNCH(#FN);                                                                                        \
         return DC_OK;                                                                                                \

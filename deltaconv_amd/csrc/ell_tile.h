@@ -7,8 +7,9 @@
 // Mapping: workgroup = (tile, 64-channel slab), thread = (point of the tile, 4 channels); 16 lanes per point.
 //   * every lane group of a ds_read_b128 covers the 16 different 16-byte columns of 256-byte rows, so random rows are
 //     bank-conflict free (MI355X_MICROARCH.md, LDS table: 256 B/clk/CU; the gather path delivers ~49);
-//   * rows, coefficients (tile order: dc_tile_permute_coef) and local indices arrive by `global_load_lds_dwordx4`
-//     (no staging registers, no ds_write: a register-staged variant of the same kernel ran 2x slower, r03a);
+//   * rows, coefficients (the k * 8 contiguous bytes of every point of the tile, straight from the operator) and local
+//     indices arrive by `global_load_lds_dwordx4` (no staging registers, no ds_write: a register-staged variant of the
+//     same kernel ran 2x slower, r03a);
 //   * all row ids are loaded before the first DMA piece is issued (hipcc waits vmcnt(0) at the first use of an
 //     ordinary load's result while DMA pieces are in flight, which would serialise the pieces);
 //   * outputs leave with non-temporal stores: a plain store leaves the whole output dirty in the per-XCD L2 until the
@@ -43,9 +44,12 @@ struct Geom {
     static constexpr int RIT = CAPR / (4 * NW);                                  // DMA instructions per wave
 };
 inline size_t chunk1k(size_t bytes) { return (bytes + 1023) / 1024 * 1024; }
+// coefficients of a tile in LDS: whole 1-KiB DMA pieces, each holding the k * 8 bytes of 64 / (k / 2) points
+inline int coef_ppi(int k) { return 64 / (k / 2); }
+inline size_t coef_bytes(int P, int k) { return (size_t)((P + coef_ppi(k) - 1) / coef_ppi(k)) * 1024; }
 template <int R, int P>
 inline size_t lds_bytes(int k, bool coef) {
-    return (size_t)Geom<R, P>::CAPR * 256 + (coef ? chunk1k((size_t)P * k * 8) : 0) + chunk1k((size_t)P * k * 2) + P * 4 + P * 2 + 16;
+    return (size_t)Geom<R, P>::CAPR * 256 + (coef ? coef_bytes(P, k) : 0) + chunk1k((size_t)P * k * 2) + P * 4 + P * 2 + 16;
 }
 
 // BODY: per-thread accumulator object, copied from the kernel argument
@@ -55,7 +59,7 @@ inline size_t lds_bytes(int k, bool coef) {
 //   void finish(long i, int c, const Vec<4>& s0, const Vec<4>& s1);
 template <int R, int P, class BODY>
 __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const int* __restrict__ plan,
-                                                          const float* __restrict__ coefP, const int* __restrict__ nbr,
+                                                          const float* __restrict__ coef, const int* __restrict__ nbr,
                                                           int slabs, int remap, BODY body) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GM = Geom<R, P>;
@@ -66,7 +70,8 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
     const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
     const int wave = tid >> 6, lane64 = tid & 63;
     const int k = L.k, PK = L.PK;
-    const size_t cfb_bytes = BODY::COEF ? (size_t)((PK * 8 + 1023) / 1024 * 1024) : 0;
+    const int cpp = k >> 1, ppi = 64 / cpp;                               // 16-byte pieces per point, points per DMA piece
+    const size_t cfb_bytes = BODY::COEF ? (size_t)((P + ppi - 1) / ppi) * 1024 : 0;
     float* rows = reinterpret_cast<float*>(smem);                         // [CAPR][64]
     char* cfb = smem + (size_t)CAPR * 256;                                // [PK] G2
     char* lcb = cfb + cfb_bytes;                                          // [PK] u16
@@ -89,9 +94,20 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
         mypt = plan[L.o_pts + tile * P + tid];
         mysl = reinterpret_cast<const unsigned short*>(plan + L.o_self)[tile * P + tid];
     }
+    // coefficient pieces of this lane: piece c = wave (+ NW) holds points c * ppi .. of the tile, this lane its point
+    // lane / cpp and the 16-byte chunk lane % cpp of that point's k * 8 bytes (k <= 64: at most two pieces per wave)
+    int cpt[2] = {-1, -1};
+    const int cpp_pt = lane64 / cpp, cpp_ch = lane64 - cpp_pt * cpp;
+    if (BODY::COEF && cpp_pt < ppi)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int p = (wave + u * NW) * ppi + cpp_pt;
+            if (p < P) cpt[u] = plan[L.o_pts + tile * P + p];
+        }
 #pragma unroll
     for (int it = 0; it < RIT; ++it) asm volatile("" : "+v"(rid[it]));   // the id waits end here, before the first DMA piece
     asm volatile("" : "+v"(mypt));
+    asm volatile("" : "+v"(cpt[0]), "+v"(cpt[1]));
 #pragma unroll
     for (int it = 0; it < RIT; ++it) {
         const int r0 = (wave + it * NW) * 4;
@@ -101,10 +117,11 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
         }
     }
     {   // coefficients and local indices of the tile: contiguous -> whole 1-KiB chunks (tail lanes re-read the end)
-        if (BODY::COEF) {
-            const char* g = reinterpret_cast<const char*>(coefP) + (size_t)tile * PK * 8;
-            for (int c = wave; c * 1024 < PK * 8; c += NW) dma16(g + min(c * 1024 + lane64 * 16, PK * 8 - 16), cfb + c * 1024);
-        }
+        if (BODY::COEF)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)                                   // (padding lanes / points re-read row 0: never used)
+                if ((wave + u * NW) * ppi < P)
+                    dma16(coef + (cpt[u] >= 0 ? (long)cpt[u] * k * 2 + cpp_ch * 4 : 0), cfb + (wave + u * NW) * 1024);
         const char* g = reinterpret_cast<const char*>(plan + L.o_loc) + (size_t)tile * PK * 2;
         for (int c = wave; c * 1024 < PK * 2; c += NW) dma16(g + min(c * 1024 + lane64 * 16, PK * 2 - 16), lcb + c * 1024);
     }
@@ -115,7 +132,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
     __syncthreads();
     const long i = pts[grp];
     if (i < 0) return;
-    const G2* cp = reinterpret_cast<const G2*>(cfb) + grp * k;
+    const G2* cp = reinterpret_cast<const G2*>(cfb + (grp / ppi) * 1024 + (grp % ppi) * (k * 8));
     const unsigned short* lp = reinterpret_cast<const unsigned short*>(lcb) + grp * k;
     const int c = cb + l16 * 4;
     body.init(c);
@@ -250,7 +267,7 @@ struct KnnMaxB {
 };
 
 template <int R, int P, class BODY>
-inline void launch_one(const DcTilePlan& L, const int* plan, const float* coefP, const int* nbr, int C, BODY body, hipStream_t s) {
+inline void launch_one(const DcTilePlan& L, const int* plan, const float* coef, const int* nbr, int C, BODY body, hipStream_t s) {
     const int slabs = C / CS;
     const size_t lds = lds_bytes<R, P>(L.k, BODY::COEF);
     static bool attr_set = false;                       // > 64 KiB of dynamic LDS needs the attribute once per kernel
@@ -259,13 +276,13 @@ inline void launch_one(const DcTilePlan& L, const int* plan, const float* coefP,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((tile_fwd_kernel<R, P, BODY>), dim3((unsigned)L.T * slabs), dim3(P * 16), lds, s, L, plan, coefP, nbr, slabs,
+    hipLaunchKernelGGL((tile_fwd_kernel<R, P, BODY>), dim3((unsigned)L.T * slabs), dim3(P * 16), lds, s, L, plan, coef, nbr, slabs,
                        dc_option(DC_OPT_XCD_REMAP), body);
 }
 template <int R, class BODY>
-inline void launch(const DcTilePlan& L, const int* plan, const float* coefP, const int* nbr, int C, BODY body, hipStream_t s) {
-    if (L.P == 64) launch_one<R, 64, BODY>(L, plan, coefP, nbr, C, body, s);
-    else launch_one<R, 32, BODY>(L, plan, coefP, nbr, C, body, s);
+inline void launch(const DcTilePlan& L, const int* plan, const float* coef, const int* nbr, int C, BODY body, hipStream_t s) {
+    if (L.P == 64) launch_one<R, 64, BODY>(L, plan, coef, nbr, C, body, s);
+    else launch_one<R, 32, BODY>(L, plan, coef, nbr, C, body, s);
 }
 
 // 16-byte path only: channels a multiple of the slab, leading dimensions and bases 16-byte aligned

@@ -21,23 +21,33 @@ __device__ __forceinline__ unsigned spread10(unsigned x) {   // 10 bits -> every
     return x;
 }
 
-__global__ void tile_clear_kernel(int* __restrict__ plan, DcTilePlan L) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long)L.T * L.P) plan[L.o_pts + i] = -1;
-    if (i < L.T) plan[L.o_nu + i] = 0;
-}
-
-// one workgroup per cloud: bounding box -> 30-bit Morton keys -> bitonic sort of (key, local index) in LDS -> the
-// cloud's tiles (point ids in Morton order, -1 padding).  Ties in the key are broken by the index: deterministic.
-__global__ __launch_bounds__(1024) void tile_order_kernel(const float* __restrict__ pos, const int* __restrict__ cloud_ptr,
-                                                          int* __restrict__ plan, DcTilePlan L) {
-    __shared__ unsigned long long key[MAX_CLOUD];
-    __shared__ float red[6][16];
-    const int b = blockIdx.x, tid = threadIdx.x;
+// Morton order of every cloud by RANKING, two kernels.
+// tile_key_kernel: workgroup (cloud, chunk of 256 points) reduces the cloud's bounding box (redundantly per chunk: 12
+//   bytes per point) and writes the sort keys of its chunk: an 18-bit Morton code (6 bits per axis: 262 144 cells for
+//   <= 4096 points) above the 12-bit index inside the cloud -- one 32-bit word per point, unique, so the order is total
+//   and deterministic.  Chunk 0 also resets the cloud's tile range: -1 padding behind the last point, zero unique-row
+//   counts (unused tile ids stay empty).
+// tile_rank_kernel: workgroup (cloud, 64 points) holds the cloud's keys in LDS; four lanes per point each count the keys
+//   below their point's key in a quarter of the list (broadcast 16-byte LDS reads, one compare + add per candidate),
+//   the four counts are added and the point's id is written at its rank.  No sort passes, no barriers in the loop,
+//   N / 64 workgroups per cloud (a bitonic sort in one workgroup per cloud took 24 us at 32 x 1024 points and left 7/8
+//   of the chip idle at 8 x 4096; one thread per point over the whole list 111 us there).
+__global__ __launch_bounds__(256) void tile_key_kernel(const float* __restrict__ pos, const int* __restrict__ cloud_ptr,
+                                                       int num_clouds, unsigned* __restrict__ keys, int* __restrict__ plan,
+                                                       DcTilePlan L) {
+    __shared__ float red[6][4];
+    const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int begin = cloud_ptr[b], N = cloud_ptr[b + 1] - begin;
-    if (N <= 0) return;
+    if (chunk == 0) {
+        const int tile0 = dc_tile_base(begin, b, L.P);
+        const int tile1 = b + 1 < num_clouds ? dc_tile_base(begin + N, b + 1, L.P) : L.T;
+        int* pts = plan + L.o_pts + (long)tile0 * L.P;
+        for (int i = max(N, 0) + tid; i < (tile1 - tile0) * L.P; i += 256) pts[i] = -1;
+        for (int t = tile0 + tid; t < tile1; t += 256) plan[L.o_nu + t] = 0;
+    }
+    if (chunk * 256 >= N) return;                          // block-uniform
     float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-    for (int i = tid; i < N; i += 1024)
+    for (int i = tid; i < N; i += 256)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const float v = pos[(long)(begin + i) * 3 + a];
@@ -56,51 +66,43 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const float* __restric
             red[3 + a][tid >> 6] = hi[a];
         }
     __syncthreads();
-    float inv[3];
+    const int i = chunk * 256 + tid;
+    if (i >= N) return;
+    unsigned q[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float l = red[a][0], h = red[3 + a][0];
-        for (int w = 1; w < 16; ++w) {
+        for (int w = 1; w < 4; ++w) {
             l = fminf(l, red[a][w]);
             h = fmaxf(h, red[3 + a][w]);
         }
-        lo[a] = l;
-        inv[a] = h > l ? 1024.f / (h - l) : 0.f;
+        const float inv = h > l ? 64.f / (h - l) : 0.f;
+        q[a] = (unsigned)min(63, max(0, (int)((pos[(long)(begin + i) * 3 + a] - l) * inv)));
     }
-    int M = 2;
-    while (M < N) M <<= 1;
-    for (int i = tid; i < M; i += 1024) {
-        unsigned long long kv = ~0ull;
-        if (i < N) {
-            unsigned q[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float f = (pos[(long)(begin + i) * 3 + a] - lo[a]) * inv[a];
-                q[a] = (unsigned)min(1023, max(0, (int)f));
-            }
-            const unsigned m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-            kv = ((unsigned long long)m << 32) | (unsigned)i;
-        }
-        key[i] = kv;
-    }
-    for (int size = 2; size <= M; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            __syncthreads();
-            for (int t = tid; t < (M >> 1); t += 1024) {
-                const int i = ((t / stride) * stride << 1) + (t % stride), j = i + stride;
-                const unsigned long long a = key[i], c = key[j];
-                const bool up = (i & size) == 0;
-                if ((a > c) == up) {
-                    key[i] = c;
-                    key[j] = a;
-                }
-            }
-        }
+    const unsigned m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    keys[begin + i] = (m << 12) | (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void tile_rank_kernel(const unsigned* __restrict__ keys, const int* __restrict__ cloud_ptr,
+                                                        int* __restrict__ plan, DcTilePlan L) {
+    __shared__ __attribute__((aligned(16))) unsigned key[MAX_CLOUD];
+    const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const int begin = cloud_ptr[b], N = cloud_ptr[b + 1] - begin;
+    if (chunk * 64 >= N) return;                           // block-uniform
+    const int N16 = (N + 15) & ~15;
+    for (int i = tid; i < N16; i += 256) key[i] = i < N ? keys[begin + i] : 0xffffffffu;   // padding sorts last
     __syncthreads();
-    const int tile0 = dc_tile_base(begin, b, L.P);
-    const int ntile = (N + L.P - 1) / L.P;
-    int* pts = plan + L.o_pts + (long)tile0 * L.P;
-    for (int i = tid; i < ntile * L.P; i += 1024) pts[i] = i < N ? begin + (int)(unsigned)(key[i] & 0xffffffffu) : -1;
+    const int i = chunk * 64 + (tid >> 2), sub = tid & 3;
+    const unsigned mine = key[min(i, N - 1)];
+    int rank = 0;
+#pragma unroll 4
+    for (int j = sub * 4; j < N16; j += 16) {              // lanes of a point interleave 16-byte pieces of the key list
+        const uint4 kq = *reinterpret_cast<const uint4*>(key + j);
+        rank += (kq.x < mine) + (kq.y < mine) + (kq.z < mine) + (kq.w < mine);
+    }
+    rank += __shfl_xor(rank, 1, 64);
+    rank += __shfl_xor(rank, 2, 64);
+    if (sub == 0 && i < N) plan[L.o_pts + (long)dc_tile_base(begin, b, L.P) * L.P + rank] = begin + i;
 }
 
 // one workgroup per tile: bitmap of the tile's rows over the cloud's local ids -> prefix popcounts -> unique list
@@ -192,20 +194,10 @@ __global__ __launch_bounds__(256) void tile_unique_kernel(const int* __restrict_
     }
 }
 
-__global__ void tile_permute_kernel(const float2* __restrict__ coef, const int* __restrict__ plan, DcTilePlan L,
-                                    float2* __restrict__ coefP) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)L.T * L.PK) return;
-    const long t = i / L.PK;
-    const int q = (int)(i - t * L.PK), p = q / L.k;
-    const int pt = plan[L.o_pts + t * L.P + p];
-    coefP[i] = pt >= 0 ? coef[(long)pt * L.k + (q - p * L.k)] : make_float2(0.f, 0.f);
-}
-
 int check_plan_args(const char* name, int num_points, int num_clouds, int k, int P) {
-    if (num_points < 0 || num_clouds < 0 || k < 1 || (P != 32 && P != 64) || P * k > MAX_PK || (P * k) % 8) {
-        dc_set_error("%s: bad size (num_points=%d num_clouds=%d k=%d P=%d; P in {32, 64}, P*k <= %d)", name, num_points,
-                     num_clouds, k, P, MAX_PK);
+    if (num_points < 0 || num_clouds < 0 || k < 2 || k % 2 || k > 64 || (P != 32 && P != 64) || P * k > MAX_PK) {
+        dc_set_error("%s: bad size (num_points=%d num_clouds=%d k=%d P=%d; k even, 2 <= k <= 64, P in {32, 64}, P*k <= %d)",
+                     name, num_points, num_clouds, k, P, MAX_PK);
         return DC_ERR_ARG;
     }
     return DC_OK;
@@ -226,28 +218,16 @@ DC_EXPORT int dc_tile_plan_build(const float* pos, const int32_t* nbr, const int
                                  int32_t num_points, int32_t max_cloud, int32_t k, int32_t P, int32_t* plan, void* stream) {
     DC_REQUIRE(pos && nbr && cloud_ptr && plan, "dc_tile_plan_build: null pointer");
     if (int rc = check_plan_args("dc_tile_plan_build", num_points, num_clouds, k, P)) return rc;
-    DC_REQUIRE(max_cloud <= MAX_CLOUD, "dc_tile_plan_build: clouds of more than %d points are not supported (max_cloud=%d)",
+    DC_REQUIRE(max_cloud >= 1 && max_cloud <= MAX_CLOUD, "dc_tile_plan_build: clouds of more than %d points are not supported (max_cloud=%d)",
                MAX_CLOUD, max_cloud);
     if (num_points == 0 || num_clouds == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DcTilePlan L = dc_tile_plan_layout(num_points, num_clouds, k, P);
-    hipLaunchKernelGGL(tile_clear_kernel, dim3(dc_cdiv((long)L.T * L.P, 256)), dim3(256), 0, s, plan, L);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(num_clouds), dim3(1024), 0, s, pos, cloud_ptr, plan, L);
+    unsigned* keys = reinterpret_cast<unsigned*>(plan + L.o_uniq);      // scratch: the uniq section is written afterwards
+    hipLaunchKernelGGL(tile_key_kernel, dim3(num_clouds, dc_cdiv(max_cloud, 256)), dim3(256), 0, s, pos, cloud_ptr, num_clouds, keys,
+                       plan, L);
+    hipLaunchKernelGGL(tile_rank_kernel, dim3(num_clouds, dc_cdiv(max_cloud, 64)), dim3(256), 0, s, keys, cloud_ptr, plan, L);
     hipLaunchKernelGGL(tile_unique_kernel, dim3(L.T), dim3(256), 0, s, nbr, cloud_ptr, num_clouds, plan, L);
     DC_CHECK_LAUNCH("dc_tile_plan_build");
-    return DC_OK;
-}
-
-// coefP[T][P*k][2]: an operator's coefficients in tile order (zeros for padding), so a tile's coefficients are one
-// contiguous LDS-DMA copy.  Once per batch and operator.
-DC_EXPORT int dc_tile_permute_coef(const float* coef, const int32_t* plan, int32_t num_points, int32_t num_clouds, int32_t k,
-                                   int32_t P, float* coefP, void* stream) {
-    DC_REQUIRE(coef && plan && coefP, "dc_tile_permute_coef: null pointer");
-    if (int rc = check_plan_args("dc_tile_permute_coef", num_points, num_clouds, k, P)) return rc;
-    if (num_points == 0 || num_clouds == 0) return DC_OK;
-    const DcTilePlan L = dc_tile_plan_layout(num_points, num_clouds, k, P);
-    hipLaunchKernelGGL(tile_permute_kernel, dim3(dc_cdiv((long)L.T * L.PK, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float2*>(coef), plan, L, reinterpret_cast<float2*>(coefP));
-    DC_CHECK_LAUNCH("dc_tile_permute_coef");
     return DC_OK;
 }

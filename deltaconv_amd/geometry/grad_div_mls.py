@@ -22,15 +22,6 @@ class SparseOp:
         assert kind in ("grad", "div")
         self.kind, self.graph, self.coef = kind, graph, coef
         self._coefT = None
-        self._coefP = None
-
-    def coefP(self, plan):
-        """Coefficients in the tile order of `plan` (graph.tile_plan()) for the tiled forward applies; built once."""
-        if self._coefP is None or self._coefP[0] is not plan:
-            out = torch.empty(plan.tiles, plan.P * plan.k, 2, dtype=torch.float32, device=self.coef.device)
-            lib.call("dc_tile_permute_coef", self.coef, plan.blob, *plan.args, out)
-            self._coefP = (plan, out)
-        return self._coefP[1]
 
     def coefT(self):
         """Coefficients in CSC order (for the transposed applies of the backward pass); built once."""

@@ -6,6 +6,7 @@ keeps ``nbr[Nt,k] int32`` (centre-major, so ``edge_index = (repeat_interleave(ar
 nbr.flatten())`` is the reference's tensor) and lazily builds the transposed adjacency used by
 every backward op of the step.
 """
+import os
 import weakref
 
 import torch
@@ -82,7 +83,7 @@ class TilePlan:
 
 
 # Forward applies / max-aggregation from a tile plan (True) or through the gather path (False): A/B switch, same results.
-USE_TILE_PLAN = [True]
+USE_TILE_PLAN = [os.environ.get("DC_TILE_PLAN", "1") != "0"]
 
 
 class Graph:
@@ -95,13 +96,26 @@ class Graph:
         self._edge_index = None
         self._tile_plan = None
 
-    def tile_plan(self):
+    def tile_plan(self, force_P=None):
         """TilePlan of this graph, built once (stream-ordered kernels: capturable), or None when the plan does not
-        apply: positions unknown, clouds beyond the builder's limit, or the switch is off."""
+        apply or does not pay: positions unknown, clouds beyond the builder's limit, k > 24, fewer than 8192 points, or
+        the switch is off.  force_P = 32 | 64 builds a plan regardless of the pay-off heuristic."""
+        if force_P is not None and (self._tile_plan is None or not self._tile_plan or self._tile_plan.P != force_P):
+            words = int(lib.raw("dc_tile_plan_words")(self.n, self.num_clouds, self.k, force_P))
+            blob = torch.empty(words, dtype=torch.int32, device=self.nbr.device)
+            lib.call("dc_tile_plan_build", self.pos, self.nbr, self.ptr, self.num_clouds, self.n, self.max_cloud,
+                     self.k, force_P, blob)
+            self._tile_plan = TilePlan(self, blob, force_P)
         if self._tile_plan is None:
             self._tile_plan = False
-            P = 64 if self.k <= 24 else 32
-            if (USE_TILE_PLAN[0] and self.pos is not None and self.nbr.is_cuda and self.n > 0
+            # Where the plan pays (profiles/r03q_tile_policy.txt): k <= 24 with tiles of 64 points and enough points to
+            # amortise the three builder launches.  Tiles of 32 points (k = 30: 64 x 30 rows overflow the LDS capacity
+            # too often) do not beat the gather path (C5: 10.28 vs 10.21 ms per step), tiny batches are launch-bound
+            # (C1: +40 us on a 1.14 ms step).  DC_TILE_P = 32 | 64 forces a plan (A/B runs, tests).
+            forced = int(os.environ.get("DC_TILE_P", 0))
+            P = forced or 64
+            pays = forced or (self.k <= 24 and self.n >= 8192)
+            if (USE_TILE_PLAN[0] and pays and self.pos is not None and self.nbr.is_cuda and self.n > 0 and self.k % 2 == 0
                     and self.max_cloud <= int(lib.raw("dc_tile_plan_max_cloud")()) and P * self.k <= 2048):
                 words = int(lib.raw("dc_tile_plan_words")(self.n, self.num_clouds, self.k, P))
                 blob = torch.empty(words, dtype=torch.int32, device=self.nbr.device)

@@ -125,26 +125,24 @@ int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, const int32_t
  * P (32 or 64) points that are consecutive on a Morton curve through the positions and lists the unique neighbour
  * rows of each tile (layout: deltaconv_amd/csrc/tile_plan.h); it depends on positions + graph only and is built once
  * per batch, like the CSC.  The reference has no counterpart (torch_sparse / torch_scatter gather from global memory).
- * Restrictions: clouds of at most dc_tile_plan_max_cloud() points, P * k <= 2048, P * k % 8 == 0; the apply entry
- * points need C % 64 == 0 and 16-byte aligned rows and return DC_ERR_ARG otherwise (use the plain entry points). */
+ * Restrictions: clouds of at most dc_tile_plan_max_cloud() points, k even, k <= 64, P * k <= 2048; the apply entry
+ * points need C % 64 == 0 and 16-byte aligned rows and return DC_ERR_ARG otherwise (use the plain entry points).
+ * The operator argument is the same G / D as for the plain entry points. */
 int32_t dc_tile_plan_tiles(int32_t num_points, int32_t num_clouds, int32_t P);     /* number of tile ids T */
 size_t dc_tile_plan_words(int32_t num_points, int32_t num_clouds, int32_t k, int32_t P);   /* plan size in int32 words */
 int32_t dc_tile_plan_max_cloud(void);
 int dc_tile_plan_build(const float* pos, const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds,
                        int32_t num_points, int32_t max_cloud, int32_t k, int32_t P, int32_t* plan, void* stream);
-/* coefP[T, P*k, 2] = an operator's coefficients in tile order (zeros for padding); once per batch and operator */
-int dc_tile_permute_coef(const float* coef, const int32_t* plan, int32_t num_points, int32_t num_clouds, int32_t k,
-                         int32_t P, float* coefP, void* stream);
-int dc_apply_grad_tiled(const float* GP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+int dc_apply_grad_tiled(const float* G, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
                         int32_t k, int32_t P, const float* x, int32_t C, int64_t ldx, float* out, int64_t ldo,
                         void* stream);
-int dc_apply_div_tiled(const float* DP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+int dc_apply_div_tiled(const float* D, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
                        int32_t k, int32_t P, const float* v, int32_t C, int64_t ldv, float* out, int64_t ldo,
                        void* stream);
-int dc_apply_div_curl_norm_tiled(const float* DP, const int32_t* plan, const int32_t* nbr, int32_t n,
+int dc_apply_div_curl_norm_tiled(const float* D, const int32_t* plan, const int32_t* nbr, int32_t n,
                                  int32_t num_clouds, int32_t k, int32_t P, const float* v, int32_t C, int64_t ldv,
                                  float* out, int64_t ldo, void* stream);
-int dc_apply_hodge_tiled(const float* GP, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+int dc_apply_hodge_tiled(const float* G, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
                          int32_t k, int32_t P, const float* dc, int32_t C, int64_t lddc, float* out, int64_t ldo,
                          void* stream);
 int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k, int32_t P,

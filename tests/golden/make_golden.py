@@ -205,3 +205,6 @@ if __name__ == "__main__":
                categorical_vector=True)
     model_case("model_cls_nonormals_B2_N256_k20", "cls", 9, 2, 256, 20, 1e-2, normals=False,
                in_channels=3, num_classes=15, conv_channels=[64, 64, 64, 128])
+    # the shapeseg family (train_shapeseg.py:68-78: mlp_depth = 1, k = 30, many equal layers) at reduced width
+    model_case("model_seg_depth1_B2_N1024_k30", "seg", 12, 2, 1024, 30, 1e-3, in_channels=3, num_classes=8,
+               conv_channels=[32] * 4, mlp_depth=1, embedding_size=128)

@@ -113,3 +113,56 @@ def test_reduced_batch_vs_oracle(name):
         ld = model(b.to(DEV))
     # no-normals: SVD-sign gauge + ill-defined x-axis -> looser
     assert rel_err(ld, lo) < (5e-3 if not normals else 1e-3)
+
+
+@pytest.mark.parametrize("name", ["C3_scanobjectnn", "C4_shapenet", "C5_shapeseg"])
+def test_reduced_batch_step_vs_oracle(name):
+    """Train-mode forward + loss + backward at the per-cloud shape of the BASELINE configuration (N, k, channels, MLP depth;
+    2 clouds): logits AND every parameter gradient against the CPU oracle in fp64, with the oracle's own fp32 run (= the
+    reference's numerics) as the yardstick -- max-aggregation / pooling make gradients piecewise, so the bound is
+    self-calibrating: no further from fp64 than 3x the fp32 oracle (+ a floor).  These are the shapes at which the
+    ragged-K guarded GEMM loads (K = 6 / 12 / 70, N = 3 / 50), the depth-2 fused nodes and the centralised [E, 64] layer 0
+    (C4), the k = 30 / 8 x 128 layers from the P = 32 tile plan (C5) and the estimate_basis path (C3) actually run.
+    No-normals (C3): the tangent frames come from an SVD whose x-axis is a gauge choice, features
+    agree up to fp rounding through the gauge -> looser floor."""
+    from deltaconv_amd.data import Batch
+    B, N, k, normals, kind, kw, bkw = CONFIGS[name]
+    b = synthetic_batch(2, N, seed=72, normals=normals, **dict(bkw))
+    seg = kind == "seg"
+    model = _build(kind, kw, k)
+    ocls = oracle.models.DeltaNetSegmentation if seg else oracle.models.DeltaNetClassification
+    ref32 = ocls(num_neighbors=k, **kw)
+    ref32.load_state_dict(model.state_dict())
+    ref64 = ocls(num_neighbors=k, **kw).double()
+    ref64.load_state_dict(model.state_dict())
+    ref32, ref64 = _no_dropout(ref32.train()), _no_dropout(ref64.train())
+    model = _no_dropout(model.to(DEV).train())
+    b64 = Batch(b.pos.double(), b.batch, None if b.norm is None else b.norm.double(), None, b.y,
+                None if b.category is None else b.category.double(), b.num_graphs)
+    l32 = ref32(b)
+    oracle.loss.calc_loss(l32, b.y, smoothing=not seg).backward()
+    l64 = ref64(b64)
+    oracle.loss.calc_loss(l64, b.y, smoothing=not seg).backward()
+    bd = b.to(DEV)
+    ld = model(bd)
+    oracle.loss.calc_loss(ld, bd.y, smoothing=not seg).backward()
+    floor = 1e-3 if normals else 5e-3
+    e_hip, e_ref = rel_err(ld, l64), rel_err(l32, l64)
+    print(f"{name} logits: hip-vs-f64 {e_hip:.2e}  oracle32-vs-f64 {e_ref:.2e}")
+    assert e_hip < 3 * e_ref + floor
+    gmax = max(float(p.grad.abs().max()) for p in ref64.parameters() if p.grad is not None)
+    worst_hip = worst_ref = 0.0
+    worst_name = ""
+    for (n1, p1), (n2, p2), (n3, p3) in zip(model.named_parameters(), ref32.named_parameters(), ref64.named_parameters()):
+        assert n1 == n2 == n3
+        if p3.grad is None:
+            assert p1.grad is None, n1
+            continue
+        assert p1.grad is not None, n1
+        scale = max(float(p3.grad.abs().max()), 1e-3 * gmax)
+        eh = float((p1.grad.cpu().double() - p3.grad).abs().max()) / scale
+        if eh > worst_hip:
+            worst_hip, worst_name = eh, n1
+        worst_ref = max(worst_ref, float((p2.grad.double() - p3.grad).abs().max()) / scale)
+    print(f"{name} worst per-parameter gradient error: hip-vs-f64 {worst_hip:.2e} ({worst_name})  oracle32-vs-f64 {worst_ref:.2e}")
+    assert worst_hip < 3 * worst_ref + floor

@@ -74,6 +74,8 @@ MODELS = {
     "model_cls_B4_N256_k20": ("cls", dict(in_channels=3, num_classes=40), True),
     "model_seg_B2_N256_k20": ("seg", dict(in_channels=3, num_classes=50, categorical_vector=True), True),
     "model_cls_nonormals_B2_N256_k20": ("cls", dict(in_channels=3, num_classes=15, conv_channels=[64, 64, 64, 128]), False),
+    "model_seg_depth1_B2_N1024_k30": ("seg", dict(in_channels=3, num_classes=8, conv_channels=[32] * 4, mlp_depth=1,
+                                                  embedding_size=128), True),
 }
 
 

@@ -28,13 +28,13 @@ def _setup(sizes, k, seed=3, dup_frac=0.0, normals=True):
     return b, gr, grad, div
 
 
-CASES = [((256, 256, 256, 256), 20), ((512, 700, 300), 20), ((1024, 1024), 30), ((200, 64, 333), 10), ((4096,), 20)]
+CASES = [((256, 256, 256, 256), 20), ((512, 700, 300), 20), ((1024, 1024), 30), ((200, 64, 333), 10), ((4096,), 20), ((700, 90), 64)]
 
 
 @pytest.mark.parametrize("sizes,k", CASES)
 def test_plan_structure(sizes, k):
     b, gr, _, _ = _setup(sizes, k, dup_frac=0.03)
-    plan = gr.tile_plan()
+    plan = gr.tile_plan(force_P=64 if k <= 24 else 32)
     assert plan is not None and plan.P == (64 if k <= 24 else 32)
     P, n = plan.P, gr.n
     pts, nu, uniq, loc, slf = (plan.section(s).cpu() for s in ("pts", "nu", "uniq", "loc", "self"))
@@ -89,11 +89,11 @@ def _pair(fn_plain, fn_tiled, *outs):
 def test_tiled_equals_plain(sizes, k, C):
     from deltaconv_amd._lib import lib
     _, gr, grad, div = _setup(sizes, k, dup_frac=0.03)
-    plan = gr.tile_plan()
+    plan = gr.tile_plan(force_P=64 if k <= 24 else 32)
     n = gr.n
     torch.manual_seed(C + k)
     x, v, dcn = _rand(n, C), _rand(2 * n, C), _rand(n, 3 * C)
-    GP, DP = grad.coefP(plan), div.coefP(plan)
+    GP, DP = grad.coef, div.coef
     a = plan.args
     _pair(lambda o: lib.call("dc_apply_grad", grad.coef, gr.nbr, n, k, x, C, C, o, C),
           lambda o: lib.call("dc_apply_grad_tiled", GP, plan.blob, gr.nbr, *a, x, C, C, o, C), torch.empty(2 * n, C, device=DEV))
@@ -120,29 +120,29 @@ def test_tiled_strided_operands():
     """Operands and results as column blocks of wider buffers (the layer writes straight into the next GEMM's operand)."""
     from deltaconv_amd._lib import lib
     _, gr, grad, div = _setup((512, 512), 20)
-    plan = gr.tile_plan()
+    plan = gr.tile_plan(force_P=64)
     n, k, C = gr.n, gr.k, 64
     a = plan.args
     vbuf, obuf = _rand(2 * n, 3 * C), torch.zeros(n, 4 * C, device=DEV)
     v = vbuf[:, C:2 * C]
     o1, o2 = obuf.clone(), obuf.clone()
     lib.call("dc_apply_div_curl_norm", div.coef, gr.nbr, n, k, v, C, 3 * C, o1[:, C:], 4 * C)
-    lib.call("dc_apply_div_curl_norm_tiled", div.coefP(plan), plan.blob, gr.nbr, *a, v, C, 3 * C, o2[:, C:], 4 * C)
+    lib.call("dc_apply_div_curl_norm_tiled", div.coef, plan.blob, gr.nbr, *a, v, C, 3 * C, o2[:, C:], 4 * C)
     assert torch.equal(o1, o2) and bool((o2[:, :C] == 0).all())
     hb1, hb2 = torch.zeros(2 * n, 3 * C, device=DEV), torch.zeros(2 * n, 3 * C, device=DEV)
     lib.call("dc_apply_hodge", grad.coef, gr.nbr, n, k, o1[:, C:], C, 4 * C, hb1[:, C:2 * C], 3 * C)
-    lib.call("dc_apply_hodge_tiled", grad.coefP(plan), plan.blob, gr.nbr, *a, o2[:, C:], C, 4 * C, hb2[:, C:2 * C], 3 * C)
+    lib.call("dc_apply_hodge_tiled", grad.coef, plan.blob, gr.nbr, *a, o2[:, C:], C, 4 * C, hb2[:, C:2 * C], 3 * C)
     assert torch.equal(hb1, hb2)
 
 
 def test_tiled_rejects_what_it_cannot_do():
     from deltaconv_amd._lib import lib
     _, gr, grad, _ = _setup((256,), 20)
-    plan = gr.tile_plan()
+    plan = gr.tile_plan(force_P=64)
     n, C = gr.n, 48                                                        # not a multiple of the 64-channel slab
     x, o = _rand(n, C), torch.empty(2 * n, C, device=DEV)
     with pytest.raises(RuntimeError, match="C % 64"):
-        lib.call("dc_apply_grad_tiled", grad.coefP(plan), plan.blob, gr.nbr, *plan.args, x, C, C, o, C)
+        lib.call("dc_apply_grad_tiled", grad.coef, plan.blob, gr.nbr, *plan.args, x, C, C, o, C)
 
 
 @pytest.mark.parametrize("k", [20, 30])
@@ -163,7 +163,7 @@ def test_tiled_overflow_tiles(k):
     ei = torch.stack([torch.arange(n).repeat_interleave(k), nbr.reshape(-1).long()]).to(DEV)
     gr = Graph.from_edge_index(ei, n, k=k, batch=batch.to(DEV))
     gr.pos = pos.to(DEV)
-    plan = gr.tile_plan()
+    plan = gr.tile_plan(force_P=64 if k <= 24 else 32)
     assert plan is not None and int(plan.section("nu").max()) > 248
     C = 64
     coef = _rand(n, k, 2)
@@ -171,10 +171,10 @@ def test_tiled_overflow_tiles(k):
     x, v = _rand(n, C), _rand(2 * n, C)
     a = plan.args
     _pair(lambda o: lib.call("dc_apply_grad", grad.coef, gr.nbr, n, k, x, C, C, o, C),
-          lambda o: lib.call("dc_apply_grad_tiled", grad.coefP(plan), plan.blob, gr.nbr, *a, x, C, C, o, C),
+          lambda o: lib.call("dc_apply_grad_tiled", grad.coef, plan.blob, gr.nbr, *a, x, C, C, o, C),
           torch.empty(2 * n, C, device=DEV))
     _pair(lambda o: lib.call("dc_apply_div_curl_norm", div.coef, gr.nbr, n, k, v, C, C, o, 3 * C),
-          lambda o: lib.call("dc_apply_div_curl_norm_tiled", div.coefP(plan), plan.blob, gr.nbr, *a, v, C, C, o, 3 * C),
+          lambda o: lib.call("dc_apply_div_curl_norm_tiled", div.coef, plan.blob, gr.nbr, *a, v, C, C, o, 3 * C),
           torch.empty(n, 3 * C, device=DEV))
     _pair(lambda o, ar: lib.call("dc_knn_max", gr.nbr, n, k, x, C, C, o, C, ar),
           lambda o, ar: lib.call("dc_knn_max_tiled", plan.blob, gr.nbr, *a, x, C, C, o, C, ar),
@@ -191,7 +191,9 @@ def test_model_identical_with_and_without_plan(kind):
     b = synthetic_batch(3, 512, seed=12, per_point_labels=(kind == "seg"), num_classes=8 if kind == "seg" else 40).to(DEV)
 
     def run(use):
+        import os
         G.USE_TILE_PLAN[0] = use
+        os.environ["DC_TILE_P"] = "64"                     # a batch this small would not get a plan by itself
         try:
             torch.manual_seed(4)
             m = (DeltaNetClassification(3, 40) if kind == "cls" else DeltaNetSegmentation(3, 8, mlp_depth=1)).to(DEV).train()
@@ -203,6 +205,7 @@ def test_model_identical_with_and_without_plan(kind):
             return out.detach(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
         finally:
             G.USE_TILE_PLAN[0] = True
+            os.environ.pop("DC_TILE_P", None)
 
     o1, g1 = run(True)
     o0, g0 = run(False)
