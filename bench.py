@@ -34,10 +34,6 @@ def parse():
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-tuned-gemm", action="store_true", help="library default GEMM heuristics")
-    ap.add_argument("--fresh-tuning", action="store_true", help="ignore shipped GEMM tuning results (tools/tune_gemm.sh)")
-    ap.add_argument("--save-tuning", default=None, metavar="CSV",
-                    help="write the TunableOp results of this run (shipped + newly tuned shapes) to CSV")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every kernel from Python each step instead of replaying the captured HIP graph")
@@ -261,10 +257,6 @@ def main():
     from deltaconv_amd.data import synthetic_batch
     from deltaconv_amd.dp import FlatGradDataParallel
 
-    if not args.no_tuned_gemm:
-        if not args.fresh_tuning:                 # --fresh-tuning: TunableOp is driven by the environment
-            from deltaconv_amd.tuning import enable_tuned_gemms
-            enable_tuned_gemms()
     torch.manual_seed(1)
     model = dc.models.DeltaNetClassification(3, 40, num_neighbors=args.k).to(dev).train()
     ddp = FlatGradDataParallel(model, always_reduce=args.force_dist)
@@ -295,7 +287,7 @@ def main():
         # one captured HIP graph; same kernels, same work per step, one host call.
         from deltaconv_amd.graph_step import GraphedTrainStep
         static = synthetic_batch(args.batch, args.points, seed=99 + rank).to(dev)
-        for _ in range(2):                                   # eager steps first: GEMM tuning lookups, optimizer state
+        for _ in range(2):                                   # eager steps first: allocator, optimizer state
             ddp.zero_grad()
             calc_loss(ddp(static), static.y).backward()
             ddp.reduce_gradients()
@@ -333,14 +325,6 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     assert torch.isfinite(loss).item(), "loss is not finite"
-    if args.save_tuning and rank == 0:
-        import torch.cuda.tunable as tn                      # same text format as TunableOp's own results file
-        with open(args.save_tuning, "w") as fh:
-            for key, val in tn.get_validators():
-                fh.write(f"Validator,{key},{val}\n")
-            for op, params, solution, ms in tn.get_results():
-                fh.write(f"{op},{params},{solution},{ms}\n")
-
     if rank == 0:
         graph, grad, div = model.deltanet_base.build_operators(data)
         roof = apply_roofline(graph, grad, div, 64)

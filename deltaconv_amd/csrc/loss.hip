@@ -2,7 +2,7 @@
 // Replaces ~25 tiny ATen launches (log_softmax, gather, sums, mean and their backward) of
 // /root/reference/experiments/utils.py:7-24 per step; at [32 x 40] logits those are pure launch latency.
 //   ce_rows_kernel : wave = row (lanes stride the classes), writes d loss / d logits and one fp64
-//                    partial per block of 64 rows (wave butterflies + fixed-order sums: bit-reproducible)
+//                    partial per block (wave butterflies + fixed-order sums: bit-reproducible)
 //   ce_final_kernel: one wave sums the block partials in a fixed order -> loss = sum / R
 // Bound: latency.  Bytes: 8 R C + 8 R.
 #include "common.h"
@@ -10,19 +10,23 @@
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 64, WAVES = 4;
+constexpr int WAVES = 4;
+// rows one wave walks: a row is a chain of dependent steps (max -> exp-sum -> log -> gradient, each behind a global load
+// or a wave reduction: ~1.2 us), so few rows (classification: B logits rows) get one wave each -- 16 rows per wave cost
+// 22 us for the [32 x 40] logits of the bench step -- and only per-point logits (segmentation) amortise a longer walk
+inline int rows_per_wave(long R) { return R >= 16384 ? 16 : 1; }
 
-// wave = row (lanes stride the classes, coalesced); each wave walks ROWS_PER_BLOCK / WAVES rows
+// wave = row (lanes stride the classes, coalesced); each wave walks rpw rows
 __global__ __launch_bounds__(64 * WAVES) void ce_rows_kernel(const float* __restrict__ x, long ldx,
                                                              const long* __restrict__ label, long R, int C, float eps,
                                                              float* __restrict__ dx, long lddx,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, int rpw) {
     __shared__ double sm[WAVES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float inv_rows = 1.f / (float)R, q_off = dcloss::ce_q_off(C, eps), q_on = 1.f - eps;
     double acc = 0.0;
-    for (int i = 0; i < ROWS_PER_BLOCK / WAVES; ++i) {
-        const long r = (long)blockIdx.x * ROWS_PER_BLOCK + w * (ROWS_PER_BLOCK / WAVES) + i;
+    for (int i = 0; i < rpw; ++i) {
+        const long r = ((long)blockIdx.x * WAVES + w) * rpw + i;
         if (r >= R) break;   // wave-uniform
         const float* xr = x + r * ldx;
         float m = -INFINITY;
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(64) void ce_final_kernel(const double* __restrict__
 }  // namespace
 
 DC_EXPORT size_t dc_ce_loss_workspace_bytes(int64_t num_rows) {
-    return (size_t)dc_cdiv(num_rows > 0 ? num_rows : 1, ROWS_PER_BLOCK) * sizeof(double);
+    return (size_t)dc_cdiv(num_rows > 0 ? num_rows : 1, WAVES) * sizeof(double);     // one partial per block, rpw >= 1
 }
 
 DC_EXPORT int dc_ce_loss(const float* logits, int64_t ld_logits, const int64_t* labels, int64_t num_rows,
@@ -80,11 +84,12 @@ DC_EXPORT int dc_ce_loss(const float* logits, int64_t ld_logits, const int64_t* 
         return DC_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nb = dc_cdiv(num_rows, ROWS_PER_BLOCK);
+    const int rpw = rows_per_wave(num_rows);
+    const int nb = dc_cdiv(num_rows, WAVES * rpw);
     double* partial = static_cast<double*>(workspace);
     hipLaunchKernelGGL(ce_rows_kernel, dim3(nb), dim3(64 * WAVES), 0, s, logits, (long)ld_logits,
                        reinterpret_cast<const long*>(labels), (long)num_rows, num_classes, smoothing, dlogits,
-                       (long)ld_dlogits, partial);
+                       (long)ld_dlogits, partial, rpw);
     hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(64), 0, s, partial, nb, (long)num_rows, loss);
     DC_CHECK_LAUNCH("dc_ce_loss");
     return DC_OK;

@@ -534,8 +534,107 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+# ---- blocks on a handful of rows (classification head: one row per cloud): csrc/rowblock.hip ------------------------
+ROWBLOCK_MAX_ROWS = 64
+USE_ROWBLOCK = True        # A/B switch: False = the composed path (library GEMM + statistics + finaliser + activation)
+
+
+def _rowblock_ok(x, w):
+    return (USE_ROWBLOCK and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
+            and 1 <= x.shape[0] <= ROWBLOCK_MAX_ROWS and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and sync_group() is None)
+
+
+def _rowblock_dx(dh, w):
+    """d X = dH W on the MFMA GEMM (ragged M is guarded there)."""
+    m, n = dh.shape
+    k = w.shape[1]
+    dx = torch.empty(m, k, dtype=torch.float32, device=dh.device)
+    lib.call("dc_linear_backward_input", dh, dh.stride(0), w, w.stride(0), m, n, k, dx, k, 0, 0)
+    return dx
+
+
+class _RowBlock(torch.autograd.Function):
+    """[Linear(no bias) -> BatchNorm1d -> leaky(slope)] on <= 64 rows as ONE kernel forward (product, statistics over
+    the rows, finalisation, running statistics, activation) and one backward (BatchNorm / activation backward, d gamma,
+    d beta, dW) + the input gradient on the MFMA GEMM.  (models/deltanet_classification.py:34-36; nn/mlp.py:7-11.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, bn, slope):
+        x, w = _rowmajor(x), _rowmajor(w)
+        m, k = x.shape
+        n = w.shape[0]
+        check_bn_rows(bn, m)
+        use_batch = bn.training or bn.running_mean is None
+        mom = 0.0 if bn.momentum is None else float(bn.momentum)
+        track = bn.training and bn.track_running_stats
+        if track:
+            bump_counter(bn)
+            if bn.momentum is None:
+                mom = 1.0 / float(bn.num_batches_tracked)
+        rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
+        dev = x.device
+        h = torch.empty(m, n, dtype=torch.float32, device=dev)
+        y = torch.empty(m, n, dtype=torch.float32, device=dev)
+        coef = torch.empty(4, n, dtype=torch.float32, device=dev)
+        lib.call("dc_rowblock_forward", x, x.stride(0), w, w.stride(0), None, m, n, k, gamma, beta, float(bn.eps), mom, rm,
+                 rv, 1 if use_batch else 2, slope, h, n, coef, y, n)
+        ctx.save_for_backward(x, w, h, coef, gamma)
+        ctx.cfg = (use_batch, slope, gamma is not None, beta is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, h, coef, gamma = ctx.saved_tensors
+        use_batch, slope, has_g, has_b = ctx.cfg
+        dy = _c(dy)
+        m, n = dy.shape
+        k = x.shape[1]
+        dev = dy.device
+        dh = torch.empty(m, n, dtype=torch.float32, device=dev)
+        dw = torch.empty(n, k, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(n, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(n, dtype=torch.float32, device=dev)
+        lib.call("dc_rowblock_backward", dy, dy.stride(0), h, n, coef, gamma, slope, 1 if use_batch else 2, x, x.stride(0),
+                 m, n, k, dw, k, None, dgamma, dbeta, dh, n)
+        dx = _rowblock_dx(dh, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, dgamma if has_g else None, dbeta if has_b else None, None, None
+
+
+class _RowLinear(torch.autograd.Function):
+    """y = x W^T (+ b) on <= 64 rows (the last Linear of the classification head, deltanet_classification.py:36)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x, w = _rowmajor(x), _rowmajor(w)
+        m, k = x.shape
+        n = w.shape[0]
+        y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        lib.call("dc_rowblock_forward", x, x.stride(0), w, w.stride(0), b, m, n, k, None, None, 0.0, 0.0, None, None, 0, 1.0,
+                 y, n, None, y, n)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        m, n = dy.shape
+        k = x.shape[1]
+        dev = dy.device
+        dw = torch.empty(n, k, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        db = torch.empty(n, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        dh = torch.empty(m, n, dtype=torch.float32, device=dev)
+        lib.call("dc_rowblock_backward", dy, dy.stride(0), None, n, None, None, 1.0, 0, x, x.stride(0), m, n, k, dw, k, db,
+                 None, None, dh, n)
+        dx = _rowblock_dx(dh, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, db
+
+
 def linear(x, w, b=None):
     """F.linear on the hand-written GEMM kernels (2-D fp32 GPU inputs; otherwise torch)."""
+    if _rowblock_ok(x, w):
+        return _RowLinear.apply(x, w, b)
     if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
         return _Linear.apply(x, w, b)
     return F.linear(x, w, b)
@@ -569,6 +668,8 @@ class _LinearBNAct(torch.autograd.Function):
 
 def linear_bn_act(x, lin, bn, slope, residual=None):
     """[Linear(no bias) -> BatchNorm1d -> leaky(slope)](x) (+ residual); lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d."""
+    if lin.bias is None and residual is None and _rowblock_ok(x, lin.weight):
+        return _RowBlock.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope))
     if (lin.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and sync_group() is None):
         return _LinearBNAct.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope), residual)
     return bn_act(linear(x, lin.weight, lin.bias), bn, slope, residual)

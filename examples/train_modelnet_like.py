@@ -25,7 +25,6 @@ from deltaconv_amd.models import DeltaNetClassification
 from deltaconv_amd.utils import calc_loss
 from deltaconv_amd.dp import FlatGradDataParallel
 from deltaconv_amd.data import synthetic_batch
-from deltaconv_amd.tuning import enable_tuned_gemms
 
 
 def make_split(num_batches, batch_size, points, seed, device):
@@ -84,7 +83,6 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    enable_tuned_gemms()
     torch.manual_seed(1)
     model = DeltaNetClassification(3, 40, num_neighbors=args.k, grad_regularizer=args.grad_regularizer).to(dev)
     ddp = FlatGradDataParallel(model)

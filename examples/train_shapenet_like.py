@@ -24,7 +24,6 @@ from deltaconv_amd.models import DeltaNetSegmentation
 from deltaconv_amd.utils import calc_loss, calc_shape_IoU
 from deltaconv_amd.dp import FlatGradDataParallel
 from deltaconv_amd.data import synthetic_batch
-from deltaconv_amd.tuning import enable_tuned_gemms
 
 
 def shapenet_model(args, num_classes):
@@ -101,7 +100,6 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    enable_tuned_gemms()
     torch.manual_seed(1)
     model = shapenet_model(args, 50).to(dev)
     ddp = FlatGradDataParallel(model)

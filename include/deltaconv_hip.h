@@ -349,6 +349,23 @@ int dc_ce_loss(const float* logits, int64_t ld_logits, const int64_t* labels, in
                float smoothing, float* loss, float* dlogits, int64_t ld_dlogits, void* workspace,
                size_t workspace_bytes, void* stream);
 
+/* ---- MLP blocks on a handful of rows: the classification head, one row per cloud --------------------------------
+ * (/root/reference/deltaconv/models/deltanet_classification.py:34-36,51: MLP([2048,512]) -> Dropout -> MLP([512,256]) ->
+ * Dropout -> Linear(256, num_classes); blocks = nn/mlp.py:7-11).  One kernel per block and direction: product +
+ * BatchNorm statistics over the rows + finalisation + running statistics + activation forward; BatchNorm / activation
+ * backward + d gamma / d beta + weight gradient backward (the input gradient dX = dH W is dc_linear_backward_input).
+ * mode 0 = Linear (+ bias) only, 1 = BatchNorm with batch statistics, 2 = with running statistics.
+ * M <= dc_rowblock_max_rows() (64), K % 4 == 0, rows of X / W / dW 16-byte aligned.  coef[4,N] = mean, invstd, scale,
+ * shift (written forward, read backward); H = the Linear output (saved for backward; mode 0: Y may alias H). */
+int32_t dc_rowblock_max_rows(void);
+int dc_rowblock_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int32_t M, int32_t N,
+                        int32_t K, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                        float* running_var, int32_t mode, float slope, float* H, int64_t ldh, float* coef, float* Y,
+                        int64_t ldy, void* stream);
+int dc_rowblock_backward(const float* dY, int64_t lddy, const float* H, int64_t ldh, const float* coef, const float* gamma,
+                         float slope, int32_t mode, const float* X, int64_t ldx, int32_t M, int32_t N, int32_t K, float* dW,
+                         int64_t lddw, float* dbias, float* dgamma, float* dbeta, float* dH, int64_t lddh, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

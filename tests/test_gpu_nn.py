@@ -7,6 +7,7 @@ import torch
 
 import oracle
 from tests.helpers import rel_err
+from deltaconv_amd.data import synthetic_batch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -391,3 +392,97 @@ def test_knn_max_affine_equals_bn_act_then_max(n_clouds, N, k, C, slope):
     o2, a2 = torch.empty_like(h), torch.empty(n, C, dtype=torch.uint8, device=DEV)
     lib.call("dc_knn_max_affine", g.nbr, n, k, h, C, C, scale, shift, slope, o2, C, a2)
     assert torch.equal(o1, o2) and torch.equal(a1, a2)
+
+
+# ---------------------------------------------------------------------------------- blocks on a handful of rows
+@pytest.mark.parametrize("M", [2, 7, 32, 33, 64])
+@pytest.mark.parametrize("K,N", [(2048, 512), (512, 256), (256, 40), (64, 10)])
+def test_rowblock_block_vs_torch_fp64(M, K, N):
+    """csrc/rowblock.hip (the classification head: one row per cloud): [Linear -> BatchNorm over the rows -> LeakyReLU] as
+    one kernel per direction against torch in fp64: output, input / weight / gamma / beta gradients, running statistics;
+    train and eval mode."""
+    from deltaconv_amd.nn import fused
+    from deltaconv_amd.nn.nonlin import BatchNorm1d
+    torch.manual_seed(M * 1000 + N)
+    x = torch.randn(M, K)
+    lin = torch.nn.Linear(K, N, bias=False)
+    bn = BatchNorm1d(N)
+    with torch.no_grad():
+        bn.bn.weight.uniform_(0.5, 1.5)
+        bn.bn.bias.uniform_(-0.5, 0.5)
+    g = torch.randn(M, N)
+    for training in (True, False):
+        # fp64 reference
+        xr = x.double().requires_grad_(True)
+        wr = lin.weight.detach().double().requires_grad_(True)
+        gr, br = bn.bn.weight.detach().double().requires_grad_(True), bn.bn.bias.detach().double().requires_grad_(True)
+        rm, rv = bn.bn.running_mean.double().clone(), bn.bn.running_var.double().clone()
+        yr = torch.nn.functional.leaky_relu(
+            torch.nn.functional.batch_norm(xr @ wr.t(), rm, rv, gr, br, training, 0.1, 1e-5), 0.2)
+        yr.backward(g.double())
+        # device
+        lin_d = torch.nn.Linear(K, N, bias=False).to(DEV)
+        lin_d.load_state_dict(lin.state_dict())
+        bn_d = BatchNorm1d(N).to(DEV)
+        bn_d.load_state_dict(bn.state_dict())
+        bn_d.train(training)
+        xd = x.to(DEV).requires_grad_(True)
+        assert fused._rowblock_ok(xd, lin_d.weight)
+        yd = fused.linear_bn_act(xd, lin_d, bn_d.bn, 0.2)
+        yd.backward(g.to(DEV))
+        tol = 2e-5
+        assert rel_err(yd, yr) < tol
+        assert rel_err(xd.grad, xr.grad) < 5 * tol and rel_err(lin_d.weight.grad, wr.grad) < 5 * tol
+        assert rel_err(bn_d.bn.weight.grad, gr.grad) < 5 * tol and rel_err(bn_d.bn.bias.grad, br.grad) < 5 * tol
+        if training:
+            assert rel_err(bn_d.bn.running_mean, rm) < tol and rel_err(bn_d.bn.running_var, rv) < tol
+            assert int(bn_d.bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("M", [1, 32, 64])
+def test_rowblock_linear_with_bias(M):
+    from deltaconv_amd.nn import fused
+    torch.manual_seed(M)
+    K, N = 256, 40
+    x, w, b, g = torch.randn(M, K), torch.randn(N, K) / 16, torch.randn(N), torch.randn(M, N)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    (xr @ wr.t() + br).backward(g.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = fused.linear(xd, wd, bd)
+    y.backward(g.to(DEV))
+    assert rel_err(y, (xr @ wr.t() + br)) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+def test_rowblock_equals_composed_path_in_the_model():
+    """The whole classification model with the head through csrc/rowblock.hip and through the composed path (library
+    GEMM + statistics + finaliser + activation): logits and every parameter gradient agree to fp32 rounding."""
+    import deltaconv_amd as dc
+    from deltaconv_amd.nn import fused
+    from deltaconv_amd.utils import calc_loss
+    b = synthetic_batch(8, 256, seed=77).to(DEV)
+
+    def run(use):
+        fused.USE_ROWBLOCK = use
+        try:
+            torch.manual_seed(2)
+            m = dc.models.DeltaNetClassification(3, 40).to(DEV).train()
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+            out = m(b)
+            calc_loss(out, b.y).backward()
+            return out.detach(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, \
+                {n: t.clone() for n, t in m.named_buffers()}
+        finally:
+            fused.USE_ROWBLOCK = True
+
+    o1, g1, b1 = run(True)
+    o0, g0, b0 = run(False)
+    assert rel_err(o1, o0) < 1e-5
+    assert g1.keys() == g0.keys()
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for n in g0:
+        assert float((g1[n] - g0[n]).abs().max()) < 2e-5 * max(float(g0[n].abs().max()), 1e-3 * gmax), n
+    for n in b0:
+        assert rel_err(b1[n].float(), b0[n].float()) < 1e-5, n

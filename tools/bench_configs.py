@@ -45,12 +45,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the config name")
     ap.add_argument("--eager-only", action="store_true", help="only the eager train step (for rocprofv3 runs)")
-    ap.add_argument("--tuned", action="store_true", help="TunableOp GEMM selection (tunes unseen shapes on the fly)")
     args = ap.parse_args()
     dev = "cuda"
-    if args.tuned:
-        from deltaconv_amd.tuning import enable_tuned_gemms
-        enable_tuned_gemms(tune_missing=True)
     print(f"# {torch.cuda.get_device_name(0)}, torch {torch.__version__}; ms per step / clouds per second")
     print(f"{'config':44s} {'train eager':>18s} {'train graph':>18s} {'eval fwd':>18s}")
     for name, (B, N, k, normals, kind, kw, bkw, optname) in CONFIGS.items():

@@ -7,9 +7,6 @@ import deltaconv_amd as dc
 from deltaconv_amd.utils import calc_loss
 from deltaconv_amd.data import synthetic_batch
 from deltaconv_amd.dp import FlatGradDataParallel
-from deltaconv_amd.tuning import enable_tuned_gemms
-if os.environ.get('DC_TUNED', '1') == '1':
-    enable_tuned_gemms()
 dev = "cuda"
 torch.manual_seed(1)
 model = dc.models.DeltaNetClassification(3, 40).to(dev).train()
