@@ -293,15 +293,13 @@ def main():
             ddp.reduce_gradients()
             opt.step()
         try:
-            gstep = GraphedTrainStep(model, calc_loss, static, optimizer=None if use_dist else opt)
+            # one rank: the whole step is one graph.  Data parallel: replay (forward + loss + backward + gradient pack)
+            # -> the one all-reduce -> replay (1/world scale + SGD update): three host calls per step
+            gstep = GraphedTrainStep(model, calc_loss, static, optimizer=opt, reducer=ddp if use_dist else None)
 
             def step():
-                loss = gstep(next_batch())
-                if use_dist:
-                    ddp.reduce_gradients()
-                    opt.step()
-                return loss
-            launch = "HIP-graph replay"
+                return gstep(next_batch())
+            launch = "HIP-graph replay" if not use_dist else "HIP-graph replay x2 around the gradient all-reduce"
         except Exception as e:                               # keep measuring (eagerly) and say so in the output
             print(f"[bench] HIP-graph capture failed, falling back to eager launches: {e!r}", file=sys.stderr)
             torch.cuda.synchronize()

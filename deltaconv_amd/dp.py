@@ -116,7 +116,9 @@ def convert_sync_batchnorm(module):
 class FlatGradDataParallel:
     """Wraps a module: ``zero_grad()`` -> forward/backward as usual -> ``reduce_gradients()``.
     sync_bn=True: BatchNorm statistics over the global batch (see above); the statistics collectives run inside
-    forward and backward, so the HIP-graph step is not available in that mode."""
+    forward and backward, so the HIP-graph step is not available in that mode.
+    With graph_step.GraphedTrainStep(..., optimizer=opt, reducer=this) a data-parallel step is three host calls:
+    replay (forward + loss + backward + gradient pack) -> one all-reduce -> replay (scale + optimizer update)."""
 
     def __init__(self, module, process_group=None, broadcast=True, always_reduce=False, sync_bn=False):
         self.module = module
@@ -151,17 +153,38 @@ class FlatGradDataParallel:
             off += p.numel()
         return views
 
+    # ---- the three pieces of reduce_gradients(), separately, for the two-graph step (graph_step.GraphedTrainStep with
+    # reducer=...): pack (captured behind the backward pass) -> all-reduce (eager: a collective) -> scale + re-point
+    # (the scale is captured in front of the optimizer update)
+    def active(self):
+        return self.world > 1 or (self.always_reduce and dist.is_initialized())
+
+    def pack(self):
+        """Copy the gradients into the flat buffer (one multi-tensor copy) and re-point .grad at its views."""
+        live = [p for p in self.params if p.grad is not None]
+        self.views = self._ensure_flat(live)
+        torch._foreach_copy_(self.views, [p.grad for p in live])
+        self.live = live
+        return live
+
+    def repoint(self):
+        for p, v in zip(self.live, self.views):
+            p.grad = v
+
+    def all_reduce(self):
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def scale(self):
+        self.flat.div_(self.world)
+
     def reduce_gradients(self):
         """Average gradients over ranks: one all-reduce of the flat buffer (no-op on 1 rank).
         Parameters that received no gradient (e.g. VectorNonLin.bias under BatchNorm, reference
         nn/nonlin.py:74-77) are skipped -- identically on every rank, since the model is replicated."""
         if self.world == 1 and not (self.always_reduce and dist.is_initialized()):
             return None
-        live = [p for p in self.params if p.grad is not None]
-        views = self._ensure_flat(live)
-        torch._foreach_copy_(views, [p.grad for p in live])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-        self.flat.div_(self.world)
-        for p, v in zip(live, views):
-            p.grad = v
+        self.pack()
+        self.all_reduce()
+        self.scale()
+        self.repoint()
         return self.flat

@@ -30,20 +30,29 @@ _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, sample_batch, optimizer=None, warmup=3):
+    def __init__(self, model, loss_fn, sample_batch, optimizer=None, warmup=3, reducer=None):
         """sample_batch: a deltaconv_amd.Batch on the GPU whose tensors become the static inputs.
         optimizer: captured into the graph when given (its first `warmup` steps are real updates, so
-        lazily created state such as momentum buffers exists before the capture)."""
+        lazily created state such as momentum buffers exists before the capture).
+        reducer: a dp.FlatGradDataParallel whose all-reduce runs between TWO captured graphs -- graph A = forward +
+        loss + backward + the gradient pack into the flat buffer, graph B = the 1/world scale + the optimizer update
+        on views of that buffer: a data-parallel step is replay -> all-reduce -> replay, three host calls instead of
+        the eager pack / div / multi-tensor-update launches behind every replay (1-2 clouds per rank: host-bound)."""
         if os.environ.get(_FLAG, "1") != "0":
             raise RuntimeError(f"GraphedTrainStep needs {_FLAG}=0 in the environment before the HIP runtime "
                                "starts (import deltaconv_amd before the first torch.cuda call, or export it)")
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
+        self.reducer = reducer if (reducer is not None and reducer.active()) else None
+        if self.reducer is not None:
+            assert optimizer is not None, "the two-graph data-parallel step captures the optimizer update"
         self.static = sample_batch
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.warmup = warmup
         self.recapture()
 
     def recapture(self):
+        if self.reducer is not None and self.reducer.flat is None and self.warmup == 0:
+            self.warmup = 1                     # the flat gradient buffer must exist before the capture
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up outside the capture (allocator, tuning)
@@ -54,9 +63,17 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
+        self.graph_update = None
         with torch.cuda.graph(self.graph):
-            self.loss, self.out = self._step()
+            self.loss, self.out = self._step(capture=True)
         torch.cuda.synchronize()
+        if self.reducer is not None:            # graph B: scale + update, reading .grad = views of the flat buffer
+            self.reducer.repoint()
+            self.graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_update):
+                self.reducer.scale()
+                self.optimizer.step()
+            torch.cuda.synchronize()
         invalidate_eval_coeffs()
         self.grads = [(p, p.grad) for p in self.params if p.grad is not None]   # rewritten by every replay
 
@@ -64,11 +81,18 @@ class GraphedTrainStep:
         for p in self.params:
             p.grad = None
 
-    def _step(self):
+    def _step(self, capture=False):
         out = self.model(self.static)
         loss = self.loss_fn(out, self.static.y)
         loss.backward()
-        if self.optimizer is not None:
+        if self.reducer is not None:
+            self.reducer.pack()                 # captured: one multi-tensor copy into the flat buffer
+            if not capture:                     # warm-up steps: the rest of the reduction + the update, eagerly
+                self.reducer.all_reduce()
+                self.reducer.scale()
+                self.reducer.repoint()
+                self.optimizer.step()
+        elif self.optimizer is not None:
             self.optimizer.step()
         return loss.detach(), out.detach()
 
@@ -87,6 +111,9 @@ class GraphedTrainStep:
         if batch is not None:
             self.load(batch)
         self.graph.replay()
+        if self.graph_update is not None:
+            self.reducer.all_reduce()           # the one collective of the step, between the two replays
+            self.graph_update.replay()
         invalidate_eval_coeffs()      # the replay moved running statistics (and parameters) without a version bump
         for p, g in self.grads:       # a gradient reducer may have re-pointed .grad at its own buffer
             p.grad = g

@@ -3,6 +3,8 @@ RCCL process group with one rank, so every collective code path executes.
   1. GraphedTrainStep (HIP-graph replay of forward + loss + backward) + FlatGradDataParallel.reduce_gradients()
      (which re-points .grad at views of its flat buffer) + optimizer step, 3 steps on changing batches
      == the same 3 steps run eagerly: parameters and BatchNorm buffers bit-identical.
+  1b. the two-graph step (GraphedTrainStep(..., optimizer, reducer)): gradient pack captured behind the backward pass,
+     scale + optimizer update captured as a second graph, the all-reduce between the replays == eager, bit-identical.
   2. sync_bn=True (split statistics kernels + all-reduce of the fp64 sums, composed layer path) on one rank
      == per-rank statistics (fused layer path): logits / gradients agree to fp32 rounding.
 Prints one JSON line."""
@@ -62,6 +64,18 @@ def main():
         o2.step()
     sd1, sd2 = m1.state_dict(), m2.state_dict()
     res["graph_dp_mismatches"] = [k for k in sd1 if not torch.equal(sd1[k], sd2[k])]
+
+    # ---- 1b. the two-graph data-parallel step: replay (fwd + loss + bwd + gradient pack) -> all-reduce -> replay
+    # (scale + optimizer update) == the same steps run eagerly
+    m5, o5 = make()
+    d5 = dp.FlatGradDataParallel(m5, always_reduce=True)
+    static5 = synthetic_batch(4, 256, seed=60).to("cuda")
+    step5 = GraphedTrainStep(m5, calc_loss, static5, optimizer=o5, warmup=2, reducer=d5)
+    assert step5.graph_update is not None
+    for b in batches:
+        step5(b)
+    sd5 = m5.state_dict()
+    res["two_graph_dp_mismatches"] = [k for k in sd1 if not torch.equal(sd1[k], sd5[k])]
 
     # ---- 2. synchronised BatchNorm on one rank vs per-rank statistics
     b = batches[1]
