@@ -147,7 +147,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
     try:
         import json as _json
         pmc = _json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_divcurlnorm.json")))
-        if C == 64 and n == 32768 and k == 20:
+        if C == 64 and n == 32768 and k == 20 and tiled:      # the counters were taken on the tiled kernel
             traffic, traffic_tag = pmc["traffic_bytes"], pmc.get("tag")
     except Exception:
         pass

@@ -52,8 +52,11 @@ int check_common(const char* name, const void* a, const void* b, const void* c, 
         DC_REQUIRE(ldi >= (MINLDI) && ldo >= (MINLDO), #FN ": leading dimension smaller than the row");           \
         if (n == 0 || C == 0) return DC_OK;                                                                       \
         hipStream_t s = static_cast<hipStream_t>(stream);                                                         \
-        if (pick_v(C, {(long)ldi, (long)ldo}, {in, out}) == 4)                                                    \
+        const int vw = pick_v(C, {(long)ldi, (long)ldo}, {in, out});                                              \
+        if (vw == 4)                                                                                              \
             launch_fwd<4>(n, C, coef, nbr, k, BODY<4>{in, (long)ldi, out, (long)ldo, C}, s);                      \
+        else if (vw == 2)                                                                                         \
+            launch_fwd<2>(n, C, coef, nbr, k, BODY<2>{in, (long)ldi, out, (long)ldo, C}, s);                      \
         else                                                                                                      \
             launch_fwd<1>(n, C, coef, nbr, k, BODY<1>{in, (long)ldi, out, (long)ldo, C}, s);                      \
         DC_CHECK_LAUNCH(#FN);                                                                                     \
@@ -76,8 +79,11 @@ DC_FWD_ENTRY(dc_apply_hodge, HodgeF, 2 * C, C)
         DC_REQUIRE(ldy >= (MINLDY) && ldx >= (MINLDX), #FN ": leading dimension smaller than the row");           \
         if (n == 0 || C == 0) return DC_OK;                                                                       \
         hipStream_t s = static_cast<hipStream_t>(stream);                                                         \
-        if (pick_v(C, {(long)ldy, (long)ldx}, {dy, dx}) == 4)                                                     \
+        const int vw = pick_v(C, {(long)ldy, (long)ldx}, {dy, dx});                                               \
+        if (vw == 4)                                                                                              \
             launch_T<4>(n, C, coefT, tptr, tedge, k, OP<4>{dy, (long)ldy, dx, (long)ldx, accumulate, C}, s);      \
+        else if (vw == 2)                                                                                         \
+            launch_T<2>(n, C, coefT, tptr, tedge, k, OP<2>{dy, (long)ldy, dx, (long)ldx, accumulate, C}, s);      \
         else                                                                                                      \
             launch_T<1>(n, C, coefT, tptr, tedge, k, OP<1>{dy, (long)ldy, dx, (long)ldx, accumulate, C}, s);      \
         DC_CHECK_LAUNCH(#FN);                                                                                     \
@@ -98,8 +104,11 @@ DC_EXPORT int dc_apply_grad_T_sum(const float* GT, const int32_t* tptr, const in
     if (n == 0 || C == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const long ldb_ = b ? (long)ldb : (long)lda;
-    if (pick_v(C, {(long)ldy, (long)lda, ldb_, (long)ldo}, {dy, a, b ? b : a, out}) == 4)
+    const int vw = pick_v(C, {(long)ldy, (long)lda, ldb_, (long)ldo}, {dy, a, b ? b : a, out});
+    if (vw == 4)
         launch_T<4>(n, C, GT, tptr, tedge, k, GradTSum<4>{dy, (long)ldy, a, (long)lda, b, (long)ldb, out, (long)ldo, C}, s);
+    else if (vw == 2)
+        launch_T<2>(n, C, GT, tptr, tedge, k, GradTSum<2>{dy, (long)ldy, a, (long)lda, b, (long)ldb, out, (long)ldo, C}, s);
     else
         launch_T<1>(n, C, GT, tptr, tedge, k, GradTSum<1>{dy, (long)ldy, a, (long)lda, b, (long)ldb, out, (long)ldo, C}, s);
     DC_CHECK_LAUNCH("dc_apply_grad_T_sum");
@@ -114,9 +123,13 @@ DC_EXPORT int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, con
     DC_REQUIRE(ldo >= 3 * C && ldv >= C && lddv >= C, "dc_apply_div_curl_norm_T: leading dimension smaller than the row");
     if (n == 0 || C == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (pick_v(C, {(long)ldo, (long)ldv, (long)lddv}, {dout, v, dv}) == 4)
+    const int vw = pick_v(C, {(long)ldo, (long)ldv, (long)lddv}, {dout, v, dv});
+    if (vw == 4)
         launch_T<4>(n, C, DT, tptr, tedge, k,
                     DivCurlNormT<4>{dout, (long)ldo, v, (long)ldv, dv, (long)lddv, accumulate, C}, s);
+    else if (vw == 2)
+        launch_T<2>(n, C, DT, tptr, tedge, k,
+                    DivCurlNormT<2>{dout, (long)ldo, v, (long)ldv, dv, (long)lddv, accumulate, C}, s);
     else
         launch_T<1>(n, C, DT, tptr, tedge, k,
                     DivCurlNormT<1>{dout, (long)ldo, v, (long)ldv, dv, (long)lddv, accumulate, C}, s);

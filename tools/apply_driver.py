@@ -18,6 +18,7 @@ ap.add_argument("--k", type=int, default=20)
 ap.add_argument("--C", type=int, default=64)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--opt", type=int, nargs=2, action="append", default=[])
+ap.add_argument("--gather", action="store_true", help="the gather-path kernels instead of the product's dispatch (tile plan)")
 a = ap.parse_args()
 for key, val in a.opt:
     lib.raw("dc_set_option")(key, val)
@@ -33,9 +34,15 @@ y2 = torch.empty(2 * n, C, device="cuda")
 y1 = torch.empty(n, C, device="cuda")
 y3 = torch.empty(n, 3 * C, device="cuda")
 torch.cuda.synchronize()
+from deltaconv_amd import _ops                                      # noqa: E402
+if a.gather:
+    g._tile_plan = False
+else:
+    g.tile_plan(force_P=64 if k <= 24 else 32)          # the plan the training step uses at this size
+    torch.cuda.synchronize()
 for _ in range(a.iters):
-    lib.call("dc_apply_grad", grad.coef, g.nbr, n, k, x, C, C, y2, C)
-    lib.call("dc_apply_div", div.coef, g.nbr, n, k, v, C, C, y1, C)
-    lib.call("dc_apply_div_curl_norm", div.coef, g.nbr, n, k, v, C, C, y3, 3 * C)
+    _ops.fwd_apply("grad", grad, x, C, C, y2, C)
+    _ops.fwd_apply("div", div, v, C, C, y1, C)
+    _ops.fwd_apply("div_curl_norm", div, v, C, C, y3, 3 * C)
 torch.cuda.synchronize()
 print("done", n, k, C)

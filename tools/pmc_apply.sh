@@ -12,10 +12,11 @@ run() {  # name, counters..., then -- driver args
   echo "$name rc=$?"; python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/$name | tee $OUT/$name.summary.txt
   find $OUT/$name -name "*.csv" -size +5M -delete
 }
-for cfg in "c2 --batch 32" "big --batch 512 --iters 5"; do
+for cfg in "c2 --batch 32" "c2gather --batch 32 --gather" "big --batch 512 --iters 5" "biggather --batch 512 --iters 5 --gather"; do
   set -- $cfg; tag=$1; shift
   run ${tag}_fetch FETCH_SIZE -- "$@"
   run ${tag}_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- "$@"
   run ${tag}_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM -- "$@"
   run ${tag}_tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr -- "$@"
+  run ${tag}_lds SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -- "$@"
 done

@@ -15,7 +15,9 @@ for row in csv.DictReader(open(files[0])):
     name = row.get("Kernel_Name", "")
     if "fwd_kernel" not in name and "_T_kernel" not in name:
         continue
-    short = name.split("(")[0].split("::")[-1]
+    import re
+    m = re.search(r"tile_fwd_kernel<\d+, \d+, dctile::(\w+)", name)
+    short = ("tile_" + m.group(1)) if m else name.split("(")[0].split("::")[-1]
     acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kname, ctrs in acc.items():
     print(kname, {c: round(sum(v) / len(v), 1) for c, v in ctrs.items()}, "dispatches", len(next(iter(ctrs.values()))))
