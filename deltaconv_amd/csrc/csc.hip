@@ -54,6 +54,48 @@ __global__ void csc_fill_kernel(const int* __restrict__ nbr, long ne, int* __res
     if (e < ne) tedge[atomicAdd(cursor + nbr[e], 1)] = (int)e;
 }
 
+// Count, scan and fill of ONE cloud in one workgroup (clouds of at most CLOUD_MAX points): the in-degree counters and
+// the fill cursors live in LDS (integer LDS atomics instead of 2 x E global atomics: csc_count + csc_scan + csc_fill +
+// the zero fill took 4.7 + 20 + 5 + 23 us at 32 x 1024 points, k = 20).  The columns come out unordered (as from
+// csc_fill_kernel) and are ordered by csc_rank_kernel afterwards: the result is the same bit for bit.
+constexpr int CLOUD_MAX = 4096, CLOUD_TPB = 1024;
+__global__ __launch_bounds__(CLOUD_TPB) void csc_cloud_kernel(const int* __restrict__ nbr, const int* __restrict__ cloud_ptr,
+                                                              int k, int num_clouds, int* __restrict__ tptr,
+                                                              int* __restrict__ unordered) {
+    __shared__ int cnt[CLOUD_MAX];
+    __shared__ int part[CLOUD_TPB];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
+    for (int q = tid; q < n; q += CLOUD_TPB) cnt[q] = 0;
+    __syncthreads();
+    const long e0 = (long)begin * k, ne = (long)n * k;
+    for (long e = tid; e < ne; e += CLOUD_TPB) atomicAdd(&cnt[nbr[e0 + e] - begin], 1);
+    __syncthreads();
+    // exclusive scan of cnt over the cloud (same partition as csc_scan_kernel: tptr is identical)
+    const int per = (n + CLOUD_TPB - 1) / CLOUD_TPB;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    int s = 0;
+    for (int q = lo; q < hi; ++q) s += cnt[q];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < CLOUD_TPB; off <<= 1) {        // inclusive Hillis-Steele scan of the partials
+        const int v = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = (int)e0 + (tid ? part[tid - 1] : 0);          // in-edges of earlier clouds + earlier partitions
+    if (cloud == num_clouds - 1 && tid == CLOUD_TPB - 1) tptr[begin + n] = (int)e0 + part[tid];   // = Nt * k
+    for (int q = lo; q < hi; ++q) {
+        const int c = cnt[q];
+        tptr[begin + q] = run;
+        cnt[q] = run;                                       // becomes the fill cursor
+        run += c;
+    }
+    __syncthreads();
+    for (long e = tid; e < ne; e += CLOUD_TPB) unordered[atomicAdd(&cnt[nbr[e0 + e] - begin], 1)] = (int)(e0 + e);
+}
+
 // Order every column by edge id without a serial sort: the rank of an entry = the number of smaller entries of its
 // column.  One wavefront per column: the lanes hold the column (64 entries at a time), every entry is broadcast
 // once (v_readlane) and compared by all lanes -- the column is read from memory once, not once per entry.
@@ -123,5 +165,29 @@ DC_EXPORT int dc_csc_build(const int32_t* nbr, const int32_t* cloud_ptr, int32_t
     hipLaunchKernelGGL(csc_rank_kernel, dim3(std::min<long>(dc_cdiv((long)num_points * 64, TPB), 256 * 16)), dim3(TPB), 0, s,
                        num_points, tptr, unordered, tedge);
     DC_CHECK_LAUNCH("dc_csc_build");
+    return DC_OK;
+}
+
+// dc_csc_build for clouds of at most 4096 points (max_cloud from the host): count + scan + fill of a cloud in ONE
+// workgroup with LDS counters, then the same column ranking: identical tptr / tedge.  Larger clouds: dc_csc_build.
+// workspace: the unordered fill [Nt*k] ints.
+DC_EXPORT int dc_csc_build_clouds(const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
+                                  int32_t max_cloud, int32_t k, int32_t* tptr, int32_t* tedge, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(nbr && cloud_ptr && tptr && tedge, "dc_csc_build_clouds: null pointer");
+    DC_REQUIRE(num_clouds >= 0 && num_points >= 0 && k >= 1 && max_cloud >= 0, "dc_csc_build_clouds: bad size");
+    DC_REQUIRE(max_cloud <= CLOUD_MAX, "dc_csc_build_clouds: clouds of more than 4096 points: use dc_csc_build");
+    DC_REQUIRE((long long)num_points * k < 2147483647LL, "dc_csc_build_clouds: edge ids overflow int32");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (num_points == 0 || num_clouds == 0) return DC_OK;
+    if (!workspace || workspace_bytes < (size_t)num_points * 4 * (size_t)k) {
+        dc_set_error("dc_csc_build_clouds: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    int* unordered = static_cast<int*>(workspace);
+    hipLaunchKernelGGL(csc_cloud_kernel, dim3(num_clouds), dim3(CLOUD_TPB), 0, s, nbr, cloud_ptr, k, num_clouds, tptr, unordered);
+    hipLaunchKernelGGL(csc_rank_kernel, dim3(std::min<long>(dc_cdiv((long)num_points * 64, TPB), 256 * 16)), dim3(TPB), 0, s,
+                       num_points, tptr, unordered, tedge);
+    DC_CHECK_LAUNCH("dc_csc_build_clouds");
     return DC_OK;
 }

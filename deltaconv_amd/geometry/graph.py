@@ -170,8 +170,12 @@ class Graph:
             tptr = torch.empty(self.n + 1, dtype=torch.int32, device=dev)
             tedge = torch.empty(self.n * self.k, dtype=torch.int32, device=dev)
             ws = torch.empty(self.n * (self.k + 1), dtype=torch.int32, device=dev)
-            lib.call("dc_csc_build", self.nbr, self.ptr, self.num_clouds, self.n, self.k, tptr, tedge, ws,
-                     ws.numel() * 4)
+            if self.max_cloud <= 4096:      # count + scan + fill of a cloud in one workgroup (LDS counters)
+                lib.call("dc_csc_build_clouds", self.nbr, self.ptr, self.num_clouds, self.n, self.max_cloud, self.k,
+                         tptr, tedge, ws, ws.numel() * 4)
+            else:
+                lib.call("dc_csc_build", self.nbr, self.ptr, self.num_clouds, self.n, self.k, tptr, tedge, ws,
+                         ws.numel() * 4)
             self._csc = (tptr, tedge)
         return self._csc
 

@@ -210,6 +210,28 @@ def test_csc_high_in_degree():
         assert bool((col[1:] > col[:-1]).all())
 
 
+def test_csc_cloud_builder_equals_general_builder():
+    """dc_csc_build_clouds (count + scan + fill of a cloud in one workgroup on LDS counters) returns exactly the tptr /
+    tedge of dc_csc_build: ragged clouds, duplicate points (hub columns), k = 20 and 30."""
+    from deltaconv_amd._lib import lib
+    from deltaconv_amd.geometry import Graph
+    for k, sizes in ((20, [512, 700, 300, 4096]), (30, [64, 1000, 2048])):
+        b = synthetic_batch(len(sizes), 0, seed=21, sizes=sizes, dup_frac=0.05).to(DEV)
+        gr = Graph.knn(b.pos, k, b.batch)
+        n = gr.n
+        outs = []
+        for name in ("dc_csc_build", "dc_csc_build_clouds"):
+            tptr = torch.full((n + 1,), -1, dtype=torch.int32, device=DEV)
+            tedge = torch.full((n * k,), -1, dtype=torch.int32, device=DEV)
+            ws = torch.empty(n * (k + 1), dtype=torch.int32, device=DEV)
+            if name == "dc_csc_build":
+                lib.call(name, gr.nbr, gr.ptr, gr.num_clouds, n, k, tptr, tedge, ws, ws.numel() * 4)
+            else:
+                lib.call(name, gr.nbr, gr.ptr, gr.num_clouds, n, gr.max_cloud, k, tptr, tedge, ws, ws.numel() * 4)
+            outs.append((tptr, tedge))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 # ---------------------------------------------------------------------------------- applies
 @pytest.fixture(scope="module")
 def ops():
