@@ -64,65 +64,88 @@ __device__ __forceinline__ double group_sum(double x) {
 // in flight while piece i is multiplied: all loads of a piece are issued together (a load -> store loop would wait for
 // every load in turn: 8 round trips per piece, 37 us for the [32 x 2048] block of the head).
 template <int SI>
-__device__ __forceinline__ void x_load(float4 (&stg)[SI], const float* __restrict__ X, long ldx, int M, int K, int kc) {
+__device__ __forceinline__ void x_load(float4 (&stg)[SI], const float* __restrict__ X, long ldx, int M, int K, int kc, int tid) {
 #pragma unroll
     for (int it = 0; it < SI; ++it) {
-        const int idx = threadIdx.x + it * TPB;
+        const int idx = tid + it * TPB;
         const int m = idx >> 6, k = kc + (idx & 63) * 4;
         stg[it] = (m < M && k < K) ? *reinterpret_cast<const float4*>(X + (long)m * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 template <int SI>
-__device__ __forceinline__ void x_store(float4* xs, const float4 (&stg)[SI]) {
+__device__ __forceinline__ void x_store(float4* xs, const float4 (&stg)[SI], int tid) {
 #pragma unroll
-    for (int it = 0; it < SI; ++it) xs[threadIdx.x + it * TPB] = stg[it];
+    for (int it = 0; it < SI; ++it) xs[tid + it * TPB] = stg[it];
 }
 
+// K-slices per workgroup: the pieces of the reduction index are a serial chain per wavefront (stage -> barrier -> multiply,
+// ~1.3 us each: 8 pieces at K = 2048), so a workgroup runs KS groups of 4 wavefronts, group s taking the pieces s, s + KS, ...
+// with its own LDS staging area; forward: the KS partial results of a column meet in LDS after the lane butterfly and are
+// added in slice order; backward (dW[n, k]): the slices own disjoint k ranges, nothing to combine.
+// forward: 4 x 32 KB (<= 32 rows) or 2 x 64 KB of staging; 1024-thread workgroups leave 128 registers per lane, so the
+// 4-slice form loads each piece right before it stores it (no register prefetch: two rounds at K = 2048).  backward keeps
+// 64 broadcast dh values per lane: 2 slices (512 threads, 256 registers).
+template <int CW> struct KSlices { static constexpr int KS = CW == 2 ? 4 : 2, KSB = 2; };
+
 template <int CW>
-__global__ __launch_bounds__(TPB) void rowblock_fwd_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ W,
-                                                           long ldw, const float* __restrict__ bias, int M, int N, int K,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float eps, float momentum, float* __restrict__ rmean,
-                                                           float* __restrict__ rvar, int mode, float slope,
-                                                           float* __restrict__ H, long ldh, float* __restrict__ coef,
-                                                           float* __restrict__ Y, long ldy) {
-    constexpr int RM = RB<CW>::RM;
+__global__ __launch_bounds__(TPB * KSlices<CW>::KS) void rowblock_fwd_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ W, long ldw, const float* __restrict__ bias, int M, int N,
+    int K, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
+    float* __restrict__ rvar, int mode, float slope, float* __restrict__ H, long ldh, float* __restrict__ coef,
+    float* __restrict__ Y, long ldy) {
+    constexpr int RM = RB<CW>::RM, KS = KSlices<CW>::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* xs = reinterpret_cast<float4*>(smem);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ks = threadIdx.x / TPB, tid = threadIdx.x - ks * TPB;           // k-slice, thread inside its 4 wavefronts
+    float4* xs = reinterpret_cast<float4*>(smem) + (size_t)ks * RM * 64;
+    const int lane = tid & 63, wave = tid >> 6;
     const int n0 = (blockIdx.x * (TPB / 64) + wave) * CW;
     float v[64];
 #pragma unroll
     for (int j = 0; j < 64; ++j) v[j] = 0.f;
     constexpr int SI = RM * 64 / TPB;
+    constexpr bool PREFETCH = KS < 4;
     float4 stg[SI];
-    x_load<SI>(stg, X, ldx, M, K, 0);
-    for (int kc = 0; kc < K; kc += KC) {
+    if (PREFETCH) x_load<SI>(stg, X, ldx, M, K, ks * KC, tid);
+    const int rounds = (K + KC * KS - 1) / (KC * KS);                           // the same for every slice: barriers match
+    for (int r = 0; r < rounds; ++r) {
+        const int kc = (r * KS + ks) * KC;                                      // >= K: an all-zero piece
+        if (!PREFETCH) x_load<SI>(stg, X, ldx, M, K, kc, tid);
         const int k = kc + lane * 4;
         float4 w4[CW];
 #pragma unroll
         for (int c = 0; c < CW; ++c)
             w4[c] = (k < K && n0 + c < N) ? *reinterpret_cast<const float4*>(W + (long)(n0 + c) * ldw + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
-        x_store<SI>(xs, stg);
+        x_store<SI>(xs, stg, tid);
         __syncthreads();
-        if (kc + KC < K) x_load<SI>(stg, X, ldx, M, K, kc + KC);
+        if (PREFETCH && r + 1 < rounds) x_load<SI>(stg, X, ldx, M, K, kc + KC * KS, tid);
+        if (kc < K) {
 #pragma unroll
-        for (int m = 0; m < RM; ++m)
-            if (m < M) {
-                const float4 x4 = xs[m * 64 + lane];
+            for (int m = 0; m < RM; ++m)
+                if (m < M) {
+                    const float4 x4 = xs[m * 64 + lane];
 #pragma unroll
-                for (int c = 0; c < CW; ++c) {
-                    float a = v[c * RM + m];
-                    a = fmaf(w4[c].x, x4.x, a);
-                    a = fmaf(w4[c].y, x4.y, a);
-                    a = fmaf(w4[c].z, x4.z, a);
-                    a = fmaf(w4[c].w, x4.w, a);
-                    v[c * RM + m] = a;
+                    for (int c = 0; c < CW; ++c) {
+                        float a = v[c * RM + m];
+                        a = fmaf(w4[c].x, x4.x, a);
+                        a = fmaf(w4[c].y, x4.y, a);
+                        a = fmaf(w4[c].z, x4.z, a);
+                        a = fmaf(w4[c].w, x4.w, a);
+                        v[c * RM + m] = a;
+                    }
                 }
-            }
+        }
     }
-    float h = halve64(v, lane);
+    float hp = halve64(v, lane);
+    // the KS partial results of (column, row): through LDS, added in slice order by slice 0
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                                // [KS][TPB]
+    red[ks * TPB + tid] = hp;
+    __syncthreads();
+    if (ks != 0) return;
+    float h = red[tid];
+#pragma unroll
+    for (int q = 1; q < KS; ++q) h += red[q * TPB + tid];
     const int c = lane / RM, m = lane - c * RM, n = n0 + c;
     const bool col = n < N, ok = col && m < M;
     if (mode == 0) {
@@ -175,17 +198,16 @@ __global__ __launch_bounds__(TPB) void rowblock_fwd_kernel(const float* __restri
 }
 
 template <int CW>
-__global__ __launch_bounds__(TPB) void rowblock_bwd_kernel(const float* __restrict__ dY, long lddy, const float* __restrict__ H,
-                                                           long ldh, const float* __restrict__ coef,
-                                                           const float* __restrict__ gamma, float slope, int mode,
-                                                           const float* __restrict__ X, long ldx, int M, int N, int K,
-                                                           float* __restrict__ dW, long lddw, float* __restrict__ dbias,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           float* __restrict__ dH, long lddh) {
-    constexpr int RM = RB<CW>::RM;
+__global__ __launch_bounds__(TPB * KSlices<CW>::KSB) void rowblock_bwd_kernel(
+    const float* __restrict__ dY, long lddy, const float* __restrict__ H, long ldh, const float* __restrict__ coef,
+    const float* __restrict__ gamma, float slope, int mode, const float* __restrict__ X, long ldx, int M, int N, int K,
+    float* __restrict__ dW, long lddw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dH, long lddh) {
+    constexpr int RM = RB<CW>::RM, KS = KSlices<CW>::KSB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* xs = reinterpret_cast<float4*>(smem);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ks = threadIdx.x / TPB, tid = threadIdx.x - ks * TPB;
+    float4* xs = reinterpret_cast<float4*>(smem) + (size_t)ks * RM * 64;
+    const int lane = tid & 63, wave = tid >> 6;
     const int n0 = (blockIdx.x * (TPB / 64) + wave) * CW;
     const int c = lane / RM, m = lane - c * RM, n = n0 + c;
     const bool col = n < N, ok = col && m < M;
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(TPB) void rowblock_bwd_kernel(const float* __restri
     if (mode == 0) {
         dh = dy;
         const double s0 = group_sum<RM>((double)dy);
-        if (dbias && m == 0 && col) dbias[n] = (float)s0;
+        if (dbias && m == 0 && col && ks == 0) dbias[n] = (float)s0;
     } else {
         const float h = ok ? H[(long)m * ldh + n] : 0.f;
         const float mu = col ? coef[n] : 0.f, is = col ? coef[N + n] : 0.f, sc = col ? coef[2 * N + n] : 0.f,
@@ -203,14 +225,14 @@ __global__ __launch_bounds__(TPB) void rowblock_bwd_kernel(const float* __restri
         dcnn::bn_bwd_terms(dy, h, sc, sh, mu, is, slope, dz, dzx);
         if (!ok) { dz = 0.f; dzx = 0.f; }
         const double s0 = group_sum<RM>((double)dz), s1 = group_sum<RM>((double)dzx);
-        if (m == 0 && col) {
+        if (m == 0 && col && ks == 0) {
             if (dbeta) dbeta[n] = (float)s0;
             if (dgamma) dgamma[n] = (float)s1;
         }
         const float gi = ((gamma && col) ? gamma[n] : 1.f) * is;
         dh = ok ? dcnn::bn_bwd_dh(dy, h, sc, sh, mu, is, slope, gi, (float)(s0 / (double)M), (float)(s1 / (double)M), mode == 1) : 0.f;
     }
-    if (ok) dH[(long)m * lddh + n] = dh;
+    if (ok && ks == 0) dH[(long)m * lddh + n] = dh;
     if (!dW) return;
     // dW[n, :] = sum_m dh[m, n] X[m, :]: dh of every row of the wavefront's columns, broadcast from its lane
     float dhr[64];
@@ -218,13 +240,16 @@ __global__ __launch_bounds__(TPB) void rowblock_bwd_kernel(const float* __restri
     for (int j = 0; j < 64; ++j) dhr[j] = __shfl(dh, j, 64);
     constexpr int SI = RM * 64 / TPB;
     float4 stg[SI];
-    x_load<SI>(stg, X, ldx, M, K, 0);
-    for (int kc = 0; kc < K; kc += KC) {
+    x_load<SI>(stg, X, ldx, M, K, ks * KC, tid);
+    const int rounds = (K + KC * KS - 1) / (KC * KS);
+    for (int r = 0; r < rounds; ++r) {
+        const int kc = (r * KS + ks) * KC;
         __syncthreads();
-        x_store<SI>(xs, stg);
+        x_store<SI>(xs, stg, tid);
         __syncthreads();
-        if (kc + KC < K) x_load<SI>(stg, X, ldx, M, K, kc + KC);
+        if (r + 1 < rounds) x_load<SI>(stg, X, ldx, M, K, kc + KC * KS, tid);
         const int k = kc + lane * 4;
+        if (k >= K) continue;
         float4 acc[CW];
 #pragma unroll
         for (int cc = 0; cc < CW; ++cc) acc[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -241,10 +266,9 @@ __global__ __launch_bounds__(TPB) void rowblock_bwd_kernel(const float* __restri
                     acc[cc].w = fmaf(d, x4.w, acc[cc].w);
                 }
             }
-        if (k < K)
 #pragma unroll
-            for (int cc = 0; cc < CW; ++cc)
-                if (n0 + cc < N) *reinterpret_cast<float4*>(dW + (long)(n0 + cc) * lddw + k) = acc[cc];
+        for (int cc = 0; cc < CW; ++cc)
+            if (n0 + cc < N) *reinterpret_cast<float4*>(dW + (long)(n0 + cc) * lddw + k) = acc[cc];
     }
 }
 
@@ -269,12 +293,18 @@ DC_EXPORT int dc_rowblock_forward(const float* X, int64_t ldx, const float* W, i
                "dc_rowblock_forward: bad mode / missing BatchNorm arguments");
     DC_REQUIRE(mode != 1 || M > 1, "dc_rowblock_forward: batch statistics need more than one row");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = (size_t)(M <= 32 ? 32 : 64) * 64 * 16;
+    const size_t lds = 128 * 1024;              // KS staging areas: 4 x [32][64] or 2 x [64][64] float4
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
     if (M <= 32)
-        hipLaunchKernelGGL((rowblock_fwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB), lds, s, X, (long)ldx, W, (long)ldw, bias, M, N, K,
+        hipLaunchKernelGGL((rowblock_fwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB * 4), lds, s, X, (long)ldx, W, (long)ldw, bias, M, N, K,
                            gamma, beta, eps, momentum, running_mean, running_var, mode, slope, H, (long)ldh, coef, Y, (long)ldy);
     else
-        hipLaunchKernelGGL((rowblock_fwd_kernel<1>), dim3(dc_cdiv(N, 4)), dim3(TPB), lds, s, X, (long)ldx, W, (long)ldw, bias, M, N, K,
+        hipLaunchKernelGGL((rowblock_fwd_kernel<1>), dim3(dc_cdiv(N, 4)), dim3(TPB * 2), lds, s, X, (long)ldx, W, (long)ldw, bias, M, N, K,
                            gamma, beta, eps, momentum, running_mean, running_var, mode, slope, H, (long)ldh, coef, Y, (long)ldy);
     DC_CHECK_LAUNCH("dc_rowblock_forward");
     return DC_OK;
@@ -293,12 +323,18 @@ DC_EXPORT int dc_rowblock_backward(const float* dY, int64_t lddy, const float* H
     DC_REQUIRE(!dW || (ldx % 4 == 0 && lddw % 4 == 0 && aligned16(X) && aligned16(dW)), "dc_rowblock_backward: rows must be 16-byte aligned");
     DC_REQUIRE(mode >= 0 && mode <= 2, "dc_rowblock_backward: bad mode");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t lds = (size_t)(M <= 32 ? 32 : 64) * 64 * 16;
+    const size_t lds = 128 * 1024;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
     if (M <= 32)
-        hipLaunchKernelGGL((rowblock_bwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB), lds, s, dY, (long)lddy, H, (long)ldh, coef, gamma,
+        hipLaunchKernelGGL((rowblock_bwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB * 2), lds, s, dY, (long)lddy, H, (long)ldh, coef, gamma,
                            slope, mode, X, (long)ldx, M, N, K, dW, (long)lddw, dbias, dgamma, dbeta, dH, (long)lddh);
     else
-        hipLaunchKernelGGL((rowblock_bwd_kernel<1>), dim3(dc_cdiv(N, 4)), dim3(TPB), lds, s, dY, (long)lddy, H, (long)ldh, coef, gamma,
+        hipLaunchKernelGGL((rowblock_bwd_kernel<1>), dim3(dc_cdiv(N, 4)), dim3(TPB * 2), lds, s, dY, (long)lddy, H, (long)ldh, coef, gamma,
                            slope, mode, X, (long)ldx, M, N, K, dW, (long)lddw, dbias, dgamma, dbeta, dH, (long)lddh);
     DC_CHECK_LAUNCH("dc_rowblock_backward");
     return DC_OK;
