@@ -68,6 +68,10 @@ class _Lib:
                 fn = getattr(cdll, name)  # AttributeError = header/library mismatch: fail loudly
                 fn.restype, fn.argtypes = restype, argtypes
             self._cdll = cdll
+            # DC_GEMM_EXACT=1: dense products through the exact fp32 MFMA chain instead of the bf16 split products
+            # (option 3 of dc_set_option; A/B runs and bitwise comparisons against an fmaf chain)
+            if os.environ.get("DC_GEMM_EXACT", "0") not in ("", "0"):
+                cdll.dc_set_option(3, 1)
         return self._cdll
 
     def last_error(self):

@@ -46,6 +46,12 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DC_X3_PLAIN
+#define DC_X3_PLAIN 2          // split-product loop of the plain products: 1 = simple, 2 = pipelined (two plane sets)
+#endif
+#ifndef DC_X3_PRO
+#define DC_X3_PRO 1            // ... of the BatchNorm-backward prologue variants (no registers for a second plane set)
+#endif
 constexpr int BK = 32;         // reduction tile
 constexpr int LDK = BK + 4;    // row stride (floats) of a k-contiguous operand tile in LDS
 constexpr int NT = 256;        // threads per workgroup (4 waves, 2 x 2)
@@ -67,6 +73,7 @@ struct GemmP {
     const float* pc; int pcn;              // packed per-column coefficients [5][pcn]: c_sc, c_sh, c_g, c_a, c_b
     float slope;
     double* part; int chunks, stat_cols;   // statistics partials [2][stat_cols][chunks]
+    int stagger, resident;                 // first-round phase shift (shader cycles) of every second workgroup of a CU
 };
 
 // Fast-path load: buffer_load through a descriptor built from the wave-uniform tile origin (SGPRs), a wave-uniform
@@ -123,7 +130,41 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0>
+// ---- split products (X3): an fp32 value x is cut into three bfloat16 planes, x = hi + mid + lo up to 2^-25 |x|
+// (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid); both differences are exact in fp32), and the product
+// of two fp32 operands is accumulated from the six partial products of weight >= 2^-16 (lo.hi, hi.lo, mid.mid, mid.hi,
+// hi.mid, hi.hi) on the bf16 matrix pipe with fp32 accumulation: v_mfma_f32_32x32x16_bf16 retires 16x the
+// multiply-adds per cycle of v_mfma_f32_32x32x2_f32, so six of them cost 6/16 of the exact chain.  The dropped terms
+// (mid.lo, lo.mid, lo.lo) are below 2^-23 of |a||b|, and each instruction sums 16 products before the one rounding
+// into the accumulator: measured error against fp64 is BELOW the fp32 chain's (profiles/r03o_bf16x3_lab.txt).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Planes { u32x4 h, m, l; };       // 8 bfloat16 each: element j of the MFMA operand = k index 8 (lane >> 5) + j
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32 (round to nearest even)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
+}
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xFFFF0000u);
+    m = pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, m << 16), s1 = r1 - __builtin_bit_cast(float, m & 0xFFFF0000u);
+    l = pk_bf16(s0, s1);
+}
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, Planes& o) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned h, m, l;
+        split_pair(x[2 * j], x[2 * j + 1], h, m, l);
+        o.h[j] = h; o.m[j] = m; o.l[j] = l;
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0, int X3 = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     constexpr bool FAST = MODE == 0;               // no guards anywhere (loads, statistics, stores)
     // guarded modes per operand: 1 = 16-byte loads, 2 = dword loads.  MODE 1: both vector, 2: both scalar, 3: A vector /
@@ -140,6 +181,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
+    // Phase shift.  The two workgroups of a CU start together and stay in lockstep: both in the K loop (sharing the
+    // matrix pipe, each at half speed -- one wave per SIMD already saturates it), then both in the epilogue / the next
+    // tile's first loads (pipe idle).  Holding back the workgroup in the ODD wave slot (HW_ID.WAVE_ID: the second
+    // workgroup placed on the CU) by about half a K loop in the first round puts one workgroup's epilogue under the
+    // other's K loop for the rest of the launch.
+    if (p.stagger > 0 && (long)blockIdx.y * gridDim.x + blockIdx.x < p.resident) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_REG_HW_ID bits [3:0]
+        if (slot & 1) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const long blk = dc_xcd_block(p.remap);
     const long kbeg = (long)blockIdx.y * p.k_per_slab;
     const long kend = min(p.K, kbeg + p.k_per_slab);
@@ -162,7 +215,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     // s_waitcnt (r02o counters: with one set the waves sat in waitcnt/barrier 12 % of their cycles, the library 4 %).
     // One set where a second does not fit the 256-register budget (2 workgroups per CU) without spilling: the
     // prologue variants (h tile + coefficients) and the 128 x 128 tile with a reduction-major B operand.
-    constexpr int STG = (PRO || (BM == 128 && BN == 128 && BL == B_KN)) ? 1 : 2;
+    constexpr int STG = (X3 || PRO || (BM == 128 && BN == 128 && BL == B_KN)) ? 1 : 2;
     f32x4 sa[STG][A_IT], sb[STG][B_IT];
     f32x4 sa2[PRO ? A_IT : 1], cf[5];          // prologue: h tile, per-column coefficients of this thread's 4 columns
     if (PRO && AL == A_KM) {                    // reduction-major A: the thread's columns never change
@@ -272,6 +325,194 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, STG - 1>;
+    if constexpr (X3 != 0) {
+        // Split-product loop.  A K tile = two k-steps of 16; per k-step a lane reads 8 consecutive k of its row / column
+        // per fragment as fp32 (the SAME LDS tiles and traffic as the exact loop), cuts them into planes in registers and
+        // issues 6 MFMAs per accumulator.  One staging set; the two workgroups of a CU run in antiphase (one wave of a SIMD
+        // splits on the VALU while the other feeds the matrix pipe).
+        f32x4 qa[TM][2], qb[TN][2];
+        Planes pa[TM], pb[TN];
+        auto read_raw = [&](int buf, int ks) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (AL == A_MK) {
+                    const float* a = As + buf * A_FL + (wm0 + 32 * i + li) * LDK + 16 * ks + 8 * lh;
+                    qa[i][0] = *reinterpret_cast<const f32x4*>(a);
+                    qa[i][1] = *reinterpret_cast<const f32x4*>(a + 4);
+                } else {
+                    const float* a = As + buf * A_FL + (16 * ks + 8 * lh) * BM + wm0 + 32 * i + li;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { qa[i][0][t] = a[t * BM]; qa[i][1][t] = a[(4 + t) * BM]; }
+                }
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                if (BL == B_NK) {
+                    const float* b = Bs + buf * B_FL + (wn0 + 32 * jn + li) * LDK + 16 * ks + 8 * lh;
+                    qb[jn][0] = *reinterpret_cast<const f32x4*>(b);
+                    qb[jn][1] = *reinterpret_cast<const f32x4*>(b + 4);
+                } else {
+                    const float* b = Bs + buf * B_FL + (16 * ks + 8 * lh) * BN + wn0 + 32 * jn + li;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { qb[jn][0][t] = b[t * BN]; qb[jn][1][t] = b[(4 + t) * BN]; }
+                }
+            }
+        };
+        auto split_all = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) split8(qa[i][0], qa[i][1], pa[i]);
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) split8(qb[jn][0], qb[jn][1], pb[jn]);
+        };
+        // smallest partial products first; consecutive MFMAs go to different accumulators
+        auto mfma_all = [&]() {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_bf16(pa[i].l, pb[jn].h, acc[i][jn]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_bf16(pa[i].h, pb[jn].l, acc[i][jn]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_bf16(pa[i].m, pb[jn].m, acc[i][jn]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_bf16(pa[i].m, pb[jn].h, acc[i][jn]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_bf16(pa[i].h, pb[jn].m, acc[i][jn]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma_bf16(pa[i].h, pb[jn].h, acc[i][jn]);
+        };
+        if constexpr (X3 == 2) {
+            // Pipelined form: two plane sets.  A k-step multiplies one set while the next k-step's fragments (read from
+            // LDS a step earlier) are cut into the other, fragment by fragment -- 6 MFMAs, then the 36 VALU instructions
+            // of one fragment, then the LDS reads that refill its fp32 registers for the step after -- so the split runs
+            // in the shadow of the matrix pipe inside ONE wave.  The LDS ring is two tiles deep: tile kt+2 is stored into
+            // the buffer of tile kt during tile kt (all of that buffer was read before the previous barrier).
+            Planes pa1[TM], pb1[TN];
+            constexpr int NF = TM + TN, NM = 6 * TM * TN, VPM = 36 * NF / NM;
+            auto read_frag = [&](int f, int buf, int ks) {
+                if (f < TM) {
+                    const int i = f;
+                    if (AL == A_MK) {
+                        const float* a = As + buf * A_FL + (wm0 + 32 * i + li) * LDK + 16 * ks + 8 * lh;
+                        qa[i][0] = *reinterpret_cast<const f32x4*>(a);
+                        qa[i][1] = *reinterpret_cast<const f32x4*>(a + 4);
+                    } else {
+                        const float* a = As + buf * A_FL + (16 * ks + 8 * lh) * BM + wm0 + 32 * i + li;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { qa[i][0][t] = a[t * BM]; qa[i][1][t] = a[(4 + t) * BM]; }
+                    }
+                } else {
+                    const int jn = f - TM;
+                    if (BL == B_NK) {
+                        const float* b = Bs + buf * B_FL + (wn0 + 32 * jn + li) * LDK + 16 * ks + 8 * lh;
+                        qb[jn][0] = *reinterpret_cast<const f32x4*>(b);
+                        qb[jn][1] = *reinterpret_cast<const f32x4*>(b + 4);
+                    } else {
+                        const float* b = Bs + buf * B_FL + (16 * ks + 8 * lh) * BN + wn0 + 32 * jn + li;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) { qb[jn][0][t] = b[t * BN]; qb[jn][1][t] = b[(4 + t) * BN]; }
+                    }
+                }
+            };
+            // one k-step: multiply the planes (ca, cb); cut the fragments in flight into (na, nb); refill them from
+            // (rbuf, rks) -- unconditionally: past the last tile they read stale LDS and nothing consumes the result
+            auto step = [&](const Planes (&ca)[TM], const Planes (&cb)[TN], Planes (&na)[TM], Planes (&nb)[TN], int rbuf, int rks) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int g = f * NM / NF; g < (f + 1) * NM / NF; ++g) {
+                        const int pr = g / (TM * TN), r = g % (TM * TN), i = r / TN, jn = r % TN;
+                        // smallest partial products first: l.h  h.l  m.m  m.h  h.m  h.h
+                        const u32x4 a = pr == 0 ? ca[i].l : (pr == 2 || pr == 3 ? ca[i].m : ca[i].h);
+                        const u32x4 b = pr == 1 ? cb[jn].l : (pr == 2 || pr == 4 ? cb[jn].m : cb[jn].h);
+                        acc[i][jn] = mfma_bf16(a, b, acc[i][jn]);
+                    }
+                    if (f < TM) split8(qa[f][0], qa[f][1], na[f]);
+                    else split8(qb[f - TM][0], qb[f - TM][1], nb[f - TM]);
+                    read_frag(f, rbuf, rks);
+                }
+#pragma unroll
+                for (int g = 0; g < NM; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);     // its share of the split
+                }
+            };
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) load_piece(n, kbeg, S0{});
+#pragma unroll
+            for (int n = 0; n < NST; ++n) store_piece(n, 0, S0{});
+            if (nk > 1) {
+#pragma unroll
+                for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + BK, S0{});
+#pragma unroll
+                for (int n = 0; n < NST; ++n) store_piece(n, 1, S0{});
+            }
+            if (nk > 2) {
+#pragma unroll
+                for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + 2 * BK, S0{});
+            }
+            lds_barrier();
+            read_raw(0, 0);
+            split_all();
+            read_raw(0, 1);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                step(pa, pb, pa1, pb1, cur ^ 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                step(pa1, pb1, pa, pb, cur ^ 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + 2 < nk) {
+#pragma unroll
+                    for (int n = 0; n < NST; ++n) store_piece(n, cur, S0{});
+                }
+                if (kt + 3 < nk) {
+#pragma unroll
+                    for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + (long)(kt + 3) * BK, S0{});
+                }
+                lds_barrier();
+            }
+        } else {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) load_piece(n, kbeg, S0{});
+#pragma unroll
+        for (int n = 0; n < NST; ++n) store_piece(n, 0, S0{});
+        if (nk > 1) {
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + BK, S0{});
+        }
+        lds_barrier();
+        read_raw(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            split_all();
+            read_raw(cur, 1);
+            mfma_all();
+            split_all();
+            if (kt + 1 < nk) {             // tile kt+1 (requested a whole tile ago) -> the other buffer
+#pragma unroll
+                for (int n = 0; n < NST; ++n) store_piece(n, cur ^ 1, S0{});
+            }
+            if (kt + 2 < nk) {
+#pragma unroll
+                for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + (long)(kt + 2) * BK, S0{});
+            }
+            lds_barrier();                 // buffer `cur` is consumed (its fragments are in registers), cur ^ 1 is written
+            if (kt + 1 < nk) read_raw(cur ^ 1, 0);
+            mfma_all();
+        }
+        }   // simple / pipelined split loop
+    } else {
 #pragma unroll
     for (int n = 0; n < NLD; ++n) load_piece(n, kbeg, S0{});
 #pragma unroll
@@ -382,6 +623,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
             tile_body(nk - 1, P0{}, F{}, F{});
         }
     }
+    }   // exact / split loop
     __syncthreads();                  // (the staging below reuses the operand buffers)
 
     // ---- statistics epilogue (rows beyond M hold zeros and add nothing)
@@ -514,30 +756,37 @@ size_t lds_bytes(int bm, int bn, int al, int bl) {
     return std::max(2 * (a + b), (size_t)bm * bn) * sizeof(float);      // operand ring | output staging
 }
 
-template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO>
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO, int X3>
 void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
     static bool configured = false;
     const size_t lds = lds_bytes(BM, BN, AL, BL);
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
                        dim3(NT), lds, s, p);
 }
 
-template <int AL, int BL, int MODE, int EPI, int PRO>
+template <int AL, int BL, int MODE, int EPI, int PRO, int X3 = 0>
 void launch_tile(const GemmP& p, Tile t, long tiles_m, int slabs, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
-    else if (t.bm == 128) launch_one<128, 64, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
-    else if (t.bn == 128) launch_one<64, 128, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
-    else launch_one<64, 64, AL, BL, MODE, EPI, PRO>(p, tiles_m, slabs, s);
+    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
+    else if (t.bm == 128) launch_one<128, 64, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
+    else if (t.bn == 128) launch_one<64, 128, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
+    else launch_one<64, 64, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
 }
 
+// The unguarded path (whole tiles: every hot shape of the reference models) multiplies through the split products where
+// they win (r03 A/B, profiles/r03_x3_ab.txt): output tiles 128 columns wide (forward / input gradient; a 64-wide tile
+// splits 12 VALU instructions per MFMA against 6) and 128 x 128 tiles of the weight gradient, whose reduction-major
+// fragments cost 8 ds_read_b32 each.  Option DC_OPT_GEMM_EXACT = 1 forces the exact fp32 chain everywhere; ragged
+// shapes always run it.
 template <int AL, int BL, int EPI, int PRO = 0>
 void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, int mode, hipStream_t s) {
-    if (mode == 0) launch_tile<AL, BL, 0, EPI, PRO>(p, t, tiles_m, slabs, s);
+    const bool split = mode == 0 && dc_option(DC_OPT_GEMM_EXACT) == 0 && t.bn == 128 && (AL == A_MK || t.bm == 128);
+    if (split) launch_tile<AL, BL, 0, EPI, PRO, (PRO ? DC_X3_PRO : DC_X3_PLAIN)>(p, t, tiles_m, slabs, s);
+    else if (mode == 0) launch_tile<AL, BL, 0, EPI, PRO>(p, t, tiles_m, slabs, s);
     else if (mode == 1) launch_tile<AL, BL, 1, EPI, PRO>(p, t, tiles_m, slabs, s);
     else if (mode == 2) launch_tile<AL, BL, 2, EPI, PRO>(p, t, tiles_m, slabs, s);
     else if (mode == 3) launch_tile<AL, BL, 3, EPI, PRO>(p, t, tiles_m, slabs, s);
@@ -550,6 +799,19 @@ void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, int mode, hipS
 int load_mode(bool whole_tiles, bool a4, bool b4) {
     if (whole_tiles && a4 && b4) return 0;
     return a4 && b4 ? 1 : (a4 ? 3 : (b4 ? 4 : 2));
+}
+
+// first-round phase shift (see the kernel): only where two 128 x 128 workgroups share a CU and the launch has a second
+// round to profit from it.  Option DC_OPT_GEMM_STAGGER = percent of the estimated K-loop time of one workgroup running
+// alone (0: the default, 50; negative: off).  r03 sweep (profiles/r03_x3_stagger.txt): 25 .. 100 are equivalent.
+void set_stagger(GemmP& p, Tile t, long workgroups, long k_per_wg) {
+    p.stagger = 0;
+    p.resident = 512;
+    int pct = dc_option(DC_OPT_GEMM_STAGGER);          // 0: default (50), < 0: off
+    if (pct == 0) pct = 50;
+    if (pct < 0 || t.bm != 128 || t.bn != 128 || workgroups < 2 * p.resident) return;
+    const long per_tile = dc_option(DC_OPT_GEMM_EXACT) ? 4200 : 1250;       // shader cycles per K tile, alone on the CU
+    p.stagger = (int)std::min<long>((k_per_wg + BK - 1) / BK * per_tile * pct / 100, 400000);
 }
 
 bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -571,6 +833,7 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.k_per_slab = K; p.slab_stride = 0;
     p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
     p.A2 = nullptr; p.lda2 = 0; p.pc = nullptr; p.pcn = 0; p.slope = 0.f;
+    set_stagger(p, t, tiles_m * p.tiles_n, (long)K);
     if (lda >= (1 << 21) || ldb >= (1 << 21) || (pro && pro->ldh >= (1 << 21))) {     // 32-bit in-tile byte offsets
         dc_set_error("%s: leading dimension above 2^21 elements", name);
         return DC_ERR_ARG;
@@ -647,6 +910,7 @@ int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R,
     p.k_per_slab = pl.rows_per_slab; p.slab_stride = (long)M * N;
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
     p.A2 = h; p.lda2 = ldh; p.pc = coefs; p.pcn = M; p.slope = slope;
+    set_stagger(p, t, tiles_m * p.tiles_n * pl.slabs, pl.rows_per_slab);
     if (lda >= (1 << 21) || ldb >= (1 << 21) || ldh >= (1 << 21)) return -1;      // 32-bit in-tile byte offsets
     const bool whole = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && N % 4 == 0 &&
                        al16p(partial);

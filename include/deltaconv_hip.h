@@ -36,7 +36,10 @@ int32_t dc_version(void);
 const char* dc_last_error(void);
 /* Experiment switches for A/B measurements (product defaults: all 0 except key 0).  key 0: XCD-aware block remap
  * (default 1); 1: edge-at-a-time max-aggregation backward; 2: value 2 = weight gradients through the round-1
- * direct-load kernel; 5 / 6: force the weight-gradient tile (1..4) / slab count (lab sweeps). */
+ * direct-load kernel; 3: value 1 = dense products through the exact fp32 MFMA chain (bitwise an fmaf chain) instead of
+ * the bf16 split products (three bf16 planes per fp32 operand, six partial products, fp32 accumulation: error against
+ * fp64 no larger than the chain's); 4: first-round phase shift of every second 128 x 128 GEMM workgroup of a CU in
+ * percent of a K loop (0 = default 50, negative = off); 5 / 6: force the weight-gradient tile (1..4) / slab count. */
 int dc_set_option(int32_t key, int32_t value);
 
 /* ---- graph ------------------------------------------------------------------------------- */

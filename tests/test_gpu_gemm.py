@@ -187,3 +187,50 @@ def test_bn_block_backward_fused_matches_unfused(R, C, K, training, accumulate):
     fused.FUSE_BN_BWD = True
     for a, b in zip(*res):
         assert rel_err(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 1024, 448), (16384, 256, 512), (8192, 128, 128), (4096, 256, 64)])
+@pytest.mark.parametrize("binades", [0.0, 3.0])
+def test_split_products_no_worse_than_exact_chain(M, N, K, binades):
+    """The default dense products (three bf16 planes per fp32 operand, six partial products on the bf16 matrix pipe, fp32
+    accumulation) against the exact fp32 MFMA chain (option 3 = 1) and an fp64 product, for the three products of a Linear
+    layer (forward, input gradient, weight gradient): the split error is no larger than 1.5 x the chain's + 1e-7, on
+    uniform operands and on operands spread over many binades with exact zeros (post-ReLU-like).  Also: the two paths
+    differ (the option really switches kernels) and each is bit-reproducible."""
+    g = torch.Generator().manual_seed(K + int(binades))
+    x = torch.randn(M, K, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    if binades:
+        x = x * torch.exp(binades * torch.randn(M, K, generator=g))
+        x[x.abs() < 0.5] = 0
+        dy = dy * torch.exp(0.5 * binades * torch.randn(M, N, generator=g))
+    x, dy = x.to(DEV), dy.to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    sub = slice(0, 2048)
+    refs = {"fwd": x[sub].double() @ w.double().t(), "dx": dy[sub].double() @ w.double(), "dw": dy.double().t() @ x.double()}
+    nb = lib.raw("dc_gemm_tn_workspace_bytes")(M, N, K)
+    ws = torch.empty((nb + 3) // 4, device=DEV)
+
+    def products():
+        y, dx, dw = torch.empty(M, N, device=DEV), torch.empty(M, K, device=DEV), torch.empty(N, K, device=DEV)
+        lib.call("dc_linear_forward", x, K, w, K, M, N, K, y, N, 0)
+        lib.call("dc_linear_backward_input", dy, N, w, K, M, N, K, dx, K, 0, 0)
+        lib.call("dc_gemm_tn", dy, N, x, K, M, N, K, dw, K, 0, ws, ws.numel() * 4)
+        return {"fwd": y, "dx": dx, "dw": dw}
+
+    opt = lib.raw("dc_set_option")
+    try:
+        opt(3, 1)
+        exact = products()
+        opt(3, 0)
+        split = products()
+        again = products()
+    finally:
+        opt(3, 0)
+    for name, ref in refs.items():
+        view = (lambda t: t[sub]) if name != "dw" else (lambda t: t)
+        e_exact, e_split = rel_err(view(exact[name]), ref), rel_err(view(split[name]), ref)
+        assert e_split < 1.5 * e_exact + 1e-7, (name, e_split, e_exact)
+        assert e_split < _tol(K if name != "dw" else M), name
+        assert torch.equal(split[name], again[name]), name
+    assert not torch.equal(split["fwd"], exact["fwd"])            # 128-column tiles: the split path ran

@@ -116,10 +116,14 @@ def test_model_step_golden(name):
     names, norms, dots = param_summaries(model)
     assert names == [str(s) for s in g["gnames"]]
     gn = g["gnorm_f64"].numpy()
-    assert np.max(np.abs(np.array(norms) - gn) / (gn + 1e-3 * gn.max())) < 5 * tol
+    den = gn + 1e-3 * gn.max()
+    # fp64 = truth; the bound is self-calibrated like the element-wise one below: the reference's OWN fp32 run sits up to
+    # 2.6e-3 from its fp64 run on these summaries (k = 30 fixture: max-aggregation argmax choices flip with any rounding)
+    ref_gap = lambda key: float(np.max(np.abs(g[key + "_f32"].numpy() - g[key + "_f64"].numpy()) / den)) if key + "_f32" in g else 0.0
+    assert np.max(np.abs(np.array(norms) - gn) / den) < 5 * tol + ref_gap("gnorm")
     # signed probe dot products (a sign / permutation error in a weight gradient changes these, not the norms)
     gd = g["gdot_f64"].numpy()
-    assert np.max(np.abs(np.array(dots) - gd) / (gn + 1e-3 * gn.max())) < 5 * tol
+    assert np.max(np.abs(np.array(dots) - gd) / den) < 5 * tol + ref_gap("gdot")
     # and two weight gradients element by element (first edge MLP, first vector MLP)
     params = dict(model.named_parameters())
     # (fp64 = truth.  The reference's own fp32 run is only as close to truth as its max-aggregation argmax
