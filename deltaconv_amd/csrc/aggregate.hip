@@ -208,15 +208,15 @@ DC_EXPORT int dc_knn_sum_backward(const int32_t* tptr, const int32_t* tedge, int
 }
 
 // ---- max aggregation from a tile plan (tile_plan.h, ell_tile.h): same values and slots, rows from LDS ---------------
-DC_EXPORT int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k, int32_t P,
+DC_EXPORT int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles, int32_t k, int32_t P,
                                const float* h, int32_t C, int64_t ldh, float* out, int64_t ldo, uint8_t* arg, void* stream) {
     DC_REQUIRE(plan && nbr && h && out && arg, "dc_knn_max_tiled: null pointer");
-    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
+    DC_REQUIRE(n >= 0 && num_tiles >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
                "dc_knn_max_tiled: bad size");
     DC_REQUIRE(dctile::eligible(C, {(long)ldh, (long)ldo}, {h, out, arg}), "dc_knn_max_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
     DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_max_tiled: leading dimension smaller than the row");
     if (n == 0) return DC_OK;
-    const DcTilePlan L = dc_tile_plan_layout(n, num_clouds, k, P);
+    const DcTilePlan L = dc_tile_plan_layout(num_tiles, k, P);
     dctile::launch<1>(L, plan, nullptr, nbr, C,
                       dctile::KnnMaxB<false>{h, (long)ldh, 0, nullptr, nullptr, 0.f, out, (long)ldo, arg, (long)C},
                       static_cast<hipStream_t>(stream));
@@ -224,16 +224,16 @@ DC_EXPORT int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t 
     return DC_OK;
 }
 
-DC_EXPORT int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k,
+DC_EXPORT int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles, int32_t k,
                                       int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale,
                                       const float* shift, float slope, float* out, int64_t ldo, uint8_t* arg, void* stream) {
     DC_REQUIRE(plan && nbr && h && scale && shift && out && arg, "dc_knn_max_affine_tiled: null pointer");
-    DC_REQUIRE(n >= 0 && num_clouds >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
+    DC_REQUIRE(n >= 0 && num_tiles >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
                "dc_knn_max_affine_tiled: bad size");
     DC_REQUIRE(dctile::eligible(C, {(long)ldh, (long)ldo}, {h, out, arg}), "dc_knn_max_affine_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
     DC_REQUIRE(ldh >= C && ldo >= C, "dc_knn_max_affine_tiled: leading dimension smaller than the row");
     if (n == 0) return DC_OK;
-    const DcTilePlan L = dc_tile_plan_layout(n, num_clouds, k, P);
+    const DcTilePlan L = dc_tile_plan_layout(num_tiles, k, P);
     dctile::launch<1>(L, plan, nullptr, nbr, C,
                       dctile::KnnMaxB<true>{h, (long)ldh, 0, scale, shift, slope, out, (long)ldo, arg, (long)C},
                       static_cast<hipStream_t>(stream));

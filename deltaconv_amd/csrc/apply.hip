@@ -149,7 +149,7 @@ int check_tiled(const char* name, const void* a, const void* b, const void* c, c
         return DC_ERR_ARG;
     }
     if (n < 0 || nc < 0 || k < 2 || k % 2 || k > 64 || (P != 32 && P != 64) || P * k > 2048) {
-        dc_set_error("%s: bad size n=%d num_clouds=%d k=%d P=%d", name, n, nc, k, P);
+        dc_set_error("%s: bad size n=%d num_tiles=%d k=%d P=%d", name, n, nc, k, P);
         return DC_ERR_ARG;
     }
     if (!ok16) {
@@ -161,15 +161,15 @@ int check_tiled(const char* name, const void* a, const void* b, const void* c, c
 }  // namespace
 
 #define DC_TILED_ENTRY(FN, BODY, R, LDJ, HS, MINLDI, MINLDO, ...)                                                     \
-    DC_EXPORT int FN(const float* coef, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,     \
+    DC_EXPORT int FN(const float* coef, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles,     \
                      int32_t k, int32_t P, const float* in, int32_t C, int64_t ldi, float* out, int64_t ldo,          \
                      void* stream) {                                                                                 \
-        if (int rc = check_tiled(#FN, coef, plan, nbr, in, out, n, num_clouds, k, P, C,                              \
+        if (int rc = check_tiled(#FN, coef, plan, nbr, in, out, n, num_tiles, k, P, C,                              \
                                  dctile::eligible(C, {(long)ldi, (long)ldo}, {in, out, coef})))                      \
             return rc;                                                                                               \
         DC_REQUIRE(ldi >= (MINLDI) && ldo >= (MINLDO), #FN ": leading dimension smaller than the row");              \
         if (n == 0) return DC_OK;                                                                                    \
-        const DcTilePlan L = dc_tile_plan_layout(n, num_clouds, k, P);                                               \
+        const DcTilePlan L = dc_tile_plan_layout(num_tiles, k, P);                                               \
         dctile::launch<R>(L, plan, coef, nbr, C, dctile::BODY{in, (long)(LDJ), (long)(HS), out, (long)ldo __VA_ARGS__}, \
                           static_cast<hipStream_t>(stream));                                                         \
         DC_CHECK_LAUNCH(#FN);                                                                                        \

@@ -18,6 +18,7 @@
 //     neighbour id -- correct for any graph, fast for the spatially coherent ones a kNN graph gives.
 // Same FMAs in the same slot order as the staged kernels (ell_math.h): results are bit-identical (tests/test_gpu_tile.py).
 #pragma once
+#include <algorithm>
 #include <initializer_list>
 #include "common.h"
 #include "ell_math.h"
@@ -53,12 +54,15 @@ inline size_t lds_bytes(int k, bool coef) {
 }
 
 // BODY: per-thread accumulator object, copied from the kernel argument
-//   static constexpr bool COEF, SELF;
+//   static constexpr bool COEF, SELF;  static constexpr int NST (store instructions finish() issues per wave);
 //   const float* in; long ldj, hs;             piece h of row j = in + j * ldj + h * hs
 //   void init(int c);  void step(int s, G2 g, const Vec<4>& p0, const Vec<4>& p1);
 //   void finish(long i, int c, const Vec<4>& s0, const Vec<4>& s1);
+// One unit (tile, 64-channel slab) per workgroup: the form of the one-piece-per-row kernels (grad, max aggregation), whose
+// 64 KB of rows let TWO workgroups share a CU -- as long as a wave stays within 64 registers, which the loop-carried state
+// of the persistent form below (next ids, pending accumulators) does not (r03: 48 -> 94 registers, grad 8.0 -> 9.4 us).
 template <int R, int P, class BODY>
-__global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const int* __restrict__ plan,
+__global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const int* __restrict__ plan,
                                                           const float* __restrict__ coef, const int* __restrict__ nbr,
                                                           int slabs, int remap, BODY body) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -174,10 +178,174 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
     body.finish(i, c, s0, s1);
 }
 
+// Persistent, software-pipelined form: the two-piece kernels (div, [div|curl|norm], hodge: 127 KB of rows, one workgroup
+// per CU whatever the registers).
+template <int R, int P, class BODY>
+__global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const int* __restrict__ plan,
+                                                          const float* __restrict__ coef, const int* __restrict__ nbr,
+                                                          int slabs, int remap, int upw, const BODY body0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using GM = Geom<R, P>;
+    constexpr int NW = GM::NW, CAPR = GM::CAPR, RIT = GM::RIT;
+    // Work unit = (tile, 64-channel slab); a workgroup owns `upw` CONSECUTIVE units (the slabs of a tile, then the next
+    // tile of the same cloud: one set of row ids serves all slabs of its tile, and the ids of the next tile are requested
+    // behind the DMA pieces of the current one, so their round trip -- a quarter of a workgroup's life when every unit
+    // was its own workgroup (r03d phase stamps) -- is paid once per workgroup instead of once per tile).
+    const long units = (long)L.T * slabs;
+    const long u0 = dc_xcd_block(remap) * upw, u1 = min(u0 + (long)upw, units);
+    if (u0 >= u1) return;
+    const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
+    const int wave = tid >> 6, lane64 = tid & 63;
+    const int k = L.k, PK = L.PK;
+    const int cpp = k >> 1, ppi = 64 / cpp;                               // 16-byte pieces per point, points per DMA piece
+    const size_t cfb_bytes = BODY::COEF ? (size_t)((P + ppi - 1) / ppi) * 1024 : 0;
+    float* rows = reinterpret_cast<float*>(smem);                         // [CAPR][64]
+    char* cfb = smem + (size_t)CAPR * 256;                                // [PK] G2
+    char* lcb = cfb + cfb_bytes;                                          // [PK] u16
+    int* pts = reinterpret_cast<int*>(lcb + (PK * 2 + 1023) / 1024 * 1024);   // [P]
+    unsigned short* sl = reinterpret_cast<unsigned short*>(pts + P);     // [P]
+    // coefficient pieces of this lane: piece c = wave (+ NW) holds points c * ppi .. of the tile, this lane its point
+    // lane / cpp and the 16-byte chunk lane % cpp of that point's k * 8 bytes (k <= 64: at most two pieces per wave)
+    const int cpp_pt = lane64 / cpp, cpp_ch = lane64 - cpp_pt * cpp;
+
+    // everything a tile needs from the plan before its first DMA piece: one round trip
+    struct Ids { int rid[RIT]; int U, mypt, cpt[2]; unsigned short mysl; };
+    auto load_ids = [&](long tile, Ids& d) {
+        const int* uq = plan + L.o_uniq + tile * PK;
+        // row ids; the unique count is read beside them, not before them (the list's tail repeats its last id)
+#pragma unroll
+        for (int it = 0; it < RIT; ++it) {
+            const int r = min((wave + it * NW) * 4 + (lane64 >> 4), PK * R - 1);
+            d.rid[it] = uq[r / R];
+        }
+        d.U = plan[L.o_nu + tile];
+        d.mypt = -1;
+        d.mysl = 0;
+        if (tid < P) {
+            d.mypt = plan[L.o_pts + tile * P + tid];
+            d.mysl = reinterpret_cast<const unsigned short*>(plan + L.o_self)[tile * P + tid];
+        }
+        d.cpt[0] = d.cpt[1] = -1;
+        if (BODY::COEF && cpp_pt < ppi)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int p = (wave + u * NW) * ppi + cpp_pt;
+                if (p < P) d.cpt[u] = plan[L.o_pts + tile * P + p];
+            }
+    };
+    Ids cur;
+    load_ids(u0 / slabs, cur);
+    // Software pipeline over the units: the output stores of unit u-1 are issued BEHIND the DMA pieces of unit u, and the
+    // wait for those pieces leaves the BODY::NST youngest vector-memory instructions (the stores) in flight -- the vmcnt
+    // counter retires in order, so a wait for pieces issued behind the stores would also wait for the stores' round trip
+    // to memory (non-temporal: the slowest instructions of the kernel).
+    BODY pbody = body0;                                                      // unit u-1: accumulators waiting to be stored
+    long pi = -1;
+    int pc = 0;
+    Vec<4> ps0 = vzero<4>(), ps1 = vzero<4>();
+    for (long u = u0; u < u1; ++u) {
+        const long tile = u / slabs;
+        const int cb = (int)(u - tile * slabs) * CS;
+        // the id waits end here, before the first DMA piece (hipcc waits vmcnt(0) at the first use of an ordinary load's
+        // result, which would serialise DMA pieces already in flight)
+#pragma unroll
+        for (int it = 0; it < RIT; ++it) asm volatile("" : "+v"(cur.rid[it]));
+        asm volatile("" : "+v"(cur.mypt), "+v"(cur.U));
+        asm volatile("" : "+v"(cur.cpt[0]), "+v"(cur.cpt[1]));
+        const int U = __builtin_amdgcn_readfirstlane(cur.U);              // block-uniform
+        const int UL = min(U, CAP), nrow = UL * R;
+        // the next unit's tile: its ids travel while this unit's rows land (requested BEFORE the pieces: older than them)
+        Ids nxt = cur;
+        if (u + 1 < u1 && (u + 1) / slabs != tile) load_ids((u + 1) / slabs, nxt);
+        asm volatile("" ::: "memory");
+        if (U != 0) {
+#pragma unroll
+            for (int it = 0; it < RIT; ++it) {
+                const int r0 = (wave + it * NW) * 4;
+                if (r0 < nrow) {
+                    const int h = R == 2 ? (lane64 >> 4) & 1 : 0;             // piece of the row this lane group loads
+                    dma16(body0.in + (long)cur.rid[it] * body0.ldj + h * body0.hs + cb + l16 * 4, rows + r0 * 64);
+                }
+            }
+            // coefficients and local indices of the tile: contiguous -> whole 1-KiB chunks (tail lanes re-read the end)
+            if (BODY::COEF)
+#pragma unroll
+                for (int w = 0; w < 2; ++w)                                   // (padding lanes / points re-read row 0: never used)
+                    if ((wave + w * NW) * ppi < P)
+                        dma16(coef + (cur.cpt[w] >= 0 ? (long)cur.cpt[w] * k * 2 + cpp_ch * 4 : 0), cfb + (wave + w * NW) * 1024);
+            const char* g = reinterpret_cast<const char*>(plan + L.o_loc) + (size_t)tile * PK * 2;
+            for (int c = wave; c * 1024 < PK * 2; c += NW) dma16(g + min(c * 1024 + lane64 * 16, PK * 2 - 16), lcb + c * 1024);
+            if (tid < P) {
+                pts[tid] = cur.mypt;
+                sl[tid] = cur.mysl;
+            }
+        }
+        // unit u-1 leaves: exactly BODY::NST store instructions per wave that has a live point, none otherwise
+        asm volatile("" ::: "memory");
+        const bool stores = __builtin_amdgcn_ballot_w64(pi >= 0) != 0;      // wave-uniform
+        if (pi >= 0) pbody.finish(pi, pc, ps0, ps1);
+        asm volatile("" ::: "memory");
+        if (stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(BODY::NST) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        pi = -1;
+        if (U != 0) {
+            const long i = pts[grp];
+            if (i >= 0) {
+                BODY body = body0;
+                const G2* cp = reinterpret_cast<const G2*>(cfb + (grp / ppi) * 1024 + (grp % ppi) * (k * 8));
+                const unsigned short* lp = reinterpret_cast<const unsigned short*>(lcb) + grp * k;
+                const int c = cb + l16 * 4;
+                body.init(c);
+                Vec<4> s0 = vzero<4>(), s1 = vzero<4>();
+                if (U <= CAP) {
+#pragma unroll 4
+                    for (int s = 0; s < k; ++s) {
+                        const int l = lp[s];
+                        const Vec<4> p0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
+                        const Vec<4> p1 = R == 2 ? *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4) : p0;
+                        body.step(s, BODY::COEF ? cp[s] : G2{0.f, 0.f}, p0, p1);
+                    }
+                    if (BODY::SELF) {
+                        const int l = sl[grp];
+                        s0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
+                        s1 = *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4);
+                    }
+                } else {                                                      // more unique rows than LDS holds: the rest by id
+#pragma unroll 1
+                    for (int s = 0; s < k; ++s) {
+                        const int l = lp[s];
+                        Vec<4> p0, p1;
+                        if (l < CAP) {
+                            p0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
+                            p1 = R == 2 ? *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4) : p0;
+                        } else {
+                            const float* g = body.in + (long)nbr[i * k + s] * body.ldj + c;
+                            p0 = dcell::vload<4>(g);
+                            p1 = R == 2 ? dcell::vload<4>(g + body.hs) : p0;
+                        }
+                        body.step(s, BODY::COEF ? cp[s] : G2{0.f, 0.f}, p0, p1);
+                    }
+                    if (BODY::SELF) {
+                        const float* g = body.in + i * body.ldj + c;
+                        s0 = dcell::vload<4>(g);
+                        s1 = dcell::vload<4>(g + body.hs);
+                    }
+                }
+                pbody = body; pi = i; pc = c; ps0 = s0; ps1 = s1;
+            }
+        }
+        // the rows are free for the next unit's pieces once every wave has read its last LDS operand (no vector-memory wait)
+        if (u + 1 < u1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        cur = nxt;
+    }
+    if (pi >= 0) pbody.finish(pi, pc, ps0, ps1);
+}
+
 // ---- bodies (the arithmetic of ell_math.h, slot by slot) ---------------------------------------------------------
 // grad @ x (ell_math.h: grad_fwd)
 struct GradB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr int NST = 2;                      // vector-memory store instructions of finish()
     const float* in; long ldj, hs; float* out; long ldo;
     Vec<4> au, av;
     __device__ void init(int) { au = vzero<4>(); av = vzero<4>(); }
@@ -190,6 +358,7 @@ struct GradB {
 // div @ v (div_fwd)
 struct DivB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr int NST = 1;
     const float* in; long ldj, hs; float* out; long ldo;
     Vec<4> acc;
     __device__ void init(int) { acc = vzero<4>(); }
@@ -199,6 +368,7 @@ struct DivB {
 // [div v | curl v | norm v] (divcurlnorm_fwd)
 struct DivCurlNormB {
     static constexpr bool COEF = true, SELF = true;
+    static constexpr int NST = 3;
     const float* in; long ldj, hs; float* out; long ldo; int C;
     Vec<4> dv, cv;
     __device__ void init(int) { dv = vzero<4>(); cv = vzero<4>(); }
@@ -220,6 +390,7 @@ struct DivCurlNormB {
 // hodge Laplacian from [div v | curl v] (hodge_fwd): pieces = the two column blocks of one row
 struct HodgeB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr int NST = 2;
     const float* in; long ldj, hs; float* out; long ldo;
     Vec<4> hu, hv;
     __device__ void init(int) { hu = vzero<4>(); hv = vzero<4>(); }
@@ -238,6 +409,7 @@ struct HodgeB {
 template <bool AFFINE>
 struct KnnMaxB {
     static constexpr bool COEF = false, SELF = false;
+    static constexpr int NST = 2;
     const float* in; long ldj, hs; const float *scale, *shift; float slope; float* out; long ldo; unsigned char* arg; long lda;
     Vec<4> best; unsigned slot[4]; float sc[4], sh[4];
     __device__ void init(int c) {
@@ -266,18 +438,46 @@ struct KnnMaxB {
     }
 };
 
+// workgroups a CU holds (LDS; 2048 threads) x CUs of the device = the persistent grid's capacity
+inline int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
 template <int R, int P, class BODY>
 inline void launch_one(const DcTilePlan& L, const int* plan, const float* coef, const int* nbr, int C, BODY body, hipStream_t s) {
     const int slabs = C / CS;
     const size_t lds = lds_bytes<R, P>(L.k, BODY::COEF);
     static bool attr_set = false;                       // > 64 KiB of dynamic LDS needs the attribute once per kernel
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fwd_kernel<R, P, BODY>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if constexpr (R == 1)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_unit_kernel<R, P, BODY>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        else
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fwd_kernel<R, P, BODY>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((tile_fwd_kernel<R, P, BODY>), dim3((unsigned)L.T * slabs), dim3(P * 16), lds, s, L, plan, coef, nbr, slabs,
-                       dc_option(DC_OPT_XCD_REMAP), body);
+    const long units = (long)L.T * slabs;
+    if constexpr (R == 1) {
+        hipLaunchKernelGGL((tile_unit_kernel<R, P, BODY>), dim3((unsigned)units), dim3(P * 16), lds, s, L, plan, coef, nbr, slabs,
+                           dc_option(DC_OPT_XCD_REMAP), body);
+    } else {
+    const long per_cu = std::max<long>(1, std::min<long>(2048 / (P * 16), (160 * 1024) / (long)lds));
+    const long capacity = per_cu * device_cus();
+    // units per workgroup: fill the resident slots once; at least 2 as soon as that still leaves a workgroup per CU (the second
+    // unit's ids ride on the first one's pieces: -8 .. -11 % per launch at 32 x 1024 points, r03 sweep tools/tile_upw.py)
+    int upw = (int)((units + capacity - 1) / capacity);
+    if (upw < 2 && units >= 2L * device_cus()) upw = 2;
+    if (dc_option(7) > 0) upw = dc_option(7);           // option 7 (lab): forced
+    hipLaunchKernelGGL((tile_fwd_kernel<R, P, BODY>), dim3((unsigned)((units + upw - 1) / upw)), dim3(P * 16), lds, s, L, plan, coef, nbr,
+                       slabs, dc_option(DC_OPT_XCD_REMAP), upw, body);
+    }
 }
 template <int R, class BODY>
 inline void launch(const DcTilePlan& L, const int* plan, const float* coef, const int* nbr, int C, BODY body, hipStream_t s) {

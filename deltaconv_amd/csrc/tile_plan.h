@@ -14,8 +14,8 @@
 //   uniq [T][P*k]   int32   the unique row ids, ascending (the tile's own points are members); tail = last id
 //   loc  [T][P*k]   uint16  tile-local index of neighbour (p, s) in uniq
 //   self [T][P]     uint16  tile-local index of the point itself
-// T = ceil(num_points / P) + num_clouds is an upper bound known on the host without a sync (ragged clouds: cloud b
-// owns the tiles floor(ptr[b] / P) + b + [0, ceil(N_b / P)); tile ids in between stay empty).
+// T (dc_tile_plan_num_tiles) is known on the host without a sync: exact for equal-sized clouds, else an upper bound; cloud b owns the tiles
+// sum_{c < b} ceil(N_c / P) + [0, ceil(N_b / P)): the occupied ids are a dense prefix, the unused ids trail and stay empty.
 #pragma once
 #include <stdint.h>
 
@@ -32,12 +32,19 @@ struct DcTilePlan {
 
 DC_TP_HD long dc_tp_round4(long w) { return (w + 3) & ~3L; }
 
-DC_TP_HD DcTilePlan dc_tile_plan_layout(int num_points, int num_clouds, int k, int P) {
+// number of tile ids T: exact when every cloud has max_cloud points (num_points == num_clouds * max_cloud: the usual
+// fixed-size batches -- the launch then has no empty workgroups at all), else the bound ceil(num_points / P) + num_clouds
+DC_TP_HD int dc_tile_plan_num_tiles(int num_points, int num_clouds, int max_cloud, int P) {
+    if ((long)num_clouds * max_cloud == (long)num_points) return num_clouds * ((max_cloud + P - 1) / P);
+    return (num_points + P - 1) / P + num_clouds;
+}
+
+DC_TP_HD DcTilePlan dc_tile_plan_layout(int num_tiles, int k, int P) {
     DcTilePlan p;
     p.P = P;
     p.k = k;
     p.PK = P * k;
-    p.T = (num_points + P - 1) / P + num_clouds;
+    p.T = num_tiles;
     long w = 0;
     p.o_pts = w;   w = dc_tp_round4(w + (long)p.T * P);
     p.o_nu = w;    w = dc_tp_round4(w + p.T);
@@ -48,5 +55,3 @@ DC_TP_HD DcTilePlan dc_tile_plan_layout(int num_points, int num_clouds, int k, i
     return p;
 }
 
-// first tile of cloud b (ptr_b = first point of the cloud)
-DC_TP_HD int dc_tile_base(int ptr_b, int b, int P) { return ptr_b / P + b; }

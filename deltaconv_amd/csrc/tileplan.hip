@@ -32,15 +32,37 @@ __device__ __forceinline__ unsigned spread10(unsigned x) {   // 10 bits -> every
 //   the four counts are added and the point's id is written at its rank.  No sort passes, no barriers in the loop,
 //   N / 64 workgroups per cloud (a bitonic sort in one workgroup per cloud took 24 us at 32 x 1024 points and left 7/8
 //   of the chip idle at 8 x 4096; one thread per point over the whole list 111 us there).
+__device__ __forceinline__ int dc_wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// First tile of cloud b = the tiles of the clouds before it, sum of ceil(N_c / P): the occupied tile ids are a dense prefix
+// [0, T_used) and the unused ids of the host-side bound T trail behind it -- a launch over T workgroups then meets its
+// empty tiles last, in the tail, instead of spending resident-workgroup slots on them in the middle of the grid (32 x 1024
+// points, P = 64: 512 occupied tiles = exactly two rounds of 256 CUs; with one spare id per cloud in between, 544).
+// Every workgroup of the two kernels below recomputes the sum (<= a few thousand cached words): no scan kernel.
+__device__ __forceinline__ int block_tile_base(const int* __restrict__ cloud_ptr, int b, int P, int* red /* [4] LDS */) {
+    int s = 0;
+    for (int c = threadIdx.x; c < b; c += 256) s += (cloud_ptr[c + 1] - cloud_ptr[c] + P - 1) / P;
+    s = dc_wave_sum_i(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const int total = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return total;
+}
+
 __global__ __launch_bounds__(256) void tile_key_kernel(const float* __restrict__ pos, const int* __restrict__ cloud_ptr,
                                                        int num_clouds, unsigned* __restrict__ keys, int* __restrict__ plan,
                                                        DcTilePlan L) {
     __shared__ float red[6][4];
+    __shared__ int tred[4];
     const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int begin = cloud_ptr[b], N = cloud_ptr[b + 1] - begin;
-    if (chunk == 0) {
-        const int tile0 = dc_tile_base(begin, b, L.P);
-        const int tile1 = b + 1 < num_clouds ? dc_tile_base(begin + N, b + 1, L.P) : L.T;
+    if (chunk == 0) {                                      // block-uniform
+        const int tile0 = block_tile_base(cloud_ptr, b, L.P, tred);
+        const int tile1 = b + 1 < num_clouds ? tile0 + (max(N, 0) + L.P - 1) / L.P : L.T;   // the last cloud also clears the unused ids
         int* pts = plan + L.o_pts + (long)tile0 * L.P;
         for (int i = max(N, 0) + tid; i < (tile1 - tile0) * L.P; i += 256) pts[i] = -1;
         for (int t = tile0 + tid; t < tile1; t += 256) plan[L.o_nu + t] = 0;
@@ -86,9 +108,11 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void tile_rank_kernel(const unsigned* __restrict__ keys, const int* __restrict__ cloud_ptr,
                                                         int* __restrict__ plan, DcTilePlan L) {
     __shared__ __attribute__((aligned(16))) unsigned key[MAX_CLOUD];
+    __shared__ int tred[4];
     const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int begin = cloud_ptr[b], N = cloud_ptr[b + 1] - begin;
     if (chunk * 64 >= N) return;                           // block-uniform
+    const int tile0 = block_tile_base(cloud_ptr, b, L.P, tred);
     const int N16 = (N + 15) & ~15;
     for (int i = tid; i < N16; i += 256) key[i] = i < N ? keys[begin + i] : 0xffffffffu;   // padding sorts last
     __syncthreads();
@@ -102,7 +126,7 @@ __global__ __launch_bounds__(256) void tile_rank_kernel(const unsigned* __restri
     }
     rank += __shfl_xor(rank, 1, 64);
     rank += __shfl_xor(rank, 2, 64);
-    if (sub == 0 && i < N) plan[L.o_pts + (long)dc_tile_base(begin, b, L.P) * L.P + rank] = begin + i;
+    if (sub == 0 && i < N) plan[L.o_pts + (long)tile0 * L.P + rank] = begin + i;
 }
 
 // one workgroup per tile: bitmap of the tile's rows over the cloud's local ids -> prefix popcounts -> unique list
@@ -204,12 +228,12 @@ int check_plan_args(const char* name, int num_points, int num_clouds, int k, int
 }
 }  // namespace
 
-DC_EXPORT int32_t dc_tile_plan_tiles(int32_t num_points, int32_t num_clouds, int32_t P) {
-    return (num_points + P - 1) / P + num_clouds;
+DC_EXPORT int32_t dc_tile_plan_tiles(int32_t num_points, int32_t num_clouds, int32_t max_cloud, int32_t P) {
+    return dc_tile_plan_num_tiles(num_points, num_clouds, max_cloud, P);
 }
 
-DC_EXPORT size_t dc_tile_plan_words(int32_t num_points, int32_t num_clouds, int32_t k, int32_t P) {
-    return (size_t)dc_tile_plan_layout(num_points, num_clouds, k, P).words;
+DC_EXPORT size_t dc_tile_plan_words(int32_t num_tiles, int32_t k, int32_t P) {
+    return (size_t)dc_tile_plan_layout(num_tiles, k, P).words;
 }
 
 DC_EXPORT int32_t dc_tile_plan_max_cloud(void) { return MAX_CLOUD; }
@@ -222,7 +246,7 @@ DC_EXPORT int dc_tile_plan_build(const float* pos, const int32_t* nbr, const int
                MAX_CLOUD, max_cloud);
     if (num_points == 0 || num_clouds == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const DcTilePlan L = dc_tile_plan_layout(num_points, num_clouds, k, P);
+    const DcTilePlan L = dc_tile_plan_layout(dc_tile_plan_num_tiles(num_points, num_clouds, max_cloud, P), k, P);
     unsigned* keys = reinterpret_cast<unsigned*>(plan + L.o_uniq);      // scratch: the uniq section is written afterwards
     hipLaunchKernelGGL(tile_key_kernel, dim3(num_clouds, dc_cdiv(max_cloud, 256)), dim3(256), 0, s, pos, cloud_ptr, num_clouds, keys,
                        plan, L);

@@ -52,12 +52,12 @@ class TilePlan:
     def __init__(self, graph, blob, P):
         self.blob, self.P = blob, P
         self.n, self.k, self.num_clouds = graph.n, graph.k, graph.num_clouds
-        self.tiles = int(lib.raw("dc_tile_plan_tiles")(graph.n, graph.num_clouds, P))
+        self.tiles = int(lib.raw("dc_tile_plan_tiles")(graph.n, graph.num_clouds, graph.max_cloud, P))
 
     @property
     def args(self):
-        """(n, num_clouds, k, P): the size arguments every tiled entry point takes after (plan, nbr)."""
-        return self.n, self.num_clouds, self.k, self.P
+        """(n, num_tiles, k, P): the size arguments every tiled entry point takes after (plan, nbr)."""
+        return self.n, self.tiles, self.k, self.P
 
     def section(self, name):
         """View of one section of the blob (tests / debugging): 'pts' [T,P], 'nu' [T], 'uniq' [T,P*k] int32;
@@ -101,7 +101,7 @@ class Graph:
         apply or does not pay: positions unknown, clouds beyond the builder's limit, k > 24, fewer than 8192 points, or
         the switch is off.  force_P = 32 | 64 builds a plan regardless of the pay-off heuristic."""
         if force_P is not None and (self._tile_plan is None or not self._tile_plan or self._tile_plan.P != force_P):
-            words = int(lib.raw("dc_tile_plan_words")(self.n, self.num_clouds, self.k, force_P))
+            words = int(lib.raw("dc_tile_plan_words")(int(lib.raw("dc_tile_plan_tiles")(self.n, self.num_clouds, self.max_cloud, force_P)), self.k, force_P))
             blob = torch.empty(words, dtype=torch.int32, device=self.nbr.device)
             lib.call("dc_tile_plan_build", self.pos, self.nbr, self.ptr, self.num_clouds, self.n, self.max_cloud,
                      self.k, force_P, blob)
@@ -117,7 +117,7 @@ class Graph:
             pays = forced or (self.k <= 24 and self.n >= 8192)
             if (USE_TILE_PLAN[0] and pays and self.pos is not None and self.nbr.is_cuda and self.n > 0 and self.k % 2 == 0
                     and self.max_cloud <= int(lib.raw("dc_tile_plan_max_cloud")()) and P * self.k <= 2048):
-                words = int(lib.raw("dc_tile_plan_words")(self.n, self.num_clouds, self.k, P))
+                words = int(lib.raw("dc_tile_plan_words")(int(lib.raw("dc_tile_plan_tiles")(self.n, self.num_clouds, self.max_cloud, P)), self.k, P))
                 blob = torch.empty(words, dtype=torch.int32, device=self.nbr.device)
                 lib.call("dc_tile_plan_build", self.pos, self.nbr, self.ptr, self.num_clouds, self.n, self.max_cloud,
                          self.k, P, blob)

@@ -136,27 +136,28 @@ int dc_apply_div_curl_norm_T(const float* DT, const int32_t* tptr, const int32_t
  * per batch, like the CSC.  The reference has no counterpart (torch_sparse / torch_scatter gather from global memory).
  * Restrictions: clouds of at most dc_tile_plan_max_cloud() points, k even, k <= 64, P * k <= 2048; the apply entry
  * points need C % 64 == 0 and 16-byte aligned rows and return DC_ERR_ARG otherwise (use the plain entry points).
- * The operator argument is the same G / D as for the plain entry points. */
-int32_t dc_tile_plan_tiles(int32_t num_points, int32_t num_clouds, int32_t P);     /* number of tile ids T */
-size_t dc_tile_plan_words(int32_t num_points, int32_t num_clouds, int32_t k, int32_t P);   /* plan size in int32 words */
+ * The operator argument is the same G / D as for the plain entry points.  Occupied tile ids are a dense prefix of
+ * [0, num_tiles): cloud b owns sum_{c<b} ceil(N_c / P) + [0, ceil(N_b / P)); for equal-sized clouds num_tiles is exact. */
+int32_t dc_tile_plan_tiles(int32_t num_points, int32_t num_clouds, int32_t max_cloud, int32_t P);   /* number of tile ids T: the `num_tiles` of every call below */
+size_t dc_tile_plan_words(int32_t num_tiles, int32_t k, int32_t P);   /* plan size in int32 words */
 int32_t dc_tile_plan_max_cloud(void);
 int dc_tile_plan_build(const float* pos, const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds,
                        int32_t num_points, int32_t max_cloud, int32_t k, int32_t P, int32_t* plan, void* stream);
-int dc_apply_grad_tiled(const float* G, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+int dc_apply_grad_tiled(const float* G, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles,
                         int32_t k, int32_t P, const float* x, int32_t C, int64_t ldx, float* out, int64_t ldo,
                         void* stream);
-int dc_apply_div_tiled(const float* D, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+int dc_apply_div_tiled(const float* D, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles,
                        int32_t k, int32_t P, const float* v, int32_t C, int64_t ldv, float* out, int64_t ldo,
                        void* stream);
 int dc_apply_div_curl_norm_tiled(const float* D, const int32_t* plan, const int32_t* nbr, int32_t n,
-                                 int32_t num_clouds, int32_t k, int32_t P, const float* v, int32_t C, int64_t ldv,
+                                 int32_t num_tiles, int32_t k, int32_t P, const float* v, int32_t C, int64_t ldv,
                                  float* out, int64_t ldo, void* stream);
-int dc_apply_hodge_tiled(const float* G, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds,
+int dc_apply_hodge_tiled(const float* G, const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles,
                          int32_t k, int32_t P, const float* dc, int32_t C, int64_t lddc, float* out, int64_t ldo,
                          void* stream);
-int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k, int32_t P,
+int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles, int32_t k, int32_t P,
                      const float* h, int32_t C, int64_t ldh, float* out, int64_t ldo, uint8_t* arg, void* stream);
-int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_clouds, int32_t k,
+int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles, int32_t k,
                             int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale, const float* shift,
                             float slope, float* out, int64_t ldo, uint8_t* arg, void* stream);
 

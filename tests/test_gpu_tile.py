@@ -44,6 +44,12 @@ def test_plan_structure(sizes, k):
     # every point exactly once
     flat = pts[valid].long()
     assert flat.numel() == n and torch.equal(torch.sort(flat).values, torch.arange(n))
+    # the occupied tile ids are a dense prefix (unused ids trail: a launch meets its empty workgroups last), and equal-sized
+    # clouds leave no unused id at all
+    occ = valid.any(1)
+    assert bool(occ[:int(occ.sum())].all())
+    if len(set(sizes)) == 1:
+        assert bool(occ.all())
     # a tile never mixes clouds; empty tiles have no unique rows; padding only at the end of a tile
     for t in range(pts.shape[0]):
         row = pts[t]

@@ -6,8 +6,9 @@ import torch
 from deltaconv_amd._lib import lib
 
 
-def _layout(n, nc, k, P):
-    T = (n + P - 1) // P + nc
+def _layout(n, nc, mx, k, P):
+    # equal-sized clouds: exactly their tiles; ragged: the host-side bound (occupied ids are a dense prefix either way)
+    T = nc * ((mx + P - 1) // P) if nc * mx == n else (n + P - 1) // P + nc
     PK = P * k
     r4 = lambda w: (w + 3) & ~3
     o_nu = r4(T * P)
@@ -17,20 +18,23 @@ def _layout(n, nc, k, P):
     return T, r4(o_self + (T * P + 1) // 2) + 64
 
 
-@pytest.mark.parametrize("n,nc,k,P", [(32768, 32, 20, 64), (32768, 8, 30, 32), (1535, 3, 10, 64), (65, 1, 64, 32), (0, 0, 20, 64)])
-def test_layout_matches_library(n, nc, k, P):
-    T, words = _layout(n, nc, k, P)
-    assert int(lib.raw("dc_tile_plan_tiles")(n, nc, P)) == T
-    assert int(lib.raw("dc_tile_plan_words")(n, nc, k, P)) == words
+@pytest.mark.parametrize("n,nc,mx,k,P", [(32768, 32, 1024, 20, 64), (32768, 8, 4096, 30, 32), (1535, 3, 700, 10, 64),
+                                         (3000, 3, 1000, 20, 64), (65, 1, 65, 64, 32), (0, 0, 0, 20, 64)])
+def test_layout_matches_library(n, nc, mx, k, P):
+    T, words = _layout(n, nc, mx, k, P)
+    assert int(lib.raw("dc_tile_plan_tiles")(n, nc, mx, P)) == T
+    assert int(lib.raw("dc_tile_plan_words")(T, k, P)) == words
+    if nc * mx == n and n:
+        assert T == nc * -(-mx // P)                   # no spare tile ids at all
 
 
 def test_section_views_cover_the_blob():
     from deltaconv_amd.geometry.graph import TilePlan
 
     class G:                                       # the fields TilePlan reads from a Graph
-        n, k, num_clouds = 1535, 10, 3
+        n, k, num_clouds, max_cloud = 1535, 10, 3, 700
     P = 64
-    words = int(lib.raw("dc_tile_plan_words")(G.n, G.num_clouds, G.k, P))
+    words = int(lib.raw("dc_tile_plan_words")(int(lib.raw("dc_tile_plan_tiles")(G.n, G.num_clouds, G.max_cloud, P)), G.k, P))
     blob = torch.arange(words, dtype=torch.int32)
     plan = TilePlan(G, blob, P)
     T = plan.tiles
@@ -39,7 +43,7 @@ def test_section_views_cover_the_blob():
     # sections are disjoint, ordered, 16-byte aligned
     starts = [int(plan.section(s).reshape(-1)[0]) for s in ("pts", "nu", "uniq")]
     assert starts == sorted(starts) and all(s % 4 == 0 for s in starts)
-    assert plan.args == (G.n, G.num_clouds, G.k, P)
+    assert plan.args == (G.n, T, G.k, P)
 
 
 def test_max_cloud_and_rowblock_limits_exported():
