@@ -143,13 +143,22 @@ def apply_roofline(graph, grad, div, C, iters=200):
     nb = lib.raw("dc_gemm_tn_workspace_bytes")(R, M, N)
     ws = torch.empty((nb + 3) // 4, device=dev)
     tg = _time(lambda: lib.call("dc_gemm_tn", A, M, Bm, N, R, M, N, Cout, N, 0, ws, ws.numel() * 4))
-    mfma = dict(kernel=f"gemm_kernel<128,128> + statistics epilogue + finaliser (Y = X W^T, {Me}x{Ne}x{Ke}, fp32 "
-                       "v_mfma_f32_32x32x2, LDS-staged)",
-                us=round(te * 1e6, 1), achieved=round(2.0 * Me * Ne * Ke / te / 1e12, 1), peak=157.3, unit="TFLOP/s",
-                frac=round(2.0 * Me * Ne * Ke / te / 1e12 / 157.3, 3),
+    # Dense products: by default an fp32 product is six bf16 partial products (3 planes per operand, csrc/gemm.hip) on the
+    # bf16 matrix pipe, fp32 accumulation -- error against fp64 at or below the exact fp32 MFMA chain's
+    # (tests/test_gpu_gemm.py::test_split_products_no_worse_than_exact_chain).  The matrix pipe therefore executes 6 x the
+    # algorithmic flops; `frac` prices THAT against the dense bf16 peak, `fp32_equivalent` is the algorithmic rate (the
+    # exact chain's ceiling is the 157.3 TFLOP/s fp32 MFMA peak; DC_GEMM_EXACT=1 selects it).
+    exact = os.environ.get("DC_GEMM_EXACT", "0") not in ("", "0")
+    mult, peak = (1.0, 157.3) if exact else (6.0, 2500.0)
+    path = "exact fp32 chain v_mfma_f32_32x32x2_f32" if exact else "bf16 split products 6 x v_mfma_f32_32x32x16_bf16, fp32 accumulate"
+
+    def _rate(flops, t):
+        return dict(us=round(t * 1e6, 1), fp32_equivalent=round(flops / t / 1e12, 1), achieved=round(mult * flops / t / 1e12, 1),
+                    frac=round(mult * flops / t / 1e12 / peak, 3))
+    mfma = dict(kernel=f"gemm_kernel<128,128> + statistics epilogue + finaliser (Y = X W^T, {Me}x{Ne}x{Ke}, {path}, LDS-staged)",
+                peak=peak, unit="TFLOP/s", pipe_flops_per_algorithmic_flop=mult, **_rate(2.0 * Me * Ne * Ke, te),
                 weight_gradient=dict(kernel=f"gemm_kernel<128,128, A_KM, B_KN> over row slabs + ordered reduce (dW = dY^T X, {R}x{M}x{N})",
-                                     us=round(tg * 1e6, 1), achieved=round(2.0 * R * M * N / tg / 1e12, 1),
-                                     frac=round(2.0 * R * M * N / tg / 1e12 / 157.3, 3)))
+                                     **_rate(2.0 * R * M * N, tg)))
     head = fam["div_curl_norm"]
     # HBM bytes per launch from the PMC passes: counters cannot be read from inside the process, they come from separate
     # `rocprofv3 --pmc` runs of tools/pmc_apply.sh on the binary named by `traffic_tag` (profiles/README.md)
@@ -341,6 +350,9 @@ def main():
             "value": args.batch * world * args.steps / dt, "unit": "clouds/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": ("fp32 tensors and fp32 accumulation everywhere; the dense per-point products multiply through six bf16 "
+                           "partial products of a 3-plane split of each fp32 operand (error against fp64 at or below the exact fp32 "
+                           "MFMA chain's: tests/test_gpu_gemm.py; DC_GEMM_EXACT=1 runs the exact chain)"),
             "data": "synthetic (seeded smooth closed surfaces with analytic normals, random-init weights)",
             "config": {"workload": f"ModelNet40 classification, {args.points} points, k={args.k}, "
                                    f"batch={args.batch} per GPU, fwd+bwd+SGD step, train-mode BN/Dropout, "

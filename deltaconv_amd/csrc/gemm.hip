@@ -74,7 +74,12 @@ struct GemmP {
     float slope;
     double* part; int chunks, stat_cols;   // statistics partials [2][stat_cols][chunks]
     int stagger, resident;                 // first-round phase shift (shader cycles) of every second workgroup of a CU
+    // Side job: the first `red_blocks` workgroups of the grid do not multiply -- they sum the slab partials of the weight
+    // gradient that the PREVIOUS launch left in its workspace (the ordered reduction of gemm_tn.hip, same association, same
+    // bits), under this product's last tiles instead of in a launch of their own between the two products.
+    const float* red_src; float* red_dst; long red_ldc, red_mn; int red_n, red_slabs, red_acc, red_blocks, red_chunks;
 };
+constexpr int RED_CHUNKS = 8;              // 64-element chunks per tail workgroup, at most (32 KB of the operand ring)
 
 // Fast-path load: buffer_load through a descriptor built from the wave-uniform tile origin (SGPRs), a wave-uniform
 // byte offset (soff: which of the thread's loads) and ONE 32-bit per-thread byte offset per operand (voff) -- no 64-bit
@@ -164,6 +169,45 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// C[e] (+)= sum over slabs of partial[slab][e] for the 64 * red_chunks elements of tail workgroup tb.  The association of
+// gemm_tn_reduce_kernel (16 interleaved chains: chain q sums the slabs q, q + 16, ..., then the chains are added in order),
+// carried by 4 waves x 4 chains: bit-identical to the stand-alone reduction.  All chunks advance together (one memory
+// round trip per 16 slabs for the whole workgroup, not per chunk).
+__device__ __forceinline__ void tail_reduce(const GemmP& p, long tb, float* sm /* [16][64 * RED_CHUNKS] */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nch = p.red_chunks;
+    const long e0 = tb * nch * 64 + lane;
+    float s[RED_CHUNKS][4];
+#pragma unroll
+    for (int ch = 0; ch < RED_CHUNKS; ++ch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[ch][j] = 0.f;
+    for (int sl0 = 0; sl0 < p.red_slabs; sl0 += 16)
+#pragma unroll
+        for (int ch = 0; ch < RED_CHUNKS; ++ch)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sl = sl0 + w + 4 * j;
+                const long e = e0 + ch * 64;
+                if (ch < nch && sl < p.red_slabs && e < p.red_mn) s[ch][j] += p.red_src[(long)sl * p.red_mn + e];
+            }
+#pragma unroll
+    for (int ch = 0; ch < RED_CHUNKS; ++ch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[(w + 4 * j) * (64 * RED_CHUNKS) + ch * 64 + lane] = s[ch][j];
+    __syncthreads();
+    for (int ch = w; ch < nch; ch += 4) {
+        const long e = e0 + ch * 64;
+        if (e < p.red_mn) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += sm[q * (64 * RED_CHUNKS) + ch * 64 + lane];
+            float* dst = p.red_dst + (e / p.red_n) * p.red_ldc + (e % p.red_n);
+            *dst = p.red_acc ? *dst + t : t;
+        }
+    }
+}
+
 template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0, int X3 = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     constexpr bool FAST = MODE == 0;               // no guards anywhere (loads, statistics, stores)
@@ -186,14 +230,26 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     // tile's first loads (pipe idle).  Holding back the workgroup in the ODD wave slot (HW_ID.WAVE_ID: the second
     // workgroup placed on the CU) by about half a K loop in the first round puts one workgroup's epilogue under the
     // other's K loop for the rest of the launch.
-    if (p.stagger > 0 && (long)blockIdx.y * gridDim.x + blockIdx.x < p.resident) {
+    // (the FIRST red_blocks workgroups of the grid, a multiple of 8: dispatched before the products, their few microseconds
+    // disappear in the first of the product's rounds; as the last workgroups they were a round of their own behind it)
+    const unsigned gemm_blocks = gridDim.x - (unsigned)p.red_blocks;
+    if (blockIdx.x < (unsigned)p.red_blocks) {       // side job (block-uniform)
+        tail_reduce(p, (long)blockIdx.x, smem);
+        return;
+    }
+    const unsigned bid = blockIdx.x - (unsigned)p.red_blocks;
+    if (p.stagger > 0 && (long)blockIdx.y * gridDim.x + bid < p.resident) {
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_REG_HW_ID bits [3:0]
         if (slot & 1) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
             while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(16);
         }
     }
-    const long blk = dc_xcd_block(p.remap);
+    long blk = bid;                                  // XCD-aware placement over the multiplying workgroups (common.h: dc_xcd_block)
+    if (p.remap) {
+        const long q = gemm_blocks >> 3, r = gemm_blocks & 7, xcd = blk & 7, idx = blk >> 3;
+        blk = xcd * q + (xcd < r ? xcd : r) + idx;
+    }
     const long kbeg = (long)blockIdx.y * p.k_per_slab;
     const long kend = min(p.K, kbeg + p.k_per_slab);
     const long tm = blk / p.tiles_n;
@@ -765,8 +821,8 @@ void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>), dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs),
-                       dim3(NT), lds, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>),
+                       dim3((unsigned)(tiles_m * p.tiles_n) + (unsigned)p.red_blocks, (unsigned)slabs), dim3(NT), lds, s, p);
 }
 
 template <int AL, int BL, int MODE, int EPI, int PRO, int X3 = 0>
@@ -818,10 +874,15 @@ bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // bl: operand layout of W; epi: fused statistics; part/chunks filled by the caller for epi != 0
 struct Prologue { const float* h; long ldh; const float* coefs; int ncoef; float slope; };
+struct TailReduce { const float* partial; int slabs; long mn; int n; float* dst; long ldc; int accumulate; };
+void clear_tail(GemmP& p) {
+    p.red_src = nullptr; p.red_dst = nullptr; p.red_ldc = 0; p.red_mn = 0; p.red_n = 1; p.red_slabs = 0; p.red_acc = 0;
+    p.red_blocks = 0; p.red_chunks = 1;
+}
 
 int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const float* B, long ldb, long M, int N, int K,
              float* C, long ldc, int accumulate, int tile, double* part, int stat_cols, hipStream_t s,
-             const Prologue* pro = nullptr) {
+             const Prologue* pro = nullptr, const TailReduce* tail = nullptr) {
     const Tile t = pick_tile(M, N, K, tile);
     const long tiles_m = (M + t.bm - 1) / t.bm;
     GemmP p;
@@ -834,6 +895,15 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
     p.A2 = nullptr; p.lda2 = 0; p.pc = nullptr; p.pcn = 0; p.slope = 0.f;
     set_stagger(p, t, tiles_m * p.tiles_n, (long)K);
+    clear_tail(p);
+    if (tail) {
+        p.red_src = tail->partial; p.red_dst = tail->dst; p.red_ldc = tail->ldc; p.red_mn = tail->mn; p.red_n = tail->n;
+        p.red_slabs = tail->slabs; p.red_acc = tail->accumulate;
+        // ~512 tail workgroups (one resident round), 1 .. RED_CHUNKS chunks of 64 elements each
+        p.red_chunks = (int)std::min<long>(RED_CHUNKS, std::max<long>(1, (tail->mn / 64 + 511) / 512));
+        p.red_blocks = (int)((tail->mn + 64L * p.red_chunks - 1) / (64L * p.red_chunks));
+        p.red_blocks = (p.red_blocks + 7) & ~7;       // keeps block id mod 8 (= the XCD) of the products' workgroups
+    }
     if (lda >= (1 << 21) || ldb >= (1 << 21) || (pro && pro->ldh >= (1 << 21))) {     // 32-bit in-tile byte offsets
         dc_set_error("%s: leading dimension above 2^21 elements", name);
         return DC_ERR_ARG;
@@ -911,6 +981,7 @@ int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R,
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
     p.A2 = h; p.lda2 = ldh; p.pc = coefs; p.pcn = M; p.slope = slope;
     set_stagger(p, t, tiles_m * p.tiles_n * pl.slabs, pl.rows_per_slab);
+    clear_tail(p);
     if (lda >= (1 << 21) || ldb >= (1 << 21) || ldh >= (1 << 21)) return -1;      // 32-bit in-tile byte offsets
     const bool whole = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && N % 4 == 0 &&
                        al16p(partial);
@@ -959,6 +1030,42 @@ DC_EXPORT int dc_linear_bn_backward_input(const float* dy, int64_t lddy, const f
     const Prologue pro{h, (long)ldh, coefs, N, slope};
     return run_gemm("dc_linear_bn_backward_input", B_KN, EPI_NONE, dy, lddy, W, ldw, M, K, N, dX, lddx, accumulate, tile,
                     nullptr, 0, static_cast<hipStream_t>(stream), &pro);
+}
+
+// Both gradients of y = x W^T for the incoming dY [R, N] (or, with h / coefs, dh = BatchNorm/activation backward of (dY, h)
+// formed in the operand loaders: dc_linear_bn_backward_weight / _input):
+//   dW[N, K] (lddw) (+)= dh^T X      slab partials into the workspace (dc_gemm_tn_workspace_bytes(R, N, K)),
+//   dX[R, K] (lddx) (+)= dh W        and the ordered slab reduction of dW runs as the TAIL workgroups of this launch --
+// the same results, bit for bit, as the two separate entry points, one launch less per layer (the reduction is a
+// 5 - 20 us launch of its own otherwise, 12 per step of the ModelNet40 model).
+DC_EXPORT int dc_linear_backward_pair(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
+                                      float slope, const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t R,
+                                      int32_t N, int32_t K, float* dW, int64_t lddw, int32_t accumulate_w, float* dX,
+                                      int64_t lddx, int32_t accumulate_x, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    DC_REQUIRE(dy && X && W && dW && dX, "dc_linear_backward_pair: null pointer");
+    DC_REQUIRE((h == nullptr) == (coefs == nullptr), "dc_linear_backward_pair: h and coefs go together");
+    DC_REQUIRE(R >= 1 && N >= 1 && K >= 1 && lddy >= N && (!h || ldh >= N) && ldx >= K && ldw >= K && lddw >= K && lddx >= K,
+               "dc_linear_backward_pair: bad size");
+    DC_REQUIRE(lddy < (1 << 21) && ldh < (1 << 21) && ldx < (1 << 21) && ldw < (1 << 21),
+               "dc_linear_backward_pair: leading dimension above 2^21 elements");
+    const DcTnPlan pl = dc_tn_lds_plan((long)R, N, K);
+    if (!workspace || workspace_bytes < (size_t)pl.slabs * N * K * sizeof(float)) {
+        dc_set_error("dc_linear_backward_pair: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* partial = static_cast<float*>(workspace);
+    const int slabs = dc_tn_lds_launch(dy, (long)lddy, X, (long)ldx, (long)R, N, K, partial, s, h, (long)ldh, coefs, slope);
+    if (slabs < 0) {
+        dc_set_error("dc_linear_backward_pair: weight-gradient launch failed");
+        return DC_ERR_LAUNCH;
+    }
+    const TailReduce tail{partial, slabs, (long)N * K, K, dW, (long)lddw, accumulate_w};
+    const Prologue pro{h, (long)ldh, coefs, N, slope};
+    // dX as a product: C[R, K] = A[R, N] B[N, K] -- reduction over N, B stored reduction-major
+    return run_gemm("dc_linear_backward_pair", B_KN, EPI_NONE, dy, lddy, W, ldw, R, K, N, dX, lddx, accumulate_x, 0, nullptr, 0,
+                    s, h ? &pro : nullptr, &tail);
 }
 
 DC_EXPORT size_t dc_linear_stats_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t tile) {

@@ -5,6 +5,8 @@ per-cloud products (the 32-row classification head) go to the vendor library.
 
 Reference semantics: deltaconv/nn/mlp.py:7-17 and nn/nonlin.py:11-86 (Linear(no bias) ->
 BatchNorm1d over rows -> LeakyReLU(0.2);  Linear(no bias) -> VectorNonLin(BatchNorm1d))."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -419,6 +421,44 @@ def mm_nn(dy, w, out=None, accumulate=False):
     return out
 
 
+# Both gradients of a Linear layer from one entry point (dc_linear_backward_pair: the weight gradient's slab reduction runs
+# as side workgroups of the input-gradient launch).  Same bits, 11 launches fewer per ModelNet40 step -- and 50 - 70 us SLOWER
+# per step in every placement tried (side workgroups last: an extra round behind the product; first: they delay its first
+# round and evict the operands from L2; profiles/r03_pair_ab.txt): off by default, env DC_PAIR=1 switches it on.
+USE_PAIR = os.environ.get("DC_PAIR", "0") == "1"
+
+
+def _pair_ok(dh, x, w, out):
+    r, n = dh.shape
+    k = w.shape[1]
+    return (USE_PAIR and USE_MFMA_TN and _own_gemm(dh) and r >= 8192 and n * k <= min(OWN_TN_MAX_OUTPUTS, OWN_GEMM_MAX_WEIGHT)
+            and x.dtype == torch.float32 and x.stride(1) == 1 and (out is None or out.stride(1) == 1))
+
+
+def linear_grads(dh, x, w, dx_out=None, accumulate=False, bn=None):
+    """Both gradients of y = x w^T for the incoming dh [R, N]: -> (dW [N, K], dX [R, K]); dX lands in `dx_out`
+    (+= when accumulate) if given.  bn = (h, ldh, coefs, slope): dh is the BatchNorm/activation backward of (dh, h), formed
+    in the operand loaders (bn_block_backward).  One entry point (dc_linear_backward_pair): the ordered slab reduction of
+    dW runs as the tail workgroups of the dX launch; where that does not apply, the two separate products."""
+    dh, w = _rowmajor(dh), _rowmajor(w)
+    if bn is None and not _pair_ok(dh, x, w, dx_out):
+        xx = x if x.stride(1) == 1 else x.contiguous()
+        return gemm_tn(dh, xx), mm_nn(dh, w, out=dx_out, accumulate=accumulate)
+    x = _rowmajor(x)
+    r, n = dh.shape
+    k = w.shape[1]
+    dev = dh.device
+    dW = torch.empty(n, k, dtype=torch.float32, device=dev)
+    dX = dx_out if dx_out is not None else torch.empty(r, k, dtype=torch.float32, device=dev)
+    assert dx_out is not None or not accumulate
+    nb = lib.raw("dc_gemm_tn_workspace_bytes")(r, n, k)
+    ws = torch.empty((nb + 3) // 4, dtype=torch.float32, device=dev)
+    h, ldh, coefs, slope = bn if bn is not None else (None, 0, None, 0.0)
+    lib.call("dc_linear_backward_pair", dh, dh.stride(0), h, ldh, coefs, slope, x, x.stride(0), w, w.stride(0), r, n, k, dW, k, 0,
+             dX, dX.stride(0), int(accumulate), ws, ws.numel() * 4)
+    return dW, dX
+
+
 def linear_stats(x, w, bn, gamma, beta, vn=0):
     """h = x w^T together with the BatchNorm coefficients of the layer behind it, from the GEMM epilogue:
     -> (h, coef[4, C] = mean / invstd / scale / shift, use_batch_stats).  vn = 2: w = the [2co, K] view of the first
@@ -488,6 +528,9 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
         coefs = torch.empty(5 * c, dtype=torch.float32, device=dev)
         lib.call("dc_bn_act_backward_reduce", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
                  int(use_batch), dg, db, coefs, ws, nb)
+        if want_dinp and USE_PAIR and lddy == dy.stride(0):
+            dW, dinp = linear_grads(dy, inp, W, dx_out=dinp_out, accumulate=accumulate, bn=(h, c, coefs, slope))
+            return dW, dg, db, dinp
         dW = torch.empty(c, k, dtype=torch.float32, device=dev)
         nb2 = lib.raw("dc_gemm_tn_workspace_bytes")(r, c, k)
         ws2 = torch.empty((nb2 + 3) // 4, dtype=torch.float32, device=dev)
@@ -528,8 +571,11 @@ class _Linear(torch.autograd.Function):
         x, w = ctx.saved_tensors
         if dy.stride(1) != 1:
             dy = dy.contiguous()
-        dx = mm_nn(dy, w) if ctx.needs_input_grad[0] else None
-        dw = gemm_tn(dy, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dw, dx = linear_grads(dy, x, w)
+        else:
+            dx = mm_nn(dy, w) if ctx.needs_input_grad[0] else None
+            dw = gemm_tn(dy, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
         db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
@@ -708,8 +754,11 @@ class _LinearBNActPool(torch.autograd.Function):
         ws, nb = _ws(r, c, dev)
         lib.call("dc_bn_act_pool_backward", dpooled, dpooled.shape[1], arg, h, c, num_clouds, n_per, c, coef[2], coef[3],
                  coef[0], coef[1], gamma, slope, int(with_mean), int(training), dh, c, dgamma, dbeta, ws, nb)
-        dw = gemm_tn(dh, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
-        dx = mm_nn(dh, w) if ctx.needs_input_grad[0] else None
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dw, dx = linear_grads(dh, x, w)
+        else:
+            dw = gemm_tn(dh, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
+            dx = mm_nn(dh, w) if ctx.needs_input_grad[0] else None
         return dx, dw, dgamma, dbeta, None, None, None, None, None
 
 

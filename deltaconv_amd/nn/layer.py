@@ -297,15 +297,15 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 dh, dg, db = _vn_backward(dcur, ldd, h, 2 if j == 0 else 0, coef, use_v[j], gv)
                 if j == 0:
                     Wst = W.view(2 * W.shape[0], K)
-                    dW = fused.gemm_tn(dh, inp).view(W.shape[0], 2 * K)      # [2c, K] rows (c, half) = the [c, 2K] layout
                     if need_v or need_x:
-                        dv_cat = fused.mm_nn(dh, Wst)                        # [2n, K]
+                        dW, dv_cat = fused.linear_grads(dh, inp, Wst)        # dv_cat [2n, K]
+                        dW = dW.view(W.shape[0], 2 * K)                      # [2c, K] rows (c, half) = the [c, 2K] layout
                     else:   # first layer (x, v carry no gradient): only the `grad @ x'` block of d v_cat is consumed
+                        dW = fused.gemm_tn(dh, inp).view(W.shape[0], 2 * K)
                         dv_cat = torch.empty(2 * n, K, **f32)
                         fused.mm_nn(dh, Wst[:, 2 * ci:].contiguous(), out=dv_cat[:, 2 * ci:])
                 else:
-                    dW = fused.gemm_tn(dh, inp)
-                    dcur = fused.mm_nn(dh, W)
+                    dW, dcur = fused.linear_grads(dh, inp, W)
                     ldd = dcur.stride(0)
                 gv_list[j] = (dW, dg, db)
             # grad^T of the `grad @ x'` block accumulates into d x'

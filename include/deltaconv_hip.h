@@ -330,6 +330,15 @@ int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const float* h, int
 int dc_linear_bn_backward_input(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
                                 float slope, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K, float* dX,
                                 int64_t lddx, int32_t accumulate, int32_t tile, void* stream);
+/* Both gradients of y = x W^T in one call: dW[N,K] (+)= dh^T X and dX[R,K] (+)= dh W, dh = dy (h == coefs == NULL) or
+ * the BatchNorm/activation backward of (dy, h) formed in the operand loaders (coefs: dc_bn_act_backward_reduce).  Same
+ * results, bit for bit, as dc_gemm_tn / dc_linear_bn_backward_weight followed by dc_linear_[bn_]backward_input; the
+ * ordered slab reduction of dW runs as the tail workgroups of the dX launch (one launch less per layer).  Replaces the
+ * autograd of nn.Linear inside the reference's MLP blocks (nn/mlp.py:9-16).  Workspace: dc_gemm_tn_workspace_bytes(R, N, K). */
+int dc_linear_backward_pair(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs, float slope,
+                            const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t R, int32_t N, int32_t K,
+                            float* dW, int64_t lddw, int32_t accumulate_w, float* dX, int64_t lddx, int32_t accumulate_x,
+                            void* workspace, size_t workspace_bytes, void* stream);
 int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
                                  float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K, float* dW,
                                  int64_t lddw, int32_t accumulate, void* workspace, size_t workspace_bytes,

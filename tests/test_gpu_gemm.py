@@ -234,3 +234,34 @@ def test_split_products_no_worse_than_exact_chain(M, N, K, binades):
         assert e_split < _tol(K if name != "dw" else M), name
         assert torch.equal(split[name], again[name]), name
     assert not torch.equal(split["fwd"], exact["fwd"])            # 128-column tiles: the split path ran
+
+
+@pytest.mark.parametrize("R,N,K", [(32768, 128, 256), (32768, 1024, 448), (16384, 64, 64), (9000, 40, 70), (8192, 256, 12)])
+@pytest.mark.parametrize("bn", [False, True])
+@pytest.mark.parametrize("acc", [0, 1])
+def test_backward_pair_equals_separate_products(R, N, K, bn, acc):
+    """dc_linear_backward_pair (weight-gradient slab reduction as tail workgroups of the input-gradient launch) returns the
+    bits of the two separate entry points: plain and BatchNorm-prologue forms, accumulate on / off, ragged shapes."""
+    g = torch.Generator().manual_seed(R + N + K)
+    dy, x = torch.randn(R, N, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
+    w = torch.randn(N, K, generator=g).to(DEV)
+    h = torch.randn(R, N, generator=g).to(DEV) if bn else None
+    coefs = torch.randn(5 * N, generator=g).to(DEV) if bn else None
+    slope = 0.2
+    nb = lib.raw("dc_gemm_tn_workspace_bytes")(R, N, K)
+    ws = torch.empty((nb + 3) // 4, device=DEV)
+    base_w, base_x = torch.randn(N, K, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
+    dW1, dX1 = base_w.clone(), base_x.clone()
+    if bn:
+        lib.call("dc_linear_bn_backward_weight", dy, N, h, N, coefs, slope, x, K, R, N, K, dW1, K, acc, ws, ws.numel() * 4)
+        lib.call("dc_linear_bn_backward_input", dy, N, h, N, coefs, slope, w, K, R, N, K, dX1, K, acc, 0)
+    else:
+        lib.call("dc_gemm_tn", dy, N, x, K, R, N, K, dW1, K, acc, ws, ws.numel() * 4)
+        lib.call("dc_linear_backward_input", dy, N, w, K, R, N, K, dX1, K, acc, 0)
+    dW2, dX2 = base_w.clone(), base_x.clone()
+    lib.call("dc_linear_backward_pair", dy, N, h, N if bn else 0, coefs, slope, x, K, w, K, R, N, K, dW2, K, acc, dX2, K, acc,
+             ws, ws.numel() * 4)
+    assert torch.equal(dW1, dW2) and torch.equal(dX1, dX2)
+    ref_w = (dy.double().t() @ x.double()) if not bn else None
+    if ref_w is not None and not acc:
+        assert rel_err(dW2, ref_w) < _tol(R)
