@@ -146,3 +146,50 @@ def test_sync_bn_whole_model_matches_single_process():
         if "running" in n:
             assert torch.allclose(res[0][3][n], b, atol=1e-5, rtol=1e-4), n
             assert torch.equal(res[0][3][n], res[1][3][n]), n           # replicas stay identical
+
+
+def _rows_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deltaconv_amd import dp
+    from deltaconv_amd.nn import fused
+    bn = torch.nn.BatchNorm1d(8).train()
+    res = {}
+
+    def refused(rows):
+        try:
+            fused.check_bn_rows(bn, rows)
+            return False
+        except ValueError:
+            return True
+    res["per_rank_one_row"] = refused(1)                    # per-rank statistics: a single row has no variance
+    dp.set_sync_bn(True)
+    res["sync_one_row"] = refused(1)                        # global statistics over 2 ranks: allowed
+    res["sync_two_rows"] = refused(2)
+    dp.set_sync_bn(False)
+    res["off_again"] = refused(1)
+    bn.eval()
+    res["eval_one_row"] = refused(1)                        # running statistics: any row count
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_check_bn_rows_under_synchronised_statistics():
+    """ADVICE (round 2, medium): one row per rank is legal when BatchNorm statistics span the ranks (the categorical head
+    of the segmentation net with one cloud per rank), and still refused with per-rank statistics, as the reference's
+    functional.batch_norm does (deltaconv/nn/nonlin.py:29-30)."""
+    world, port = 2, 29561
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r] == {"per_rank_one_row": True, "sync_one_row": False, "sync_two_rows": False, "off_again": True,
+                          "eval_one_row": False}, res[r]

@@ -14,5 +14,6 @@ cd $GRAFT_REPO_ROOT
 python tools/prof_summary.py $OUT/prof > $OUT/kernel_summary.txt 2>&1
 python tools/step_timeline.py $OUT/prof > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt
 find $OUT/prof -name "*.csv" -size +20M -delete
-bash tools/pmc_apply.sh $TAG/pmc_apply > $OUT/pmc_apply_summary.txt 2>&1; grep -c . $OUT/pmc_apply_summary.txt
+PMC_CFGS="${PMC_CFGS:-c2 c2gather}" bash tools/pmc_apply.sh $TAG/pmc_apply > $OUT/pmc_apply_summary.txt 2>&1; grep -c . $OUT/pmc_apply_summary.txt
 python tools/bench_configs.py --steps 20 2>&1 | grep -v amdgpu | tee $OUT/configs.txt
+bash tools/gpu_x3_pmc.sh $TAG/x3pmc > $OUT/x3pmc_summary.txt 2>&1; grep -c gemm_kernel $OUT/x3pmc_summary.txt

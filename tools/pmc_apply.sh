@@ -12,8 +12,10 @@ run() {  # name, counters..., then -- driver args
   echo "$name rc=$?"; python $GRAFT_REPO_ROOT/tools/pmc_summary.py $OUT/$name | tee $OUT/$name.summary.txt
   find $OUT/$name -name "*.csv" -size +5M -delete
 }
+# PMC_CFGS="c2" limits the passes to the graded size through the tiled kernels (the `traffic` figure of the bench line)
 for cfg in "c2 --batch 32" "c2gather --batch 32 --gather" "big --batch 512 --iters 5" "biggather --batch 512 --iters 5 --gather"; do
   set -- $cfg; tag=$1; shift
+  if [ -n "$PMC_CFGS" ] && [[ " $PMC_CFGS " != *" $tag "* ]]; then continue; fi
   run ${tag}_fetch FETCH_SIZE -- "$@"
   run ${tag}_write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- "$@"
   run ${tag}_sq SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM -- "$@"

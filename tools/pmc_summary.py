@@ -13,10 +13,10 @@ if not files:
 acc = defaultdict(lambda: defaultdict(list))
 for row in csv.DictReader(open(files[0])):
     name = row.get("Kernel_Name", "")
-    if "fwd_kernel" not in name and "_T_kernel" not in name:
+    if "fwd_kernel" not in name and "_T_kernel" not in name and "tile_unit_kernel" not in name:
         continue
     import re
-    m = re.search(r"tile_fwd_kernel<\d+, \d+, dctile::(\w+)", name)
+    m = re.search(r"tile_(?:fwd|unit)_kernel<\d+, \d+, dctile::(\w+)", name)
     short = ("tile_" + m.group(1)) if m else name.split("(")[0].split("::")[-1]
     acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kname, ctrs in acc.items():
