@@ -840,7 +840,9 @@ void launch_tile(const GemmP& p, Tile t, long tiles_m, int slabs, hipStream_t s)
 // shapes always run it.
 template <int AL, int BL, int EPI, int PRO = 0>
 void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, int mode, hipStream_t s) {
-    const bool split = mode == 0 && dc_option(DC_OPT_GEMM_EXACT) == 0 && t.bn == 128 && (AL == A_MK || t.bm == 128);
+    // (DC_OPT_GEMM_EXACT = 2, lab: split on every unguarded tile)
+    const bool split = mode == 0 && (dc_option(DC_OPT_GEMM_EXACT) == 2 ||
+                                     (dc_option(DC_OPT_GEMM_EXACT) == 0 && t.bn == 128 && (AL == A_MK || t.bm == 128)));
     if (split) launch_tile<AL, BL, 0, EPI, PRO, (PRO ? DC_X3_PRO : DC_X3_PLAIN)>(p, t, tiles_m, slabs, s);
     else if (mode == 0) launch_tile<AL, BL, 0, EPI, PRO>(p, t, tiles_m, slabs, s);
     else if (mode == 1) launch_tile<AL, BL, 1, EPI, PRO>(p, t, tiles_m, slabs, s);
@@ -948,7 +950,9 @@ DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     // r02r sweep (profiles/r02r_tn_sweep.txt): outputs below 64K elements run best on 64 x 64 tiles (more workgroups
     // per slab, shorter epilogues; 4 fit a CU) with ~768 workgroups; larger ones on 128 x 128 tiles with at most 512
     // workgroups = ONE resident wave of 2 per CU (576 cost +25 %: a second, nearly empty round); <= 128 slabs
-    const bool small = (long)M * N < 65536;
+    // (r03 lab, profiles/r03_tn_x3_lab.txt: with the split products a 128 x 256 / 256 x 128 / 128 x 384 output runs 10-13 % faster on
+    // 128 x 128 tiles than on 64 x 64 ones -- the bound between the two plans moved from 64K to 32K outputs)
+    const bool small = (long)M * N < 32768;
     pl.bm = (M > 64 && !small) ? 128 : 64;
     pl.bn = (N > 64 && !small) ? 128 : 64;
     if (M % pl.bm != 0 && M % 64 == 0) pl.bm = 64;        // a tile that divides the output runs the unguarded loads
