@@ -39,7 +39,8 @@ const char* dc_last_error(void);
  * direct-load kernel; 3: value 1 = dense products through the exact fp32 MFMA chain (bitwise an fmaf chain) instead of
  * the bf16 split products (three bf16 planes per fp32 operand, six partial products, fp32 accumulation: error against
  * fp64 no larger than the chain's); 4: first-round phase shift of every second 128 x 128 GEMM workgroup of a CU in
- * percent of a K loop (0 = default 50, negative = off); 5 / 6: force the weight-gradient tile (1..4) / slab count. */
+ * percent of a K loop (0 = default 50, negative = off); 5 / 6: force the weight-gradient tile (1..4) / slab count;
+ * 7: units (tile x 64-channel slab) per workgroup of the persistent two-piece tiled applies (0 = launcher's choice). */
 int dc_set_option(int32_t key, int32_t value);
 
 /* ---- graph ------------------------------------------------------------------------------- */
