@@ -67,8 +67,12 @@ __device__ __forceinline__ void touch(Planes& p) {
 }
 // MODE: 0 = MFMAs only; 1 = split only; 2 = split, then MFMAs (serial); 3 = interleaved (one fragment's split behind every 6 MFMAs,
 // pinned 1 MFMA : 6 VALU); 4 = interleaved, scheduler's own order (no pinning)
+// MODE 5 / 6 (second lab): the same k-step WITH its LDS traffic.  5 = the shipped structure: 8 ds_read_b128 refill the fp32 fragments,
+// 144 split instructions, 4 ds_write_b128 stage the next tile;  6 = split once per workgroup at staging time: 72 split instructions on
+// the thread's 16 staged elements, 12 ds_write_b64 of planes, 12 ds_read_b128 of plane fragments, no split in the fragment path.
 template <int MODE, int SPLIT>
 __global__ __launch_bounds__(256, 2) void lab(const float* in, float* out, int iters, long long* cyc) {
+    __shared__ __attribute__((aligned(16))) float lds[16384];
     float raw[4][8];
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -102,6 +106,45 @@ __global__ __launch_bounds__(256, 2) void lab(const float* in, float* out, int i
             } else if (MODE == 1) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f) { touch(raw[f]); split8<SPLIT>(raw[f], n[f]); touch(n[f]); }
+            } else if (MODE == 5) {
+                float* base = lds + (threadIdx.x & 255) * 4 + half * 4096;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+#pragma unroll
+                    for (int g = 6 * f; g < 6 * f + 6; ++g) mf(g, c);
+                    split8<SPLIT>(raw[f], n[f]);
+                    const float4 a = *reinterpret_cast<const float4*>(base + f * 1024), b = *reinterpret_cast<const float4*>(base + f * 1024 + 2048);
+                    raw[f][0] = a.x; raw[f][1] = a.y; raw[f][2] = a.z; raw[f][3] = a.w;
+                    raw[f][4] = b.x; raw[f][5] = b.y; raw[f][6] = b.z; raw[f][7] = b.w;
+                    *reinterpret_cast<float4*>(base + f * 1024 + 1024 * (half ^ 1)) = float4{raw[f][0], raw[f][1], raw[f][2], raw[f][3]};
+                }
+#pragma unroll
+                for (int g = 0; g < 24; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                }
+            } else if (MODE == 6) {
+                float* base = lds + (threadIdx.x & 255) * 4 + half * 4096;
+                // staging: this thread's 16 elements of the next stage -> planes -> LDS (12 ds_write_b64)
+                Planes st[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+#pragma unroll
+                    for (int g = 12 * f; g < 12 * f + 12; ++g) mf(g, c);
+                    touch(raw[f]);
+                    split8<SPLIT>(raw[f], st[f]);
+                    unsigned long long* w = reinterpret_cast<unsigned long long*>(base + f * 1024);
+                    w[0] = ((unsigned long long)st[f].h[1] << 32) | st[f].h[0];   w[256] = ((unsigned long long)st[f].h[3] << 32) | st[f].h[2];
+                    w[512] = ((unsigned long long)st[f].m[1] << 32) | st[f].m[0]; w[768] = ((unsigned long long)st[f].m[3] << 32) | st[f].m[2];
+                    w[1024] = ((unsigned long long)st[f].l[1] << 32) | st[f].l[0]; w[1280] = ((unsigned long long)st[f].l[3] << 32) | st[f].l[2];
+                }
+                // fragments of the next k-step: 4 fragments x 3 planes, one ds_read_b128 each
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const u32x4 h = *reinterpret_cast<const u32x4*>(base + f * 768), m = *reinterpret_cast<const u32x4*>(base + f * 768 + 256),
+                                l = *reinterpret_cast<const u32x4*>(base + f * 768 + 512);
+                    n[f].h = h; n[f].m = m; n[f].l = l;
+                }
             } else if (MODE == 2) {
 #pragma unroll
                 for (int f = 0; f < 4; ++f) { touch(raw[f]); split8<SPLIT>(raw[f], n[f]); }
@@ -176,6 +219,8 @@ int main() {
         run<4, 0>("interleaved free: RNE/compiler", in, out, cyc, w);
         run<4, 1>("interleaved free: RNE/plain", in, out, cyc, w);
         run<4, 2>("interleaved free: truncated/plain", in, out, cyc, w);
+        run<5, 0>("k-step + LDS, shipped structure", in, out, cyc, w);
+        run<6, 0>("k-step + LDS, split at staging", in, out, cyc, w);
     }
     return 0;
 }
