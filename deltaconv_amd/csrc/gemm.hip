@@ -52,6 +52,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifndef DC_X3_PRO
 #define DC_X3_PRO 1            // ... of the BatchNorm-backward prologue variants (no registers for a second plane set)
 #endif
+#ifdef DC_LAB_STAMPS
+__device__ unsigned long long dc_lab_stamps[8192 * 8];
+#define DC_STAMP(n) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) dc_lab_stamps[blockIdx.x * 8 + (n)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DC_STAMP(n) do { } while (0)
+#endif
 constexpr int BK = 32;         // reduction tile
 constexpr int LDK = BK + 4;    // row stride (floats) of a k-contiguous operand tile in LDS
 constexpr int NT = 256;        // threads per workgroup (4 waves, 2 x 2)
@@ -232,6 +238,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     // other's K loop for the rest of the launch.
     // (the FIRST red_blocks workgroups of the grid, a multiple of 8: dispatched before the products, their few microseconds
     // disappear in the first of the product's rounds; as the last workgroups they were a round of their own behind it)
+    DC_STAMP(0);
     const unsigned gemm_blocks = gridDim.x - (unsigned)p.red_blocks;
     if (blockIdx.x < (unsigned)p.red_blocks) {       // side job (block-uniform)
         tail_reduce(p, (long)blockIdx.x, smem);
@@ -378,6 +385,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[i][t], rb[jn][t], acc[i][jn], 0, 0, 0);
     };
 
+    DC_STAMP(1);
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, STG - 1>;
@@ -518,6 +526,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
                 for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + 2 * BK, S0{});
             }
             lds_barrier();
+            DC_STAMP(7);
             read_raw(0, 0);
             split_all();
             read_raw(0, 1);
@@ -680,6 +689,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
         }
     }
     }   // exact / split loop
+    DC_STAMP(2);
     __syncthreads();                  // (the staging below reuses the operand buffers)
 
     // ---- statistics epilogue (rows beyond M hold zeros and add nothing)
@@ -742,6 +752,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
         __syncthreads();   // sst is about to be overwritten by the output staging
     }
 
+    DC_STAMP(3);
     // ---- store: each wave transposes its WM x WN tile through LDS and writes whole rows, 16 bytes per lane.
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (q & 3) + 8 (q >> 2) + 4 (lane >> 5).  The staging row
     // stride is exactly WN floats: the ds_read_b128 lane groups then cover all 16 slots of a 256-byte bank row.
@@ -784,6 +795,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
             }
         }
     }
+    DC_STAMP(4);
+#ifdef DC_LAB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DC_STAMP(5);
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 8192) dc_lab_stamps[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((16 << 11) | 4);
+#endif
 }
 
 struct Tile { int bm, bn; };
@@ -1131,3 +1148,11 @@ DC_EXPORT int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const floa
     DC_CHECK_LAUNCH("dc_linear_vn_stats_forward");
     return DC_OK;
 }
+
+#ifdef DC_LAB_STAMPS
+// (lab build only) copies the phase stamps of the last launches to the host: [8192][8] = entry, first-loads issued?, K loop done,
+// statistics done, stores issued, stores complete, HW_ID
+DC_EXPORT int dc_lab_read_stamps(unsigned long long* host, int32_t n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(dc_lab_stamps), (size_t)n_words * 8) == hipSuccess ? DC_OK : DC_ERR_LAUNCH;
+}
+#endif
