@@ -490,7 +490,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
             };
             // one k-step: multiply the planes (ca, cb); cut the fragments in flight into (na, nb); refill them from
             // (rbuf, rks) -- unconditionally: past the last tile they read stale LDS and nothing consumes the result
-            auto step = [&](const Planes (&ca)[TM], const Planes (&cb)[TN], Planes (&na)[TM], Planes (&nb)[TN], int rbuf, int rks) {
+            // `stage(f)`: the share of fragment group f in moving the operand ring on (LDS stores of tile kt+2, global loads of
+            // tile kt+3): issued between the MFMAs of the k-step instead of in a burst behind it, where the matrix pipe idled
+            auto step = [&](const Planes (&ca)[TM], const Planes (&cb)[TN], Planes (&na)[TM], Planes (&nb)[TN], int rbuf, int rks,
+                            auto stage) {
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
 #pragma unroll
@@ -504,11 +507,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
                     if (f < TM) split8(qa[f][0], qa[f][1], na[f]);
                     else split8(qb[f - TM][0], qb[f - TM][1], nb[f - TM]);
                     read_frag(f, rbuf, rks);
+                    stage(f);
                 }
 #pragma unroll
-                for (int g = 0; g < NM; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);     // its share of the split
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int g = 0; g < NM / NF; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0); // its share of the split
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x200, (NST + NF - 1) / NF, 0);     // LDS stores of the group
+                    __builtin_amdgcn_sched_group_barrier(0x020, (NLD + NF - 1) / NF, 0);     // global loads of the group
                 }
             };
 #pragma unroll
@@ -532,19 +541,36 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
             read_raw(0, 1);
             for (int kt = 0; kt < nk; ++kt) {
                 const int cur = kt & 1;
-                __builtin_amdgcn_sched_barrier(0);
-                step(pa, pb, pa1, pb1, cur ^ 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                step(pa1, pb1, pa, pb, cur ^ 1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (kt + 2 < nk) {
+                // (unconditional: past the last tiles the stores refill a buffer nobody reads again and the loads re-read the last
+                // tile -- no branches inside the pinned instruction stream)
+                const long k3 = kbeg + (long)min(kt + 3, nk - 1) * BK;
+                auto none = [&](int) {};
+                auto stores_loads = [&](int f) {                           // (piece n is stored before its registers are reloaded)
 #pragma unroll
-                    for (int n = 0; n < NST; ++n) store_piece(n, cur, S0{});
-                }
-                if (kt + 3 < nk) {
+                    for (int n = f * NST / NF; n < (f + 1) * NST / NF; ++n) store_piece(n, cur, S0{});
 #pragma unroll
-                    for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + (long)(kt + 3) * BK, S0{});
+                    for (int n = f * NLD / NF; n < (f + 1) * NLD / NF; ++n) load_piece(n, k3, S0{});
+                };
+                // (the weight gradient's reduction-major form spills with the pieces inside the stream: it keeps the burst behind it)
+                constexpr bool INSIDE = AL == A_MK;
+                __builtin_amdgcn_sched_barrier(0);
+                step(pa, pb, pa1, pb1, cur ^ 1, 0, none);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (INSIDE) {
+                    step(pa1, pb1, pa, pb, cur ^ 1, 1, stores_loads);
+                } else {
+                    step(pa1, pb1, pa, pb, cur ^ 1, 1, none);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (kt + 2 < nk) {
+#pragma unroll
+                        for (int n = 0; n < NST; ++n) store_piece(n, cur, S0{});
+                    }
+                    if (kt + 3 < nk) {
+#pragma unroll
+                        for (int n = 0; n < NLD; ++n) load_piece(n, kbeg + (long)(kt + 3) * BK, S0{});
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 lds_barrier();
             }
         } else {
