@@ -149,6 +149,47 @@ __global__ __launch_bounds__(64 * RED_WAVES) void gemm_tn_reduce_kernel(const fl
     }
 }
 
+// At most 16 slabs: every chain of the kernel above holds at most one slab, its result is the plain ordered sum over the slabs
+// starting from 0.f -- the same bits from a streaming form: thread = 4 consecutive elements (16-byte loads, all slabs of a thread
+// in flight), no LDS, no idle waves (the 1024 x 448 embedding gradient has 9 slabs: 7 of the 16 waves above had nothing to do,
+// 20 -> ~6 us).  mn, N and ldc multiples of 4, 16-byte aligned bases.
+__global__ __launch_bounds__(256) void gemm_tn_reduce_few_kernel(const float* __restrict__ partial, int slabs, long mn, int N,
+                                                                 float* __restrict__ C, long ldc, int accumulate) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= mn) return;
+    float v[16][4];
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl)
+        if (sl < slabs) {
+            const float4 q = *reinterpret_cast<const float4*>(partial + (long)sl * mn + e);
+            v[sl][0] = q.x; v[sl][1] = q.y; v[sl][2] = q.z; v[sl][3] = q.w;
+        }
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl)
+        if (sl < slabs)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] += (0.f + v[sl][j]);          // (chain q: 0.f + p_q, then the chains in order)
+    float* dst = C + (e / N) * ldc + (e % N);
+    float4 o = {t[0], t[1], t[2], t[3]};
+    if (accumulate) {
+        const float4 d = *reinterpret_cast<const float4*>(dst);
+        o.x = d.x + o.x; o.y = d.y + o.y; o.z = d.z + o.z; o.w = d.w + o.w;
+    }
+    *reinterpret_cast<float4*>(dst) = o;
+}
+// the ordered slab reduction: streaming form where it applies, else the 16-chain form
+static void launch_tn_reduce(const float* partial, int slabs, long mn, int N, float* C, long ldc, int accumulate, hipStream_t s) {
+    const bool few = slabs <= 16 && mn % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(partial) & 15) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+                     dc_option(DC_OPT_TN_LDS) != 3;            // (option 2 = 3, lab: always the 16-chain form)
+    if (few)
+        hipLaunchKernelGGL(gemm_tn_reduce_few_kernel, dim3(dc_cdiv(mn / 4, 256)), dim3(256), 0, s, partial, slabs, mn, N, C, ldc, accumulate);
+    else
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 64)), dim3(64 * RED_WAVES), 0, s, partial, slabs, mn, N, C, ldc,
+                           accumulate);
+}
+
 struct Plan {
     int wm, wn, tiles_m, tiles_n, slabs, rows_per_slab;
 };
@@ -202,8 +243,7 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     if (!direct) {
         const int slabs = dc_tn_lds_launch(A, (long)lda, B, (long)ldb, (long)R, M, N, partial, s);
         const long mn2 = (long)M * N;
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn2, 64)), dim3(64 * RED_WAVES), 0, s, partial, slabs, mn2, N,
-                           C, (long)ldc, accumulate);
+        launch_tn_reduce(partial, slabs, mn2, N, C, (long)ldc, accumulate, s);
         DC_CHECK_LAUNCH("dc_gemm_tn");
         return DC_OK;
     }
@@ -217,8 +257,7 @@ DC_EXPORT int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ld
     else if (p.wn == 2) DC_TN_LAUNCH(1, 2);
     else DC_TN_LAUNCH(1, 1);
     const long mn = (long)M * N;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 64)), dim3(64 * RED_WAVES), 0, s, partial, p.slabs, mn, N, C,
-                       (long)ldc, accumulate);
+    launch_tn_reduce(partial, p.slabs, mn, N, C, (long)ldc, accumulate, s);
     DC_CHECK_LAUNCH("dc_gemm_tn");
     return DC_OK;
 }
@@ -243,8 +282,7 @@ DC_EXPORT int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const 
     float* partial = static_cast<float*>(workspace);
     const int slabs = dc_tn_lds_launch(dy, (long)lddy, X, (long)ldx, (long)R, N, K, partial, s, h, (long)ldh, coefs, slope);
     const long mn = (long)N * K;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3(dc_cdiv(mn, 64)), dim3(64 * RED_WAVES), 0, s, partial, slabs, mn, K, dW,
-                       (long)lddw, accumulate);
+    launch_tn_reduce(partial, slabs, mn, K, dW, (long)lddw, accumulate, s);
     DC_CHECK_LAUNCH("dc_linear_bn_backward_weight");
     return DC_OK;
 }
