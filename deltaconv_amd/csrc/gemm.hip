@@ -1,4 +1,10 @@
-// Dense per-point GEMMs of the scalar / vector MLP stream on the fp32 matrix cores, LDS-staged.
+// Dense per-point GEMMs of the scalar / vector MLP stream on the matrix cores, LDS-staged.  fp32 tensors in and out, fp32
+// accumulation; two multiply paths over the same tiles, staging, prologues and epilogues:
+//   * split products (X3, the default on whole 128-column tiles): every fp32 fragment is cut in registers into three bfloat16
+//     planes and each accumulator gets six v_mfma_f32_32x32x16_bf16 per 16-deep k-step -- error against fp64 at or below the
+//     exact chain's, 1.24-1.31 x its speed (comment at split_pair / the X3 loop below);
+//   * the exact chain described next (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain): ragged shapes, 64-column tiles,
+//     option DC_OPT_GEMM_EXACT.
 //
 //   forward          Y[M,N]  = X[M,K] W[N,K]^T          (every Linear(no bias): /root/reference/deltaconv/nn/mlp.py:9,15)
 //   input gradient   dX[M,K] (+)= dY[M,N] W[N,K]        (ATen mm in the autograd of the same lines)
@@ -33,8 +39,9 @@
 // partial per (column, row tile); the ordered final stage of colreduce.h turns them into scale / shift.  The
 // separate statistics pass over the [M, N] output (one full read) disappears.  Deterministic: fixed order.
 //
-// Bound: MFMA (157 TFLOP/s fp32).  Per 32-deep K tile a 128 x 128 workgroup issues 64 MFMAs per wave (4096
-// cycles) against 32 KB of global loads (8 B/clk/CU) and 16 ds_read_b128 per wave.
+// Bound: MFMA.  Exact chain: 157 TFLOP/s fp32; per 32-deep K tile a 128 x 128 workgroup issues 64 MFMAs per wave (4096
+// cycles) against 32 KB of global loads (8 B/clk/CU) and 16 ds_read_b128 per wave.  Split products: 48 bf16 MFMAs per wave
+// (1536 cycles of a 2.5 PFLOP/s pipe that runs power-limited at ~1.65 GHz) + 288 split instructions on the VALU.
 #include <algorithm>
 #include <type_traits>
 #include "common.h"
