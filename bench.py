@@ -65,7 +65,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
     arg = torch.empty(n, C, dtype=torch.uint8, device=dev)
     # the product's dispatch (deltaconv_amd/_ops.py): from the graph's tile plan (neighbour rows in LDS, csrc/ell_tile.h)
     # when it applies, else through the gather path
-    cases = {
+    cases_F = {
         "div_curl_norm": (lambda: _ops.fwd_apply("div_curl_norm", div, v, C, C, y3, 3 * C), 20 * C * n + 12 * E),
         "grad": (lambda: _ops.fwd_apply("grad", grad, x, C, C, y2, C), 12 * C * n + 12 * E),
         "div": (lambda: _ops.fwd_apply("div", div, v, C, C, y1, C), 12 * C * n + 12 * E),
@@ -73,19 +73,33 @@ def apply_roofline(graph, grad, div, C, iters=200):
         "knn_max": (lambda: _ops.fwd_knn_max(graph, x, C, C, y1, C, arg), 9 * C * n + 4 * E),
     }
 
-    def measure(passes=2):
+    # backward half of the operator (round 4): the transposed applies and the max-aggregation backward with the operand
+    # layouts of the layer node (accumulating outputs are read once more): from the transposed tile plan
+    # (csrc/ell_tileT.h) when the graph has one, else over the CSC through the gather path
+    dyv, a1 = torch.randn(2 * n, C, device=dev), torch.randn(n, C, device=dev)
+    o1, o2c, dvv = torch.empty(n, C, device=dev), torch.zeros(n, 2 * C, device=dev), torch.zeros(2 * n, C, device=dev)
+    argr = torch.randint(0, k, (n, C), device=dev).to(torch.uint8)
+    cases_T = {
+        "div_curl_norm_T": (lambda: _ops.bwd_div_curl_norm(div, dcn, C, 3 * C, v, C, dvv, C, 1), 36 * C * n + 12 * E),
+        "hodge_T": (lambda: _ops.bwd_apply("hodge", grad, dyv, C, C, o2c, 2 * C, 1), 24 * C * n + 12 * E),
+        "grad_T_sum": (lambda: _ops.bwd_grad_sum(grad, dyv, C, C, a1, C, None, 0, o1, C), 16 * C * n + 12 * E),
+        "knn_max_bwd": (lambda: _ops.bwd_knn_max(graph, argr, x, C, C, o1, C, 0), 9 * C * n + 4 * E),
+    }
+
+    def measure(passes=2, cases=None):
+        cases = cases or cases_F
         # two passes over the family, the second one reported: the first replay series of a case in a process runs
         # 1 - 1.5 us slower than every later one (r03 lab, tools/tile_upw.py: 14.6 then 13.1 x 7 for the fused apply --
         # fresh allocations / cold translation caches), and the training step launches these kernels every iteration
         out = {}
         for rep in range(passes):
             first = {k_: v_["us"] for k_, v_ in out.items()}
-            _measure_pass(out)
+            _measure_pass(out, cases)
         for k_ in out:
             out[k_]["first_pass_us"] = first.get(k_)
         return out
 
-    def _measure_pass(out):
+    def _measure_pass(out, cases):
         for name, (fn, nbytes) in cases.items():
             for _ in range(10):
                 fn()
@@ -116,6 +130,16 @@ def apply_roofline(graph, grad, div, C, iters=200):
         plan, graph._tile_plan = graph._tile_plan, False
         fam_gather = measure()
         graph._tile_plan = plan
+    tiled_T = graph.tile_plan_T() is not None
+    if tiled_T:
+        grad.coefTt(), div.coefTt()
+    graph.csc(), grad.coefT(), div.coefT()
+    fam_T = measure(cases=cases_T)
+    fam_T_gather = None
+    if tiled_T:
+        plan_T, graph._tile_plan_T = graph._tile_plan_T, False
+        fam_T_gather = measure(cases=cases_T)
+        graph._tile_plan_T = plan_T
     # the hand-written fp32-MFMA GEMMs (csrc/gemm.hip, gemm_tn.hip): forward product of the embedding MLP with the
     # BatchNorm-statistics epilogue (the largest GEMM of the step) and the layer-2 v_mlp weight gradient
     def _time(fn, it=30):
@@ -187,6 +211,10 @@ def apply_roofline(graph, grad, div, C, iters=200):
                         "from the per-batch tile plan)" if tiled else
                         "divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)"), channels=C,
                 bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam, family_gather_path=fam_gather,
+                family_T=fam_T, family_T_gather_path=fam_T_gather,
+                family_T_note=("backward half: transposed applies + max-aggregation backward at the layer node's operand layouts "
+                               "(accumulating outputs counted read + written), " +
+                               ("tileT_kernel from the transposed tile plan (source rows in LDS)" if tiled_T else "gather path over the CSC")),
                 mfma=mfma)
 
 

@@ -51,6 +51,60 @@ def fwd_knn_max(g, h, c, ldh, out, ldo, arg, affine=None):
         lib.call("dc_knn_max_affine", g.nbr, g.n, g.k, h, c, ldh, affine[0], affine[1], affine[2], out, ldo, arg)
 
 
+# ---- transposed applies / max-aggregation backward: from the graph's transposed tile plan when it applies (source rows in
+# LDS, csrc/ell_tileT.h), else over the CSC through the gather path.  Same results bit for bit.
+def _tiledT(graph, c, *tensors_lds):
+    if c <= 0 or c % 64:
+        return None
+    for t, ld in tensors_lds:
+        if t is not None and (ld % 4 or t.data_ptr() % 16):
+            return None
+    return graph.tile_plan_T()
+
+
+def bwd_apply(name, op, dy, c, ldy, out, ldo, accumulate):
+    """name in {'grad', 'div', 'hodge'}: dc_apply_<name>_T[_tiled](op^T, dy[., c]) (+)-> out."""
+    g = op.graph
+    plan = _tiledT(g, c, (dy, ldy), (out, ldo))
+    if plan is not None:
+        lib.call(f"dc_apply_{name}_T_tiled", op.coefTt(), plan.blob, *plan.args, dy, c, ldy, out, ldo, int(accumulate))
+    else:
+        tptr, tedge = g.csc()
+        lib.call(f"dc_apply_{name}_T", op.coefT(), tptr, tedge, g.n, g.k, dy, c, ldy, out, ldo, int(accumulate))
+
+
+def bwd_grad_sum(op, dy, c, ldy, a, lda, b, ldb, out, ldo):
+    """out = a (+ b) + grad^T dy (dc_apply_grad_T_sum[_tiled])."""
+    g = op.graph
+    plan = _tiledT(g, c, (dy, ldy), (a, lda), (b, ldb), (out, ldo))
+    if plan is not None:
+        lib.call("dc_apply_grad_T_sum_tiled", op.coefTt(), plan.blob, *plan.args, dy, c, ldy, a, lda, b, ldb, out, ldo)
+    else:
+        tptr, tedge = g.csc()
+        lib.call("dc_apply_grad_T_sum", op.coefT(), tptr, tedge, g.n, g.k, dy, c, ldy, a, lda, b, ldb, out, ldo)
+
+
+def bwd_div_curl_norm(op, dout, c, ldo, v, ldv, dv, lddv, accumulate):
+    g = op.graph
+    plan = _tiledT(g, c, (dout, ldo), (v, ldv), (dv, lddv))
+    if plan is not None:
+        lib.call("dc_apply_div_curl_norm_T_tiled", op.coefTt(), plan.blob, *plan.args, dout, c, ldo, v, ldv, dv, lddv,
+                 int(accumulate))
+    else:
+        tptr, tedge = g.csc()
+        lib.call("dc_apply_div_curl_norm_T", op.coefT(), tptr, tedge, g.n, g.k, dout, c, ldo, v, ldv, dv, lddv,
+                 int(accumulate))
+
+
+def bwd_knn_max(g, arg, dout, c, ldo, dh, ldh, accumulate=0):
+    plan = _tiledT(g, c, (dout, ldo), (dh, ldh), (arg, 4))
+    if plan is not None:
+        lib.call("dc_knn_max_backward_tiled", plan.blob, *plan.args, arg, dout, c, ldo, dh, ldh, int(accumulate))
+    else:
+        tptr, tedge = g.csc()
+        lib.call("dc_knn_max_backward", tptr, tedge, g.n, g.k, arg, dout, c, ldo, dh, ldh, int(accumulate))
+
+
 class _Apply(torch.autograd.Function):
     """kind in {'grad','div'}: y = A @ x with A in ELL form."""
 
@@ -74,13 +128,12 @@ class _Apply(torch.autograd.Function):
     def backward(ctx, dy):
         dy = _f32c(dy)
         g, c = ctx.graph, dy.shape[1]
-        tptr, tedge = g.csc()
         if ctx.kind == 'grad':
             dx = torch.empty(g.n, c, dtype=torch.float32, device=dy.device)
-            lib.call("dc_apply_grad_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
+            bwd_apply("grad", ctx.op, dy, c, c, dx, c, 0)
         else:
             dx = torch.empty(2 * g.n, c, dtype=torch.float32, device=dy.device)
-            lib.call("dc_apply_div_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dy, c, c, dx, c, 0)
+            bwd_apply("div", ctx.op, dy, c, c, dx, c, 0)
         return dx, None, None, None
 
 
@@ -104,9 +157,8 @@ class _DivCurlNorm(torch.autograd.Function):
         dout = _f32c(dout)
         (v,) = ctx.saved_tensors
         g, c = ctx.graph, v.shape[1]
-        tptr, tedge = g.csc()
         dv = torch.empty_like(v)
-        lib.call("dc_apply_div_curl_norm_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dout, c, 3 * c, v, c, dv, c, 0)
+        bwd_div_curl_norm(ctx.op, dout, c, 3 * c, v, c, dv, c, 0)
         return dv, None, None
 
 
@@ -129,10 +181,9 @@ class _Hodge(torch.autograd.Function):
     def backward(ctx, dh):
         dh = _f32c(dh)
         g, c, ld = ctx.graph, ctx.c, ctx.ld
-        tptr, tedge = g.csc()
         ddcn = torch.zeros(g.n, ld, dtype=torch.float32, device=dh.device) if ld > 2 * c else \
             torch.empty(g.n, ld, dtype=torch.float32, device=dh.device)
-        lib.call("dc_apply_hodge_T", ctx.op.coefT(), tptr, tedge, g.n, g.k, dh, c, c, ddcn, ld, 0)
+        bwd_apply("hodge", ctx.op, dh, c, c, ddcn, ld, 0)
         return ddcn, None, None, None
 
 
@@ -157,9 +208,8 @@ class _KnnMax(torch.autograd.Function):
         dout = _f32c(dout)
         (arg,) = ctx.saved_tensors
         g, c = ctx.graph, dout.shape[1]
-        tptr, tedge = g.csc()
         dh = torch.empty(g.n, c, dtype=torch.float32, device=dout.device)
-        lib.call("dc_knn_max_backward", tptr, tedge, g.n, g.k, arg, dout, c, c, dh, c, 0)
+        bwd_knn_max(g, arg, dout, c, c, dh, c, 0)
         return dh, None
 
 

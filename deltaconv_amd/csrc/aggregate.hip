@@ -7,6 +7,7 @@
 #include "common.h"
 #include "ell_stage.h"
 #include "ell_tile.h"
+#include "ell_tileT.h"
 
 namespace {
 using namespace dcell;
@@ -238,5 +239,22 @@ DC_EXPORT int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, i
                       dctile::KnnMaxB<true>{h, (long)ldh, 0, scale, shift, slope, out, (long)ldo, arg, (long)C},
                       static_cast<hipStream_t>(stream));
     DC_CHECK_LAUNCH("dc_knn_max_affine_tiled");
+    return DC_OK;
+}
+
+// ---- max-aggregation backward from the transposed tile plan (ell_tileT.h): same sums in the same order, rows + slot words in LDS
+DC_EXPORT int dc_knn_max_backward_tiled(const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles, int32_t k,
+                                        int32_t P, const uint8_t* arg, const float* dout, int32_t C, int64_t ldo, float* dh,
+                                        int64_t ldh, int32_t accumulate, void* stream) {
+    DC_REQUIRE(planT && arg && dout && dh, "dc_knn_max_backward_tiled: null pointer");
+    DC_REQUIRE(n >= 0 && num_clouds >= 0 && num_tiles >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
+               "dc_knn_max_backward_tiled: bad size");
+    DC_REQUIRE(dctile::eligible(C, {(long)ldo, (long)ldh}, {dout, dh, arg}), "dc_knn_max_backward_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
+    DC_REQUIRE(ldo >= C && ldh >= C, "dc_knn_max_backward_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlanT L = dc_tile_plan_T_layout(n, num_clouds, num_tiles, k, P);
+    dctileT::launch<1>(L, planT, nullptr, C, dctileT::KnnMaxTB{dout, (long)ldo, 0, arg, (long)C, dh, (long)ldh, accumulate},
+                       static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_knn_max_backward_tiled");
     return DC_OK;
 }

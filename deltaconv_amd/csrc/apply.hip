@@ -13,6 +13,7 @@
 #include "common.h"
 #include "ell_stage.h"
 #include "ell_tile.h"
+#include "ell_tileT.h"
 
 namespace {
 using namespace dcell;
@@ -180,3 +181,106 @@ DC_TILED_ENTRY(dc_apply_grad_tiled, GradB, 1, ldi, 0, C, C)
 DC_TILED_ENTRY(dc_apply_div_tiled, DivB, 2, 2 * ldi, ldi, C, C)
 DC_TILED_ENTRY(dc_apply_div_curl_norm_tiled, DivCurlNormB, 2, 2 * ldi, ldi, C, 3 * C, , C)
 DC_TILED_ENTRY(dc_apply_hodge_tiled, HodgeB, 2, ldi, C, 2 * C, C)
+
+// ---- transposed, from the transposed tile plan (tile_plan.h second half, ell_tileT.h) ------------------------------------
+// Same results bit for bit as the entry points above (same FMAs, ascending edge id per target); the source rows come from
+// LDS.  coefTt = the operator's coefficients in TILE order (dc_tile_plan_T_permute_coef); planT from
+// dc_tile_plan_T_build.  C must be a multiple of 64 and all rows 16-byte aligned (otherwise DC_ERR_ARG: use the entry points above).
+namespace {
+int check_tiledT(const char* name, std::initializer_list<const void*> ptrs, int n, int nc, int nt, int k, int P, bool ok16, int C) {
+    for (const void* p : ptrs)
+        if (!p) {
+            dc_set_error("%s: null pointer", name);
+            return DC_ERR_ARG;
+        }
+    if (n < 0 || nc < 0 || nt < 0 || k < 2 || k % 2 || k > 64 || (P != 32 && P != 64) || P * k > 2048) {
+        dc_set_error("%s: bad size n=%d num_clouds=%d num_tiles=%d k=%d P=%d", name, n, nc, nt, k, P);
+        return DC_ERR_ARG;
+    }
+    if (!ok16) {
+        dc_set_error("%s: needs C %% 64 == 0 and 16-byte aligned rows (C=%d)", name, C);
+        return DC_ERR_ARG;
+    }
+    return DC_OK;
+}
+}  // namespace
+
+DC_EXPORT int dc_apply_grad_T_tiled(const float* GTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                                    int32_t k, int32_t P, const float* dy, int32_t C, int64_t ldy, float* dx, int64_t ldx,
+                                    int32_t accumulate, void* stream) {
+    if (int rc = check_tiledT("dc_apply_grad_T_tiled", {GTt, planT, dy, dx}, n, num_clouds, num_tiles, k, P,
+                              dctile::eligible(C, {(long)ldy, (long)ldx}, {dy, dx, GTt}), C))
+        return rc;
+    DC_REQUIRE(ldy >= C && ldx >= C, "dc_apply_grad_T_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlanT L = dc_tile_plan_T_layout(n, num_clouds, num_tiles, k, P);
+    dctileT::launch<2>(L, planT, GTt, C,
+                       dctileT::GradTB<false>{dy, 2 * (long)ldy, (long)ldy, nullptr, 0, nullptr, 0, nullptr, 0, dx, (long)ldx, accumulate},
+                       static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_apply_grad_T_tiled");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_apply_grad_T_sum_tiled(const float* GTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                                        int32_t k, int32_t P, const float* dy, int32_t C, int64_t ldy, const float* a, int64_t lda,
+                                        const float* b, int64_t ldb, float* out, int64_t ldo, void* stream) {
+    const long ldb_ = b ? (long)ldb : (long)lda;
+    if (int rc = check_tiledT("dc_apply_grad_T_sum_tiled", {GTt, planT, dy, a, out}, n, num_clouds, num_tiles, k, P,
+                              dctile::eligible(C, {(long)ldy, (long)lda, ldb_, (long)ldo}, {dy, a, b ? b : a, out, GTt}), C))
+        return rc;
+    DC_REQUIRE(ldy >= C && lda >= C && ldo >= C && (!b || ldb >= C), "dc_apply_grad_T_sum_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlanT L = dc_tile_plan_T_layout(n, num_clouds, num_tiles, k, P);
+    dctileT::launch<2>(L, planT, GTt, C,
+                       dctileT::GradTB<true>{dy, 2 * (long)ldy, (long)ldy, nullptr, 0, a, (long)lda, b, (long)ldb, out, (long)ldo, 0},
+                       static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_apply_grad_T_sum_tiled");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_apply_div_T_tiled(const float* DTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                                   int32_t k, int32_t P, const float* dy, int32_t C, int64_t ldy, float* dv, int64_t ldv,
+                                   int32_t accumulate, void* stream) {
+    if (int rc = check_tiledT("dc_apply_div_T_tiled", {DTt, planT, dy, dv}, n, num_clouds, num_tiles, k, P,
+                              dctile::eligible(C, {(long)ldy, (long)ldv}, {dy, dv, DTt}), C))
+        return rc;
+    DC_REQUIRE(ldy >= C && ldv >= C, "dc_apply_div_T_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlanT L = dc_tile_plan_T_layout(n, num_clouds, num_tiles, k, P);
+    dctileT::launch<1>(L, planT, DTt, C, dctileT::DivTB{dy, (long)ldy, 0, nullptr, 0, dv, (long)ldv, accumulate},
+                       static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_apply_div_T_tiled");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_apply_hodge_T_tiled(const float* GTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                                     int32_t k, int32_t P, const float* dh, int32_t C, int64_t ldh, float* ddc, int64_t ldd,
+                                     int32_t accumulate, void* stream) {
+    if (int rc = check_tiledT("dc_apply_hodge_T_tiled", {GTt, planT, dh, ddc}, n, num_clouds, num_tiles, k, P,
+                              dctile::eligible(C, {(long)ldh, (long)ldd}, {dh, ddc, GTt}), C))
+        return rc;
+    DC_REQUIRE(ldh >= C && ldd >= 2 * C, "dc_apply_hodge_T_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlanT L = dc_tile_plan_T_layout(n, num_clouds, num_tiles, k, P);
+    dctileT::launch<2>(L, planT, GTt, C, dctileT::HodgeTB{dh, 2 * (long)ldh, (long)ldh, nullptr, 0, ddc, (long)ldd, accumulate, C},
+                       static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_apply_hodge_T_tiled");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_apply_div_curl_norm_T_tiled(const float* DTt, const int32_t* planT, int32_t n, int32_t num_clouds,
+                                             int32_t num_tiles, int32_t k, int32_t P, const float* dout, int32_t C, int64_t ldo,
+                                             const float* v, int64_t ldv, float* dv, int64_t lddv, int32_t accumulate,
+                                             void* stream) {
+    if (int rc = check_tiledT("dc_apply_div_curl_norm_T_tiled", {DTt, planT, dout, v, dv}, n, num_clouds, num_tiles, k, P,
+                              dctile::eligible(C, {(long)ldo, (long)ldv, (long)lddv}, {dout, v, dv, DTt}), C))
+        return rc;
+    DC_REQUIRE(ldo >= 3 * C && ldv >= C && lddv >= C, "dc_apply_div_curl_norm_T_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlanT L = dc_tile_plan_T_layout(n, num_clouds, num_tiles, k, P);
+    dctileT::launch<2>(L, planT, DTt, C,
+                       dctileT::DivCurlNormTB{dout, (long)ldo, (long)C, nullptr, 0, v, (long)ldv, dv, (long)lddv, accumulate, C},
+                       static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_apply_div_curl_norm_T_tiled");
+    return DC_OK;
+}

@@ -218,6 +218,158 @@ __global__ __launch_bounds__(256) void tile_unique_kernel(const int* __restrict_
     }
 }
 
+// ---- transposed plan (tile_plan.h, second half): one workgroup per tile ---------------------------------------------
+// Inputs: the forward plan's tiles (pts) and the CSC of the graph (tptr, tedge: in-edges per point, ascending edge id).
+//   1. in-degrees of the tile's targets; rank by (degree descending, position ascending) -> lane group of every target;
+//   2. start of the tile's range: the cloud's base + the rounded lengths of the cloud's earlier tiles (recomputed by every
+//      workgroup from pts + tptr: <= 4096 cached words, no scan kernel, no atomics);
+//   3. bitmap of the sources over the cloud's local ids -> prefix popcounts -> unique list + the tile-local index of every
+//      in-edge's source (as tile_unique_kernel does for the neighbours);
+//   4. records + edge ids in (lane group, ascending edge id) order.
+__global__ __launch_bounds__(256) void tileT_build_kernel(const int* __restrict__ plan, DcTilePlan L, const int* __restrict__ tptr,
+                                                          const int* __restrict__ tedge, const int* __restrict__ cloud_ptr,
+                                                          int num_clouds, int* __restrict__ planT, DcTilePlanT LT) {
+    __shared__ int pts[64], deg[64], spt[64], sdeg[64], sbeg[64], scol[64];
+    __shared__ unsigned bm[MAX_CLOUD / 32];
+    __shared__ int pre[MAX_CLOUD / 32 + 1];
+    __shared__ int red[4];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int P = L.P, k = L.k;
+    int4* tg_g = reinterpret_cast<int4*>(planT + LT.o_tg) + (long)t * P;
+    int4* hdr_g = reinterpret_cast<int4*>(planT + LT.o_hdr) + t;
+    const int* pts_g = plan + L.o_pts + (long)t * P;
+    const int first = pts_g[0];
+    if (first < 0) {                                        // unused tile id: empty (block-uniform)
+        if (tid < P) tg_g[tid] = make_int4(-1, 0, 0, 0);
+        if (tid == 0) *hdr_g = make_int4(0, 0, 0, 0);
+        return;
+    }
+    int lo = 0, hi = num_clouds;                            // cloud of the tile
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cloud_ptr[mid] <= first) lo = mid; else hi = mid;
+    }
+    const int b = lo, base = cloud_ptr[b], N = cloud_ptr[b + 1] - base;
+    const int tile0 = block_tile_base(cloud_ptr, b, P, red);
+    const int tc = t - tile0;                               // tile index inside the cloud
+    if (tid < 64) {
+        const int j = tid < P ? pts_g[tid] : -1;
+        pts[tid] = j;
+        deg[tid] = j >= 0 ? tptr[j + 1] - tptr[j] : 0;
+    }
+    const int W = (N + 31) >> 5;
+    for (int w = tid; w < W; w += 256) bm[w] = 0u;
+    // 2. rounded lengths of the cloud's earlier tiles (segments of P lanes = one tile)
+    int part = 0;
+    for (int q0 = 0; q0 < tc * P; q0 += 256) {
+        const int q = q0 + tid;
+        int d = 0;
+        if (q < tc * P) {
+            const int j = plan[L.o_pts + (long)tile0 * P + q];
+            if (j >= 0) d = tptr[j + 1] - tptr[j];
+        }
+        for (int o = P >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if ((tid & (P - 1)) == 0) part += (d + 3) & ~3;
+    }
+    part = dc_wave_sum_i(part);
+    __syncthreads();                                        // (red of block_tile_base is free again; pts / deg / bm visible)
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const long toff = (((long)base * k + 3) & ~3L) + 4L * (tile0 + b) + red[0] + red[1] + red[2] + red[3];
+    // 1. degree order (64 x 64 compares)
+    if (tid < 64) {
+        const int d = deg[tid];
+        int r = 0;
+        for (int q = 0; q < 64; ++q) r += (deg[q] > d) || (deg[q] == d && q < tid);
+        spt[r] = pts[tid];
+        sdeg[r] = d;
+        scol[r] = pts[tid] >= 0 ? tptr[pts[tid]] : 0;
+    }
+    __syncthreads();
+    if (tid < 64) {                                         // exclusive scan of the sorted degrees (one wavefront)
+        int v = sdeg[tid];
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(v, o, 64);
+            if (tid >= o) v += u;
+        }
+        sbeg[tid] = v - sdeg[tid];
+        if (tid == 63) red[0] = v;
+    }
+    __syncthreads();
+    const int Et = red[0];
+    // 3. bitmap of the sources: four lanes per target walk its list
+    const int g = tid >> 2, sub = tid & 3;
+    {
+        const int d = sdeg[g], col = scol[g];
+        for (int r = sub; r < d; r += 4) {
+            const int j = tedge[col + r] / k - base;
+            atomicOr(&bm[j >> 5], 1u << (j & 31));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) pre[0] = 0;
+    if (tid < 128) pre[tid + 1] = tid < W ? __popc(bm[tid]) : 0;
+    __syncthreads();
+    for (int off = 1; off < 128; off <<= 1) {
+        int v = 0;
+        if (tid < 128 && tid >= off) v = pre[tid + 1 - off];
+        __syncthreads();
+        if (tid < 128 && tid >= off) pre[tid + 1] += v;
+        __syncthreads();
+    }
+    const int U = pre[W];
+    int* uq_g = planT + LT.o_uniq + (long)t * LT.UQ;
+    for (int w = tid; w < W; w += 256) {
+        unsigned bits = bm[w];
+        int o = pre[w];
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            if (o < LT.UQ) uq_g[o] = base + (w << 5) + bit;
+            ++o;
+        }
+    }
+    // 4. records
+    unsigned* rec_g = reinterpret_cast<unsigned*>(planT + LT.o_rec) + toff;
+    int* edge_g = planT + LT.o_edge + toff;
+    {
+        const int d = sdeg[g], col = scol[g], eb = sbeg[g];
+        for (int r = sub; r < d; r += 4) {
+            const int e = tedge[col + r];
+            const int i = e / k, j = i - base;
+            const int l = pre[j >> 5] + __popc(bm[j >> 5] & ((1u << (j & 31)) - 1u));
+            rec_g[eb + r] = (unsigned)l | ((unsigned)(e - i * k) << 16);
+            edge_g[eb + r] = e;
+        }
+    }
+    if (tid < ((Et + 3) & ~3) - Et) {                       // padding of the range: harmless entries
+        rec_g[Et + tid] = 0u;
+        edge_g[Et + tid] = base * k;
+    }
+    if (tid < P) tg_g[tid] = make_int4(spt[tid], sbeg[tid], sdeg[tid], 0);
+    if (tid == 0) *hdr_g = make_int4(U, (int)toff, Et, 0);
+    __syncthreads();                                        // the unique list's tail repeats its last id
+    if (U < LT.UQ && U > 0) {
+        // (every lane re-reads the last id written by this workgroup: visible after the barrier only through memory --
+        //  recompute it instead: the highest set bit of the bitmap)
+        int last = 0;
+        for (int w = W - 1; w >= 0; --w)
+            if (bm[w]) { last = base + (w << 5) + 31 - __clz(bm[w]); break; }
+        for (int q = U + tid; q < LT.UQ; q += 256) uq_g[q] = last;
+    }
+}
+
+// operator coefficients in tile order: out[p] = coef[edge[p]]; the words between the tile ranges were never written by the
+// builder (arbitrary bits): anything that is not an edge id gives (0, 0) and no memory access
+__global__ void tileT_permute_kernel(const float2* __restrict__ coef, const int* __restrict__ edge, long ep, unsigned ne,
+                                     float2* __restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t < ep) {
+        const unsigned e = (unsigned)edge[t];
+        out[t] = e < ne ? coef[e] : make_float2(0.f, 0.f);
+    }
+}
+
 int check_plan_args(const char* name, int num_points, int num_clouds, int k, int P) {
     if (num_points < 0 || num_clouds < 0 || k < 2 || k % 2 || k > 64 || (P != 32 && P != 64) || P * k > MAX_PK) {
         dc_set_error("%s: bad size (num_points=%d num_clouds=%d k=%d P=%d; k even, 2 <= k <= 64, P in {32, 64}, P*k <= %d)",
@@ -253,5 +405,51 @@ DC_EXPORT int dc_tile_plan_build(const float* pos, const int32_t* nbr, const int
     hipLaunchKernelGGL(tile_rank_kernel, dim3(num_clouds, dc_cdiv(max_cloud, 64)), dim3(256), 0, s, keys, cloud_ptr, plan, L);
     hipLaunchKernelGGL(tile_unique_kernel, dim3(L.T), dim3(256), 0, s, nbr, cloud_ptr, num_clouds, plan, L);
     DC_CHECK_LAUNCH("dc_tile_plan_build");
+    return DC_OK;
+}
+
+// ---- transposed plan ---------------------------------------------------------------------------------------------------
+DC_EXPORT size_t dc_tile_plan_T_words(int32_t num_points, int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P) {
+    return (size_t)dc_tile_plan_T_layout(num_points, num_clouds, num_tiles, k, P).words;
+}
+// entries of the edge-ordered sections (= the length of an operator's coefficient array in tile order)
+DC_EXPORT int64_t dc_tile_plan_T_edges(int32_t num_points, int32_t num_clouds, int32_t num_tiles, int32_t k) {
+    return dc_tile_plan_T_edges((long)num_points, k, num_tiles, num_clouds);
+}
+// word offset of the edge-id section inside the blob (the permutation handed to dc_csc_permute_coef)
+DC_EXPORT int64_t dc_tile_plan_T_edge_offset(int32_t num_points, int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P) {
+    return dc_tile_plan_T_layout(num_points, num_clouds, num_tiles, k, P).o_edge;
+}
+
+DC_EXPORT int dc_tile_plan_T_build(const int32_t* plan, const int32_t* tptr, const int32_t* tedge, const int32_t* cloud_ptr,
+                                   int32_t num_clouds, int32_t num_points, int32_t max_cloud, int32_t k, int32_t P,
+                                   int32_t* planT, void* stream) {
+    DC_REQUIRE(plan && tptr && tedge && cloud_ptr && planT, "dc_tile_plan_T_build: null pointer");
+    if (int rc = check_plan_args("dc_tile_plan_T_build", num_points, num_clouds, k, P)) return rc;
+    DC_REQUIRE(max_cloud >= 1 && max_cloud <= MAX_CLOUD, "dc_tile_plan_T_build: clouds of more than %d points are not supported (max_cloud=%d)",
+               MAX_CLOUD, max_cloud);
+    DC_REQUIRE((long long)num_points * k < 2147483647LL - 4LL * (num_points / P + 2 * num_clouds) - 16, "dc_tile_plan_T_build: edge ids overflow int32");
+    if (num_points == 0 || num_clouds == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int T = dc_tile_plan_num_tiles(num_points, num_clouds, max_cloud, P);
+    const DcTilePlan L = dc_tile_plan_layout(T, k, P);
+    const DcTilePlanT LT = dc_tile_plan_T_layout(num_points, num_clouds, T, k, P);
+    hipLaunchKernelGGL(tileT_build_kernel, dim3(T), dim3(256), 0, s, plan, L, tptr, tedge, cloud_ptr, num_clouds, planT, LT);
+    DC_CHECK_LAUNCH("dc_tile_plan_T_build");
+    return DC_OK;
+}
+
+// coefTt[EP, 2] = the operator's coefficients coef[Nt * k, 2] in the tile order of planT (EP = dc_tile_plan_T_edges).
+// Once per batch and operator, like dc_csc_permute_coef for the CSC order.
+DC_EXPORT int dc_tile_plan_T_permute_coef(const float* coef, const int32_t* planT, int32_t num_points, int32_t num_clouds,
+                                          int32_t num_tiles, int32_t k, int32_t P, float* coefTt, void* stream) {
+    DC_REQUIRE(coef && planT && coefTt, "dc_tile_plan_T_permute_coef: null pointer");
+    if (int rc = check_plan_args("dc_tile_plan_T_permute_coef", num_points, num_clouds, k, P)) return rc;
+    if (num_points == 0) return DC_OK;
+    const DcTilePlanT LT = dc_tile_plan_T_layout(num_points, num_clouds, num_tiles, k, P);
+    hipLaunchKernelGGL(tileT_permute_kernel, dim3(dc_cdiv(LT.EP, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float2*>(coef), planT + LT.o_edge, LT.EP, (unsigned)((long)num_points * k),
+                       reinterpret_cast<float2*>(coefTt));
+    DC_CHECK_LAUNCH("dc_tile_plan_T_permute_coef");
     return DC_OK;
 }

@@ -22,6 +22,15 @@ class SparseOp:
         assert kind in ("grad", "div")
         self.kind, self.graph, self.coef = kind, graph, coef
         self._coefT = None
+        self._coefTt = None
+
+    def coefTt(self):
+        """Coefficients in the TILE order of the graph's transposed tile plan (transposed applies from LDS); built once."""
+        if self._coefTt is None:
+            pt = self.graph.tile_plan_T()
+            self._coefTt = torch.empty(pt.edges, 2, dtype=torch.float32, device=self.coef.device)
+            lib.call("dc_tile_plan_T_permute_coef", self.coef, pt.blob, *pt.args, self._coefTt)
+        return self._coefTt
 
     def coefT(self):
         """Coefficients in CSC order (for the transposed applies of the backward pass); built once."""

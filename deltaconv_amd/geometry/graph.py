@@ -82,8 +82,51 @@ class TilePlan:
         raise KeyError(name)
 
 
+class TilePlanT:
+    """Transposed tile plan (deltaconv_amd/csrc/tile_plan.h, second half): the tiles of the forward plan seen from the
+    target side -- targets ordered by in-degree, unique source rows, the tile's in-edge lists in tile order.  The
+    transposed applies and the max-aggregation backward run from it with their source rows in LDS (csrc/ell_tileT.h)."""
+
+    def __init__(self, graph, fwd, blob):
+        self.blob, self.P = blob, fwd.P
+        self.n, self.k, self.num_clouds, self.tiles = graph.n, graph.k, graph.num_clouds, fwd.tiles
+        self.edges = int(lib.raw("dc_tile_plan_T_edges")(self.n, self.num_clouds, self.tiles, self.k))
+        self._o_edge = int(lib.raw("dc_tile_plan_T_edge_offset")(self.n, self.num_clouds, self.tiles, self.k, self.P))
+
+    @property
+    def args(self):
+        """(n, num_clouds, num_tiles, k, P): the size arguments every transposed tiled entry point takes after planT."""
+        return self.n, self.num_clouds, self.tiles, self.k, self.P
+
+    @property
+    def edge_ids(self):
+        """int32 [edges]: global edge ids in tile order = the permutation of an operator's coefficients."""
+        return self.blob[self._o_edge:self._o_edge + self.edges]
+
+    def section(self, name):
+        """'tg' [T,P,4] (target, offset, degree, 0), 'hdr' [T,4] (U, start, entries, 0), 'uniq' [T,256], 'rec' [edges]
+        (local source | slot << 16), 'edge' [edges]."""
+        T, P = self.tiles, self.P
+        o_tg, o_hdr = 0, 4 * T * P
+        o_uniq = o_hdr + 4 * T
+        o_rec = o_uniq + 256 * T
+        if name == "tg":
+            return self.blob[o_tg:o_hdr].view(T, P, 4)
+        if name == "hdr":
+            return self.blob[o_hdr:o_uniq].view(T, 4)
+        if name == "uniq":
+            return self.blob[o_uniq:o_rec].view(T, 256)
+        if name == "rec":
+            return self.blob[o_rec:o_rec + self.edges]
+        if name == "edge":
+            return self.edge_ids
+        raise KeyError(name)
+
+
 # Forward applies / max-aggregation from a tile plan (True) or through the gather path (False): A/B switch, same results.
 USE_TILE_PLAN = [os.environ.get("DC_TILE_PLAN", "1") != "0"]
+# Transposed applies / max-aggregation backward from the transposed plan (needs the forward plan): A/B switch, same results.
+USE_TILE_PLAN_T = [os.environ.get("DC_TILE_PLAN_T", "1") != "0"]
 
 
 class Graph:
@@ -95,6 +138,22 @@ class Graph:
         self._csc = None
         self._edge_index = None
         self._tile_plan = None
+        self._tile_plan_T = None
+
+    def tile_plan_T(self):
+        """TilePlanT of this graph (built once from the forward plan + the CSC: one stream-ordered kernel), or None when
+        the graph has no forward plan or the switch is off."""
+        if self._tile_plan_T is None:
+            self._tile_plan_T = False
+            fwd = self.tile_plan()
+            if fwd is not None and USE_TILE_PLAN_T[0]:
+                tptr, tedge = self.csc()
+                words = int(lib.raw("dc_tile_plan_T_words")(self.n, self.num_clouds, fwd.tiles, self.k, fwd.P))
+                blob = torch.empty(words, dtype=torch.int32, device=self.nbr.device)
+                lib.call("dc_tile_plan_T_build", fwd.blob, tptr, tedge, self.ptr, self.num_clouds, self.n, self.max_cloud,
+                         self.k, fwd.P, blob)
+                self._tile_plan_T = TilePlanT(self, fwd, blob)
+        return self._tile_plan_T or None
 
     def tile_plan(self, force_P=None):
         """TilePlan of this graph, built once (stream-ordered kernels: capturable), or None when the plan does not
@@ -106,6 +165,7 @@ class Graph:
             lib.call("dc_tile_plan_build", self.pos, self.nbr, self.ptr, self.num_clouds, self.n, self.max_cloud,
                      self.k, force_P, blob)
             self._tile_plan = TilePlan(self, blob, force_P)
+            self._tile_plan_T = None
         if self._tile_plan is None:
             self._tile_plan = False
             # Where the plan pays (profiles/r03q_tile_policy.txt): k <= 24 with tiles of 64 points and enough points to

@@ -313,12 +313,11 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 ga, lda_ = _rows(dx_new if dx_new is not None else dx_dup)
                 gb, ldb_ = _rows(dx_dup) if (dx_new is not None and dx_dup is not None) else (None, 0)
                 dxn, lddx = torch.empty(n, co, **f32), co
-                call("dc_apply_grad_T_sum", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, ga, lda_, gb,
-                     ldb_, dxn, lddx)
+                _ops.bwd_grad_sum(cfg.grad, dv_cat[:, 2 * ci:], co, K, ga, lda_, gb, ldb_, dxn, lddx)
             else:
                 if not private:                # accumulated into below: never touch autograd's buffer
                     dxn, lddx = (dxn.clone() if dxn.is_contiguous() else dxn.contiguous()), co
-                call("dc_apply_grad_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, 2 * ci:], co, K, dxn, lddx, 1)
+                _ops.bwd_apply("grad", cfg.grad, dv_cat[:, 2 * ci:], co, K, dxn, lddx, 1)
 
         # ---- s_mlp blocks (residual: d x_max = d x')
         d_xcat = None
@@ -335,18 +334,15 @@ class DeltaConvLayerFn(torch.autograd.Function):
             else:
                 d_xcat = dinp
         if dv_cat is not None and d_xcat is not None:   # hodge^T accumulates into d[div | curl]
-            call("dc_apply_hodge_T", cfg.grad.coefT(), tptr, tedge, n, k, dv_cat[:, ci:], ci, 2 * ci + co,
-                 d_xcat[:, ci:], 4 * ci, 1)
+            _ops.bwd_apply("hodge", cfg.grad, dv_cat[:, ci:], ci, 2 * ci + co, d_xcat[:, ci:], 4 * ci, 1)
         dv = None
         if need_v:
             if dv_cat is not None:          # accumulate on top of d v from the v_mlp operand, in place
                 dv = dv_cat[:, :ci]
-                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0),
-                     dv, 2 * ci + co, 1)
+                _ops.bwd_div_curl_norm(cfg.div, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0), dv, 2 * ci + co, 1)
             else:
                 dv = torch.empty(2 * n, ci, **f32)
-                call("dc_apply_div_curl_norm_T", cfg.div.coefT(), tptr, tedge, n, k, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0),
-                     dv, ci, 0)
+                _ops.bwd_div_curl_norm(cfg.div, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0), dv, ci, 0)
 
         # ---- max-aggregation branch (d x_max = d x')
         dx = d_xcat[:, :ci] if (need_x and d_xcat is not None) else None
@@ -372,7 +368,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
             else:
                 (arg,) = max_saved
                 dcur = torch.empty(n, co, **f32)
-                call("dc_knn_max_backward", tptr, tedge, n, k, arg, dxn, co, lddx, dcur, co, 0)
+                _ops.bwd_knn_max(g, arg, dxn, co, lddx, dcur, co, 0)
                 first = nm - 1
             for j in range(first, -1, -1):        # [Linear -> BN -> act] blocks, last to first; block 0 feeds d x
                 inp, h, coef = sm[j]

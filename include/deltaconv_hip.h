@@ -162,6 +162,42 @@ int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, 
                             int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale, const float* shift,
                             float slope, float* out, int64_t ldo, uint8_t* arg, void* stream);
 
+/* ---- transposed applies / max-aggregation backward from the TRANSPOSED TILE PLAN (round 4) -----------------------
+ * Same operations as dc_apply_{grad,grad_T_sum,div,hodge,div_curl_norm}_T and dc_knn_max_backward, i.e. the backward of
+ * the reference's `SparseTensor @ dense` (torch_sparse autograd spmm with A^T: nn/deltaconv.py:57,66,
+ * geometry/operators.py:27,33,40,43) and of torch_scatter.scatter(reduce='max') (nn/deltaconv.py:52,54); results
+ * identical bit for bit (same sums, ascending edge id per target, no floating-point atomics).  The plan keeps the tiles
+ * of the forward plan, orders the targets of a tile by in-degree (the four targets of a wavefront finish together),
+ * lists the unique SOURCE rows of the tile (staged in LDS by LDS-DMA) and stores the tile's in-edge lists contiguously
+ * (layout: deltaconv_amd/csrc/tile_plan.h, second half).  It is built once per batch from the forward plan + the CSC.
+ * Operator argument: the coefficients in TILE order (dc_tile_plan_T_permute_coef: [dc_tile_plan_T_edges(...), 2] floats).  Same restrictions as the forward tiled entry points (C % 64 == 0, 16-byte rows). */
+size_t dc_tile_plan_T_words(int32_t num_points, int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P);
+int64_t dc_tile_plan_T_edges(int32_t num_points, int32_t num_clouds, int32_t num_tiles, int32_t k);
+int64_t dc_tile_plan_T_edge_offset(int32_t num_points, int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P);
+int dc_tile_plan_T_build(const int32_t* plan, const int32_t* tptr, const int32_t* tedge, const int32_t* cloud_ptr,
+                         int32_t num_clouds, int32_t num_points, int32_t max_cloud, int32_t k, int32_t P, int32_t* planT,
+                         void* stream);
+int dc_tile_plan_T_permute_coef(const float* coef, const int32_t* planT, int32_t num_points, int32_t num_clouds,
+                                int32_t num_tiles, int32_t k, int32_t P, float* coefTt, void* stream);
+int dc_apply_grad_T_tiled(const float* GTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                          int32_t k, int32_t P, const float* dy, int32_t C, int64_t ldy, float* dx, int64_t ldx,
+                          int32_t accumulate, void* stream);
+int dc_apply_grad_T_sum_tiled(const float* GTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                              int32_t k, int32_t P, const float* dy, int32_t C, int64_t ldy, const float* a, int64_t lda,
+                              const float* b, int64_t ldb, float* out, int64_t ldo, void* stream);
+int dc_apply_div_T_tiled(const float* DTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                         int32_t k, int32_t P, const float* dy, int32_t C, int64_t ldy, float* dv, int64_t ldv,
+                         int32_t accumulate, void* stream);
+int dc_apply_hodge_T_tiled(const float* GTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
+                           int32_t k, int32_t P, const float* dh, int32_t C, int64_t ldh, float* ddc, int64_t lddc,
+                           int32_t accumulate, void* stream);
+int dc_apply_div_curl_norm_T_tiled(const float* DTt, const int32_t* planT, int32_t n, int32_t num_clouds,
+                                   int32_t num_tiles, int32_t k, int32_t P, const float* dout, int32_t C, int64_t ldo,
+                                   const float* v, int64_t ldv, float* dv, int64_t lddv, int32_t accumulate, void* stream);
+int dc_knn_max_backward_tiled(const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles, int32_t k,
+                              int32_t P, const uint8_t* arg, const float* dout, int32_t C, int64_t ldo, float* dh,
+                              int64_t ldh, int32_t accumulate, void* stream);
+
 /* ---- max aggregation (torch_scatter.scatter(reduce='max'): deltaconv/nn/deltaconv.py:52,54) -- */
 /* out[i,c] = max_s h[nbr[i,s],c]; arg[Nt,C] = first maximal slot (k <= 255) */
 int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh, float* out,
