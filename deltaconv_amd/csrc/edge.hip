@@ -6,6 +6,7 @@
 #include "common.h"
 #include "colreduce.h"
 #include "edge_math.h"
+#include "ell_tileT.h"
 
 namespace {
 using namespace dccol;
@@ -76,6 +77,43 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(long total, int groups, i
     edge_bwd_point<V>(t, groups, tptr, tedge, k, y, ldy, dzs, s1pt, ldo, argmax, argmin, lda, scale, mean, invstd, m1, m2,
                       training, dy, lddy);
 }
+
+// CSC pass of the backward from the transposed tile plan (ell_tileT.h): rows of the in-edges' sources = (y_i, dz*_i) as the
+// two pieces, the selected slot bytes (dc_edge_max_apply's `arg`) as the staged slot words.  Same sums in the same
+// (ascending edge id) order and the same closing expression as edge_bwd_point: bit-identical.
+struct EdgeTB {
+    static constexpr bool COEF = false, ARG = true;
+    static constexpr int NST = 1;
+    const float* in; long ldj, hs; const unsigned char* arg; long lda;      // in = y, in + hs = dzs (same row stride)
+    const float* s1pt; const float *scale, *mean, *invstd, *m1, *m2; int k, training; float* dy; long lddy;
+    dcell::Vec<4> sel, T; float indeg;
+    __device__ void init() { sel = dcell::vzero<4>(); T = dcell::vzero<4>(); indeg = 0.f; }
+    __device__ void step(int s, dcell::G2, const dcell::Vec<4>& yi, const dcell::Vec<4>& dz, unsigned w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sel.v[q] += ((w >> (8 * q)) & 0xffu) == (unsigned)s ? dz.v[q] : 0.f;
+            T.v[q] += yi.v[q];
+        }
+        indeg += 1.f;
+    }
+    __device__ void finish(long j, int c0) {
+        const dcell::Vec<4> yj = dcell::vload<4>(in + j * ldj + c0), dzj = dcell::vload<4>(in + hs + j * ldj + c0),
+                            s1 = dcell::vload<4>(s1pt + j * ldj + c0);
+        dcell::Vec<4> out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q;
+            float g = sel.v[q] - dzj.v[q];
+            if (training) {
+                const float col_hat = (indeg * yj.v[q] - T.v[q] - indeg * mean[c]) * invstd[c];
+                const float row_hat = (s1.v[q] - (float)k * mean[c]) * invstd[c];
+                g -= m1[c] * (indeg - (float)k) + m2[c] * (col_hat - row_hat);
+            }
+            out.v[q] = scale[c] * g;
+        }
+        dctileT::st16<dctileT::ST>(dy + j * lddy + c0, out);
+    }
+};
 }  // namespace
 
 // Gather pass over y[Nt,C] (= Linear(x), no bias): per point amax/amin of a_e = y_j - y_i with
@@ -163,5 +201,36 @@ DC_EXPORT int dc_edge_max_backward(const float* dout, int64_t lddo, const float*
                            training, dy, (long)lddy);
     }
     DC_CHECK_LAUNCH("dc_edge_max_backward");
+    return DC_OK;
+}
+
+// dc_edge_max_backward with the CSC pass running from the transposed tile plan (tile_plan.h second half, ell_tileT.h).
+// argsel = the selected slot per (point, channel) as written by dc_edge_max_apply(arg != NULL); y, dzs contiguous [Nt, C]
+// (row stride C), C % 64 == 0, 16-byte aligned.  Same results bit for bit.
+DC_EXPORT int dc_edge_max_backward_tiled(const float* dout, int64_t lddo, const float* y, const int32_t* planT, int32_t n,
+                                         int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P, int32_t C,
+                                         const float* amax, const float* amin, const uint8_t* argsel, const float* s1pt,
+                                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                                         float slope, int32_t training, float* dzs, float* dy, int64_t lddy, float* dgamma,
+                                         float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(dout && y && planT && amax && amin && argsel && s1pt && scale && shift && mean && invstd && dzs && dy,
+               "dc_edge_max_backward_tiled: null pointer");
+    DC_REQUIRE(n >= 1 && num_clouds >= 1 && num_tiles >= 1 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048 &&
+                   lddo >= C && lddy >= C, "dc_edge_max_backward_tiled: bad size");
+    DC_REQUIRE(dctile::eligible(C, {(long)lddo, (long)lddy}, {dout, y, dzs, dy, amax, amin, s1pt, argsel}) &&
+                   ((dzs - y) % 4 == 0), "dc_edge_max_backward_tiled: needs C %% 64 == 0 and 16-byte aligned rows");
+    if (!workspace || workspace_bytes < ws_need(n, C)) {
+        dc_set_error("dc_edge_max_backward_tiled: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Ws w = carve(workspace, n, C);
+    const BwdFin fin{(long)n * k, dgamma, dbeta, w.m1, w.m2};   // m1, m2 are means over all E edges
+    run_colreduce<4>(EdgeBwdF<4>{dout, amax, amin, scale, shift, mean, invstd, (long)lddo, (long)C, slope, dzs}, n, C, w, s, fin);
+    const DcTilePlanT L = dc_tile_plan_T_layout(n, num_clouds, num_tiles, k, P);
+    dctileT::launch<2>(L, planT, nullptr, C,
+                       EdgeTB{y, (long)C, (long)(dzs - y), argsel, (long)C, s1pt, scale, mean, invstd, w.m1, w.m2, k, training, dy, (long)lddy},
+                       s);
+    DC_CHECK_LAUNCH("dc_edge_max_backward_tiled");
     return DC_OK;
 }

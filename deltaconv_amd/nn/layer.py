@@ -58,6 +58,15 @@ class LayerCfg:
         self.dup = dup     # (buffer [n, sum co], column offset): x' is written into that column block as well
 
 
+def _padded(rows, cols, block, f32):
+    """[rows, cols] fp32 matrix whose column `block` starts on a 16-byte boundary and whose row stride is a multiple of
+    4 floats: a view behind (-block) % 4 spare columns of a wider buffer when that is possible, else a plain matrix."""
+    pad = (-block) % 4
+    if pad and (cols + pad) % 4 == 0:
+        return torch.empty(rows, cols + pad, **f32)[:, pad:]
+    return torch.empty(rows, cols, **f32)
+
+
 def _adopt(t, rows, cols, width):
     """The buffer [rows, width] whose left `cols` columns ARE `t` (t was produced by the previous layer inside this
     layer's operand buffer), or None.  Only buffers that the previous layer created FOR chaining qualify (they carry
@@ -163,9 +172,10 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 call("dc_edge_gather_stats", y0, co, g.nbr, n, k, co, int(use_m), gm, bm, float(bn_m.eps), mom,
                      rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
                      coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)
+                argsel = torch.empty(n, co, dtype=torch.uint8, device=dev)   # the selected slot: backward from the tile plan
                 call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], slope_m,
-                     x_max, co, None)
-                max_saved = (stat, args)
+                     x_max, co, argsel)
+                max_saved = (stat, args, argsel)
                 saved_m.append((inp, y0, coef_m, use_m))
             else:
                 hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
@@ -209,10 +219,13 @@ class DeltaConvLayerFn(torch.autograd.Function):
             K = 2 * ci + co
             v_cat = _adopt(v, 2 * n, ci, K)
             if v_cat is None:
-                v_cat = torch.empty(2 * n, K, **f32)
+                # (first layer, ci = 3: two spare columns in front put the `grad @ x'` block on a 16-byte boundary with a
+                #  row stride that is a multiple of 4 floats, so that block runs from the tile plans, forward and transposed)
+                v_cat = _padded(2 * n, K, 2 * ci, f32)
                 v_cat[:, :ci].copy_(v)
-            _ops.fwd_apply("hodge", cfg.grad, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], K)
-            _ops.fwd_apply("grad", cfg.grad, x_new, co, ldxn, v_cat[:, 2 * ci:], K)
+            ldvc = v_cat.stride(0)
+            _ops.fwd_apply("hodge", cfg.grad, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], ldvc)
+            _ops.fwd_apply("grad", cfg.grad, x_new, co, ldxn, v_cat[:, 2 * ci:], ldvc)
             if cfg.chain is not None and cfg.chain[1] is not None:
                 vbuf = torch.empty(2 * n, cfg.chain[1], **f32)
                 vbuf._dc_chain = True
@@ -268,7 +281,6 @@ class DeltaConvLayerFn(torch.autograd.Function):
         dev = x.device
         f32 = dict(dtype=_F32, device=dev)
         call = lib.call
-        tptr, tedge = g.csc()
         need_x, need_v, need_xmax = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gm_list, gs_list, gv_list = [None] * nm, [None] * ns, [None] * nv        # per block (dW, dgamma, dbeta)
 
@@ -302,7 +314,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
                         dW = dW.view(W.shape[0], 2 * K)                      # [2c, K] rows (c, half) = the [c, 2K] layout
                     else:   # first layer (x, v carry no gradient): only the `grad @ x'` block of d v_cat is consumed
                         dW = fused.gemm_tn(dh, inp).view(W.shape[0], 2 * K)
-                        dv_cat = torch.empty(2 * n, K, **f32)
+                        dv_cat = _padded(2 * n, K, 2 * ci, f32)
                         fused.mm_nn(dh, Wst[:, 2 * ci:].contiguous(), out=dv_cat[:, 2 * ci:])
                 else:
                     dW, dcur = fused.linear_grads(dh, inp, W)
@@ -313,11 +325,11 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 ga, lda_ = _rows(dx_new if dx_new is not None else dx_dup)
                 gb, ldb_ = _rows(dx_dup) if (dx_new is not None and dx_dup is not None) else (None, 0)
                 dxn, lddx = torch.empty(n, co, **f32), co
-                _ops.bwd_grad_sum(cfg.grad, dv_cat[:, 2 * ci:], co, K, ga, lda_, gb, ldb_, dxn, lddx)
+                _ops.bwd_grad_sum(cfg.grad, dv_cat[:, 2 * ci:], co, dv_cat.stride(0), ga, lda_, gb, ldb_, dxn, lddx)
             else:
                 if not private:                # accumulated into below: never touch autograd's buffer
                     dxn, lddx = (dxn.clone() if dxn.is_contiguous() else dxn.contiguous()), co
-                _ops.bwd_apply("grad", cfg.grad, dv_cat[:, 2 * ci:], co, K, dxn, lddx, 1)
+                _ops.bwd_apply("grad", cfg.grad, dv_cat[:, 2 * ci:], co, dv_cat.stride(0), dxn, lddx, 1)
 
         # ---- s_mlp blocks (residual: d x_max = d x')
         d_xcat = None
@@ -334,12 +346,12 @@ class DeltaConvLayerFn(torch.autograd.Function):
             else:
                 d_xcat = dinp
         if dv_cat is not None and d_xcat is not None:   # hodge^T accumulates into d[div | curl]
-            _ops.bwd_apply("hodge", cfg.grad, dv_cat[:, ci:], ci, 2 * ci + co, d_xcat[:, ci:], 4 * ci, 1)
+            _ops.bwd_apply("hodge", cfg.grad, dv_cat[:, ci:], ci, dv_cat.stride(0), d_xcat[:, ci:], 4 * ci, 1)
         dv = None
         if need_v:
             if dv_cat is not None:          # accumulate on top of d v from the v_mlp operand, in place
                 dv = dv_cat[:, :ci]
-                _ops.bwd_div_curl_norm(cfg.div, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0), dv, 2 * ci + co, 1)
+                _ops.bwd_div_curl_norm(cfg.div, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0), dv, dv_cat.stride(0), 1)
             else:
                 dv = torch.empty(2 * n, ci, **f32)
                 _ops.bwd_div_curl_norm(cfg.div, d_xcat[:, ci:], ci, 4 * ci, v, v.stride(0), dv, ci, 0)
@@ -353,13 +365,20 @@ class DeltaConvLayerFn(torch.autograd.Function):
             inp, hm, coef_m = sm[-1]
             Wm, gm, _ = pm[-1]
             if centralized:
-                stat, args = max_saved
+                stat, args, argsel = max_saved
                 dzs, dpre = torch.empty(n, co, **f32), torch.empty(n, co, **f32)
                 dg, db = torch.empty(co, **f32), torch.empty(co, **f32)
                 ws, nb = fused._ws(n, co, dev)
-                call("dc_edge_max_backward", dxn, lddx, hm, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
-                     stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slopes_m[-1], int(use_m[-1]), dzs, dpre, co,
-                     dg, db, ws, nb)
+                planT = _ops._tiledT(g, co, (dxn, lddx), (hm, co))
+                if planT is not None and hm.is_contiguous():
+                    call("dc_edge_max_backward_tiled", dxn, lddx, hm, planT.blob, *planT.args, co, stat[0], stat[1], argsel,
+                         stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slopes_m[-1], int(use_m[-1]), dzs, dpre, co,
+                         dg, db, ws, nb)
+                else:
+                    tptr, tedge = g.csc()
+                    call("dc_edge_max_backward", dxn, lddx, hm, co, tptr, tedge, n, k, co, stat[0], stat[1], args[0], args[1],
+                         stat[2], coef_m[2], coef_m[3], coef_m[0], coef_m[1], cfg.slopes_m[-1], int(use_m[-1]), dzs, dpre, co,
+                         dg, db, ws, nb)
                 gm_list[-1] = (fused.gemm_tn(dpre, inp), dg, db)
                 dcur = fused.mm_nn(dpre, Wm) if nm > 1 else None
                 if nm == 1 and need_x:            # d x = d_xcat[:, :ci] + dpre Wm, accumulated in place (ldc = 4 ci)

@@ -281,6 +281,15 @@ int dc_edge_max_backward(const float* dout, int64_t lddo, const float* y, int64_
                          const float* shift, const float* mean, const float* invstd, float slope, int32_t training,
                          float* dzs, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* dc_edge_max_backward with its CSC pass running from the transposed tile plan (rows (y_i, dz*_i) of the in-edges' sources
+ * and the selected slot bytes in LDS); argsel = the `arg` output of dc_edge_max_apply; y, dzs, amax, amin, s1pt contiguous
+ * [Nt, C], C % 64 == 0.  Same results bit for bit (same reference lines: nn/deltaconv.py:50-52 backward). */
+int dc_edge_max_backward_tiled(const float* dout, int64_t lddo, const float* y, const int32_t* planT, int32_t n,
+                               int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P, int32_t C, const float* amax,
+                               const float* amin, const uint8_t* argsel, const float* s1pt, const float* scale,
+                               const float* shift, const float* mean, const float* invstd, float slope, int32_t training,
+                               float* dzs, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ---- weight-gradient GEMM on the fp32 matrix cores ---------------------------------------------------
  * C[M,N] (+)= A^T B,  A [R,M], B [R,N], R >> M,N  (dW = dY^T X of every per-point Linear layer: ATen mm in the

@@ -171,6 +171,45 @@ def test_tiledT_strided_operands():
     assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize("sizes,k", [((512, 700, 300), 20), ((1024, 1024), 30)])
+@pytest.mark.parametrize("training", [1, 0])
+def test_edge_backward_tiled_equals_gather(sizes, k, training):
+    """Backward of the layer-0 edge MLP (dc_edge_max_backward: /root/reference/deltaconv/nn/deltaconv.py:50-52): the CSC
+    pass from the transposed plan gives the same bits as the gather kernel, for both BatchNorm modes and mixed-sign scales."""
+    from deltaconv_amd._lib import lib
+    from deltaconv_amd.nn import fused
+    _, gr, _, _ = _setup(sizes, k, dup_frac=0.03)
+    pt = gr.tile_plan_T()
+    n, C = gr.n, 64
+    tptr, tedge = gr.csc()
+    torch.manual_seed(k + training)
+    y, dout = _rand(n, C), _rand(n, C)
+    gamma, beta = _rand(C), _rand(C)                                       # mixed signs: max and min selections
+    stat = torch.empty(3, n, C, device=DEV)
+    args = torch.empty(2, n, C, dtype=torch.uint8, device=DEV)
+    coef = torch.empty(4, C, device=DEV)
+    ws, nb = fused._ws(n, C, DEV)
+    lib.call("dc_edge_gather_stats", y, C, gr.nbr, n, k, C, 1, gamma, beta, 1e-5, 0.1, None, None, stat[0], stat[1], args[0], args[1],
+             stat[2], coef[0], coef[1], coef[2], coef[3], ws, nb)
+    xmax, argsel = torch.empty(n, C, device=DEV), torch.empty(n, C, dtype=torch.uint8, device=DEV)
+    lib.call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, C, coef[2], coef[3], 0.2, xmax, C, argsel)
+    assert torch.equal(argsel, torch.where(coef[2] >= 0, args[0], args[1]))
+    outs = []
+    for tiled in (False, True):
+        dzs, dy = torch.full((n, C), float("nan"), device=DEV), torch.full((n, C), float("nan"), device=DEV)
+        dg, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        if tiled:
+            lib.call("dc_edge_max_backward_tiled", dout, C, y, pt.blob, *pt.args, C, stat[0], stat[1], argsel, stat[2], coef[2],
+                     coef[3], coef[0], coef[1], 0.2, training, dzs, dy, C, dg, db, ws, nb)
+        else:
+            lib.call("dc_edge_max_backward", dout, C, y, C, tptr, tedge, n, k, C, stat[0], stat[1], args[0], args[1], stat[2],
+                     coef[2], coef[3], coef[0], coef[1], 0.2, training, dzs, dy, C, dg, db, ws, nb)
+        torch.cuda.synchronize()
+        outs.append((dzs, dy, dg, db))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_) and bool(torch.isfinite(b_).all())
+
+
 def test_tiledT_rejects_what_it_cannot_do():
     from deltaconv_amd._lib import lib
     _, gr, grad, _ = _setup((256,), 20)
