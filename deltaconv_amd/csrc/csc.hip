@@ -69,7 +69,20 @@ __global__ __launch_bounds__(CLOUD_TPB) void csc_cloud_kernel(const int* __restr
     for (int q = tid; q < n; q += CLOUD_TPB) cnt[q] = 0;
     __syncthreads();
     const long e0 = (long)begin * k, ne = (long)n * k;
-    for (long e = tid; e < ne; e += CLOUD_TPB) atomicAdd(&cnt[nbr[e0 + e] - begin], 1);
+    // (eight independent loads in flight per thread: the one-load-one-atomic loop ran 20 dependent global round trips per
+    //  pass and made this kernel 25 us at 32 x 1024 points, k = 20, with one workgroup per cloud)
+    for (long eb = 0; eb < ne; eb += 8 * CLOUD_TPB) {
+        int col[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long e = eb + u * CLOUD_TPB + tid;
+            const int c = nbr[e0 + min(e, ne - 1)];        // unconditional (clamped) load: see csc_range_kernel
+            col[u] = e < ne ? c - begin : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (col[u] >= 0) atomicAdd(&cnt[col[u]], 1);
+    }
     __syncthreads();
     // exclusive scan of cnt over the cloud (same partition as csc_scan_kernel: tptr is identical)
     const int per = (n + CLOUD_TPB - 1) / CLOUD_TPB;
@@ -93,7 +106,96 @@ __global__ __launch_bounds__(CLOUD_TPB) void csc_cloud_kernel(const int* __restr
         run += c;
     }
     __syncthreads();
-    for (long e = tid; e < ne; e += CLOUD_TPB) unordered[atomicAdd(&cnt[nbr[e0 + e] - begin], 1)] = (int)(e0 + e);
+    for (long eb = 0; eb < ne; eb += 8 * CLOUD_TPB) {       // (nbr is re-read from L2: the loads of a batch fly together)
+        int col[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long e = eb + u * CLOUD_TPB + tid;
+            const int c = nbr[e0 + min(e, ne - 1)];        // unconditional (clamped) load: see csc_range_kernel
+            col[u] = e < ne ? c - begin : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (col[u] >= 0) unordered[atomicAdd(&cnt[col[u]], 1)] = (int)(e0 + eb + u * CLOUD_TPB + tid);
+    }
+}
+
+// Count, scan and fill of ONE COLUMN RANGE of a cloud per workgroup: RANGES workgroups per cloud instead of one.  The LDS
+// atomics of csc_cloud_kernel (2 x N * k per cloud, all in one CU) bound it: 25 us at 32 x 1024 points, k = 20 on 32 of 256
+// CUs.  Every workgroup scans ALL edges of its cloud (coalesced, L2-resident) but counts / fills only the targets of its
+// range; the targets BELOW the range are counted in registers on the way (no atomics), which gives the range its base
+// offset without any hand-off between workgroups.  tptr is identical to csc_cloud_kernel's, the columns come out unordered
+// and are ordered by csc_rank_kernel as before.
+constexpr int RANGES = 8, RANGE_MAX = CLOUD_MAX / RANGES;
+constexpr int RB = 20;   // loads in flight per thread and batch (the kernel is bound by the latency of its global loads: 20 = one batch at 1024 points, k = 20)
+__global__ __launch_bounds__(CLOUD_TPB) void csc_range_kernel(const int* __restrict__ nbr, const int* __restrict__ cloud_ptr,
+                                                              int k, int num_clouds, int* __restrict__ tptr,
+                                                              int* __restrict__ unordered) {
+    __shared__ int cnt[RANGE_MAX];
+    __shared__ int red[CLOUD_TPB / 64];
+    const int cloud = blockIdx.x, tid = threadIdx.x;
+    const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
+    const int rs = (n + RANGES - 1) / RANGES;               // columns per range
+    const int r0 = blockIdx.y * rs, r1 = min(r0 + rs, n);
+    if (r0 >= n) return;                                    // block-uniform
+    for (int q = tid; q < rs; q += CLOUD_TPB) cnt[q] = 0;
+    __syncthreads();
+    const long e0 = (long)begin * k, ne = (long)n * k;
+    int below = 0;
+    for (long eb = 0; eb < ne; eb += RB * CLOUD_TPB) {
+        int col[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const long e = eb + u * CLOUD_TPB + tid;
+            const int c = nbr[e0 + min(e, ne - 1)];        // unconditional (clamped): a conditional load compiles to a branch
+            col[u] = e < ne ? c - begin : n;               // with its own vmcnt(0), i.e. twenty serial round trips
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            below += col[u] < r0;
+            if (col[u] >= r0 && col[u] < r1) atomicAdd(&cnt[col[u] - r0], 1);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += __shfl_xor(below, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = below;
+    __syncthreads();
+    int base = (int)e0;
+#pragma unroll
+    for (int w = 0; w < CLOUD_TPB / 64; ++w) base += red[w];
+    // exclusive scan of the range's counts by the first wavefront (rs <= 512: eight columns per lane)
+    if (tid < 64) {
+        const int per = (rs + 63) / 64;
+        const int lo = min(tid * per, r1 - r0), hi = min(lo + per, r1 - r0);
+        int s = 0;
+        for (int q = lo; q < hi; ++q) s += cnt[q];
+        int incl = s;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += u;
+        }
+        int run = base + incl - s;
+        for (int q = lo; q < hi; ++q) {
+            const int c = cnt[q];
+            tptr[begin + r0 + q] = run;
+            cnt[q] = run;                                   // becomes the fill cursor
+            run += c;
+        }
+        if (tid == 63 && cloud == num_clouds - 1 && r1 == n) tptr[begin + n] = base + incl;   // = Nt * k
+    }
+    __syncthreads();
+    for (long eb = 0; eb < ne; eb += RB * CLOUD_TPB) {
+        int col[RB];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const long e = eb + u * CLOUD_TPB + tid;
+            const int c = nbr[e0 + min(e, ne - 1)];        // unconditional (clamped): a conditional load compiles to a branch
+            col[u] = e < ne ? c - begin : n;               // with its own vmcnt(0), i.e. twenty serial round trips
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+            if (col[u] >= r0 && col[u] < r1) unordered[atomicAdd(&cnt[col[u] - r0], 1)] = (int)(e0 + eb + u * CLOUD_TPB + tid);
+    }
 }
 
 // Order every column by edge id without a serial sort: the rank of an entry = the number of smaller entries of its
@@ -185,7 +287,10 @@ DC_EXPORT int dc_csc_build_clouds(const int32_t* nbr, const int32_t* cloud_ptr, 
         return DC_ERR_WORKSPACE;
     }
     int* unordered = static_cast<int*>(workspace);
-    hipLaunchKernelGGL(csc_cloud_kernel, dim3(num_clouds), dim3(CLOUD_TPB), 0, s, nbr, cloud_ptr, k, num_clouds, tptr, unordered);
+    if (dc_option(DC_OPT_CSC_ONE_WG))                       // A/B switch: the one-workgroup-per-cloud kernel of round 3
+        hipLaunchKernelGGL(csc_cloud_kernel, dim3(num_clouds), dim3(CLOUD_TPB), 0, s, nbr, cloud_ptr, k, num_clouds, tptr, unordered);
+    else
+        hipLaunchKernelGGL(csc_range_kernel, dim3(num_clouds, RANGES), dim3(CLOUD_TPB), 0, s, nbr, cloud_ptr, k, num_clouds, tptr, unordered);
     hipLaunchKernelGGL(csc_rank_kernel, dim3(std::min<long>(dc_cdiv((long)num_points * 64, TPB), 256 * 16)), dim3(TPB), 0, s,
                        num_points, tptr, unordered, tedge);
     DC_CHECK_LAUNCH("dc_csc_build_clouds");

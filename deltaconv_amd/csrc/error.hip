@@ -14,7 +14,7 @@ void dc_set_error(const char* fmt, ...) {
 DC_EXPORT const char* dc_last_error(void) { return g_err; }
 DC_EXPORT int32_t dc_version(void) { return 100; }  // 0.1.0 -> major*10000 + minor*100 + patch
 
-static int g_opt[DC_OPT_COUNT] = {1, 0, 0, 0, 0, 0, 0, 0};  // XCD remap on by default
+static int g_opt[DC_OPT_COUNT] = {1};  // XCD remap on by default
 int dc_option(int key) { return (key >= 0 && key < DC_OPT_COUNT) ? g_opt[key] : 0; }
 // Experiment switch for A/B measurements (key 0: XCD-aware block remap, default 1).
 DC_EXPORT int dc_set_option(int32_t key, int32_t value) {

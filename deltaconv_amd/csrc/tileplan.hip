@@ -53,6 +53,17 @@ __device__ __forceinline__ int block_tile_base(const int* __restrict__ cloud_ptr
     return total;
 }
 
+// cloud of a point id: cloud_ptr[b] <= first < cloud_ptr[b + 1].  Every thread tests its own clouds (one memory round trip
+// for the workgroup; a binary search is log2(B) DEPENDENT round trips, a fifth of these latency-bound builder kernels).
+__device__ __forceinline__ int block_find_cloud(const int* __restrict__ cloud_ptr, int num_clouds, int first, int* slot /* LDS */) {
+    for (int c = threadIdx.x; c < num_clouds; c += blockDim.x)
+        if (cloud_ptr[c] <= first && first < cloud_ptr[c + 1]) *slot = c;
+    __syncthreads();
+    const int b = *slot;
+    __syncthreads();
+    return b;
+}
+
 __global__ __launch_bounds__(256) void tile_key_kernel(const float* __restrict__ pos, const int* __restrict__ cloud_ptr,
                                                        int num_clouds, unsigned* __restrict__ keys, int* __restrict__ plan,
                                                        DcTilePlan L) {
@@ -142,11 +153,8 @@ __global__ __launch_bounds__(256) void tile_unique_kernel(const int* __restrict_
     const int* pts_g = plan + L.o_pts + (long)t * P;
     const int first = pts_g[0];
     if (first < 0) return;                                  // unused tile id (stays empty: nu = 0)
-    int lo = 0, hi = num_clouds;                            // cloud of the tile: cloud_ptr[lo] <= first < cloud_ptr[lo + 1]
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (cloud_ptr[mid] <= first) lo = mid; else hi = mid;
-    }
+    __shared__ int cslot;
+    const int lo = block_find_cloud(cloud_ptr, num_clouds, first, &cslot);   // cloud of the tile
     const int base = cloud_ptr[lo], N = cloud_ptr[lo + 1] - base;
     const int W = (N + 31) >> 5;
     if (tid < P) pts[tid] = pts_g[tid];
@@ -156,12 +164,20 @@ __global__ __launch_bounds__(256) void tile_unique_kernel(const int* __restrict_
         const int j = pts[tid] - base;
         atomicOr(&bm[j >> 5], 1u << (j & 31));
     }
-    for (int q = tid; q < PK; q += 256) {
-        const int p = q / k, pt = pts[p];
-        if (pt >= 0) {
-            const int j = nbr[(long)pt * k + (q - p * k)] - base;
-            atomicOr(&bm[j >> 5], 1u << (j & 31));
+    // (neighbour ids by unconditional, clamped loads, eight in flight: a conditional load compiles to a branch with its own
+    //  wait -- the five loads of a thread were five serial round trips, twice)
+    int jv[8];
+    for (int q0 = 0; q0 < PK; q0 += 8 * 256) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u * 256 + tid, qq = min(q, PK - 1);
+            const int p = qq / k, pt = pts[p];
+            const int j = nbr[(long)max(pt, 0) * k + (qq - p * k)];
+            jv[u] = (q < PK && pt >= 0) ? j - base : -1;
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (jv[u] >= 0) atomicOr(&bm[jv[u] >> 5], 1u << (jv[u] & 31));
     }
     __syncthreads();
     if (tid == 0) pre[0] = 0;
@@ -198,14 +214,23 @@ __global__ __launch_bounds__(256) void tile_unique_kernel(const int* __restrict_
     int* uq_g = plan + L.o_uniq + (long)t * PK;
     for (int q = tid; q < PK; q += 256) uq_g[q] = uq[min(q, Uc - 1)];
     unsigned short* loc_g = reinterpret_cast<unsigned short*>(plan + L.o_loc) + (long)t * PK;
-    for (int q = tid; q < PK; q += 256) {
-        const int p = q / k, pt = pts[p];
-        int l = 0;
-        if (pt >= 0) {
-            const int j = nbr[(long)pt * k + (q - p * k)] - base;
-            l = pre[j >> 5] + __popc(bm[j >> 5] & ((1u << (j & 31)) - 1u));
+    for (int q0 = 0; q0 < PK; q0 += 8 * 256) {
+        if (PK > 8 * 256 || q0 > 0) {                       // (one batch covers P * k <= 2048: the ids are still in registers)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * 256 + tid, qq = min(q, PK - 1);
+                const int p = qq / k, pt = pts[p];
+                const int j = nbr[(long)max(pt, 0) * k + (qq - p * k)];
+                jv[u] = (q < PK && pt >= 0) ? j - base : -1;
+            }
         }
-        loc_g[q] = (unsigned short)l;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int q = q0 + u * 256 + tid;
+            const int j = max(jv[u], 0);
+            const int l = jv[u] >= 0 ? pre[j >> 5] + __popc(bm[j >> 5] & ((1u << (j & 31)) - 1u)) : 0;
+            if (q < PK) loc_g[q] = (unsigned short)l;
+        }
     }
     unsigned short* self_g = reinterpret_cast<unsigned short*>(plan + L.o_self) + (long)t * P;
     if (tid < P) {
@@ -226,13 +251,13 @@ __global__ __launch_bounds__(256) void tile_unique_kernel(const int* __restrict_
 //   3. bitmap of the sources over the cloud's local ids -> prefix popcounts -> unique list + the tile-local index of every
 //      in-edge's source (as tile_unique_kernel does for the neighbours);
 //   4. records + edge ids in (lane group, ascending edge id) order.
-__global__ __launch_bounds__(256) void tileT_build_kernel(const int* __restrict__ plan, DcTilePlan L, const int* __restrict__ tptr,
-                                                          const int* __restrict__ tedge, const int* __restrict__ cloud_ptr,
-                                                          int num_clouds, int* __restrict__ planT, DcTilePlanT LT) {
+__global__ __launch_bounds__(1024) void tileT_build_kernel(const int* __restrict__ plan, DcTilePlan L, const int* __restrict__ tptr,
+                                                           const int* __restrict__ tedge, const int* __restrict__ cloud_ptr,
+                                                           int num_clouds, int* __restrict__ planT, DcTilePlanT LT) {
     __shared__ int pts[64], deg[64], spt[64], sdeg[64], sbeg[64], scol[64];
     __shared__ unsigned bm[MAX_CLOUD / 32];
     __shared__ int pre[MAX_CLOUD / 32 + 1];
-    __shared__ int red[4];
+    __shared__ int red[16];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int P = L.P, k = L.k;
     int4* tg_g = reinterpret_cast<int4*>(planT + LT.o_tg) + (long)t * P;
@@ -244,38 +269,41 @@ __global__ __launch_bounds__(256) void tileT_build_kernel(const int* __restrict_
         if (tid == 0) *hdr_g = make_int4(0, 0, 0, 0);
         return;
     }
-    int lo = 0, hi = num_clouds;                            // cloud of the tile
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (cloud_ptr[mid] <= first) lo = mid; else hi = mid;
-    }
-    const int b = lo, base = cloud_ptr[b], N = cloud_ptr[b + 1] - base;
-    const int tile0 = block_tile_base(cloud_ptr, b, P, red);
-    const int tc = t - tile0;                               // tile index inside the cloud
+    __shared__ int cslot;
+    const int b = block_find_cloud(cloud_ptr, num_clouds, first, &cslot);   // cloud of the tile
+    const int base = cloud_ptr[b], N = cloud_ptr[b + 1] - base;
+    // first tile of the cloud (block_tile_base over 1024 threads)
+    int tsum = 0;
+    for (int c = tid; c < b; c += 1024) tsum += (cloud_ptr[c + 1] - cloud_ptr[c] + P - 1) / P;
+    tsum = dc_wave_sum_i(tsum);
+    if ((tid & 63) == 0) red[tid >> 6] = tsum;
     if (tid < 64) {
         const int j = tid < P ? pts_g[tid] : -1;
         pts[tid] = j;
         deg[tid] = j >= 0 ? tptr[j + 1] - tptr[j] : 0;
     }
     const int W = (N + 31) >> 5;
-    for (int w = tid; w < W; w += 256) bm[w] = 0u;
+    for (int w = tid; w < W; w += 1024) bm[w] = 0u;
+    __syncthreads();
+    int tile0 = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tile0 += red[w];
+    const int tc = t - tile0;                               // tile index inside the cloud
     // 2. rounded lengths of the cloud's earlier tiles (segments of P lanes = one tile)
     int part = 0;
-    for (int q0 = 0; q0 < tc * P; q0 += 256) {
+    for (int q0 = 0; q0 < tc * P; q0 += 1024) {
         const int q = q0 + tid;
-        int d = 0;
-        if (q < tc * P) {
-            const int j = plan[L.o_pts + (long)tile0 * P + q];
-            if (j >= 0) d = tptr[j + 1] - tptr[j];
-        }
+        // (unconditional, clamped loads: a conditional load compiles to a branch with its own wait)
+        const int j = plan[L.o_pts + (long)tile0 * P + min(q, tc * P - 1)];
+        const int jj = max(j, 0);
+        int d = tptr[jj + 1] - tptr[jj];
+        d = (q < tc * P && j >= 0) ? d : 0;
         for (int o = P >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
         if ((tid & (P - 1)) == 0) part += (d + 3) & ~3;
     }
     part = dc_wave_sum_i(part);
-    __syncthreads();                                        // (red of block_tile_base is free again; pts / deg / bm visible)
+    __syncthreads();                                        // (every thread has read red: it is free again)
     if ((tid & 63) == 0) red[tid >> 6] = part;
-    __syncthreads();
-    const long toff = (((long)base * k + 3) & ~3L) + 4L * (tile0 + b) + red[0] + red[1] + red[2] + red[3];
     // 1. degree order (64 x 64 compares)
     if (tid < 64) {
         const int d = deg[tid];
@@ -286,6 +314,9 @@ __global__ __launch_bounds__(256) void tileT_build_kernel(const int* __restrict_
         scol[r] = pts[tid] >= 0 ? tptr[pts[tid]] : 0;
     }
     __syncthreads();
+    long toff = (((long)base * k + 3) & ~3L) + 4L * (tile0 + b);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) toff += red[w];
     if (tid < 64) {                                         // exclusive scan of the sorted degrees (one wavefront)
         int v = sdeg[tid];
         for (int o = 1; o < 64; o <<= 1) {
@@ -293,20 +324,26 @@ __global__ __launch_bounds__(256) void tileT_build_kernel(const int* __restrict_
             if (tid >= o) v += u;
         }
         sbeg[tid] = v - sdeg[tid];
-        if (tid == 63) red[0] = v;
     }
-    __syncthreads();
-    const int Et = red[0];
-    // 3. bitmap of the sources: four lanes per target walk its list
-    const int g = tid >> 2, sub = tid & 3;
-    {
-        const int d = sdeg[g], col = scol[g];
-        for (int r = sub; r < d; r += 4) {
-            const int j = tedge[col + r] / k - base;
+    // 3. bitmap of the sources: sixteen lanes per target walk its list (one or two entries per lane at k = 20)
+    const int g = tid >> 4, sub = tid & 15;
+    const int dgt = sdeg[g], col = scol[g];
+    // the first 64 entries of the list by unconditional, clamped loads (four in flight per lane; kept for the record pass)
+    int ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ev[u] = tedge[dgt > 0 ? col + min(sub + 16 * u, dgt - 1) : 0];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (sub + 16 * u < dgt) {
+            const int j = ev[u] / k - base;
             atomicOr(&bm[j >> 5], 1u << (j & 31));
         }
+    for (int r = 64 + sub; r < dgt; r += 16) {
+        const int j = tedge[col + r] / k - base;
+        atomicOr(&bm[j >> 5], 1u << (j & 31));
     }
     __syncthreads();
+    const int Et = sbeg[63] + sdeg[63];
     if (tid == 0) pre[0] = 0;
     if (tid < 128) pre[tid + 1] = tid < W ? __popc(bm[tid]) : 0;
     __syncthreads();
@@ -318,29 +355,41 @@ __global__ __launch_bounds__(256) void tileT_build_kernel(const int* __restrict_
         __syncthreads();
     }
     const int U = pre[W];
+    // unique list: four lanes per bitmap word, each emits the set bits of one byte
     int* uq_g = planT + LT.o_uniq + (long)t * LT.UQ;
-    for (int w = tid; w < W; w += 256) {
-        unsigned bits = bm[w];
-        int o = pre[w];
+    if (tid < 4 * W) {
+        const int w = tid >> 2, by = tid & 3;
+        const unsigned word = bm[w];
+        unsigned bits = (word >> (8 * by)) & 0xffu;
+        int o = pre[w] + __popc(word & ((1u << (8 * by)) - 1u));
         while (bits) {
             const int bit = __ffs(bits) - 1;
             bits &= bits - 1;
-            if (o < LT.UQ) uq_g[o] = base + (w << 5) + bit;
+            if (o < LT.UQ) uq_g[o] = base + (w << 5) + 8 * by + bit;
             ++o;
         }
+    }
+    if (U < LT.UQ && U > 0) {                               // the list's tail repeats its last id = the highest set bit
+        int last = 0;
+        for (int w = W - 1; w >= 0; --w)
+            if (bm[w]) { last = base + (w << 5) + 31 - __clz(bm[w]); break; }
+        for (int q = U + tid; q < LT.UQ; q += 1024) uq_g[q] = last;
     }
     // 4. records
     unsigned* rec_g = reinterpret_cast<unsigned*>(planT + LT.o_rec) + toff;
     int* edge_g = planT + LT.o_edge + toff;
     {
-        const int d = sdeg[g], col = scol[g], eb = sbeg[g];
-        for (int r = sub; r < d; r += 4) {
-            const int e = tedge[col + r];
+        const int eb = sbeg[g];
+        auto emit = [&](int r, int e) {
             const int i = e / k, j = i - base;
             const int l = pre[j >> 5] + __popc(bm[j >> 5] & ((1u << (j & 31)) - 1u));
             rec_g[eb + r] = (unsigned)l | ((unsigned)(e - i * k) << 16);
             edge_g[eb + r] = e;
-        }
+        };
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (sub + 16 * u < dgt) emit(sub + 16 * u, ev[u]);
+        for (int r = 64 + sub; r < dgt; r += 16) emit(r, tedge[col + r]);
     }
     if (tid < ((Et + 3) & ~3) - Et) {                       // padding of the range: harmless entries
         rec_g[Et + tid] = 0u;
@@ -348,25 +397,18 @@ __global__ __launch_bounds__(256) void tileT_build_kernel(const int* __restrict_
     }
     if (tid < P) tg_g[tid] = make_int4(spt[tid], sbeg[tid], sdeg[tid], 0);
     if (tid == 0) *hdr_g = make_int4(U, (int)toff, Et, 0);
-    __syncthreads();                                        // the unique list's tail repeats its last id
-    if (U < LT.UQ && U > 0) {
-        // (every lane re-reads the last id written by this workgroup: visible after the barrier only through memory --
-        //  recompute it instead: the highest set bit of the bitmap)
-        int last = 0;
-        for (int w = W - 1; w >= 0; --w)
-            if (bm[w]) { last = base + (w << 5) + 31 - __clz(bm[w]); break; }
-        for (int q = U + tid; q < LT.UQ; q += 256) uq_g[q] = last;
-    }
 }
 
 // operator coefficients in tile order: out[p] = coef[edge[p]]; the words between the tile ranges were never written by the
 // builder (arbitrary bits): anything that is not an edge id gives (0, 0) and no memory access
-__global__ void tileT_permute_kernel(const float2* __restrict__ coef, const int* __restrict__ edge, long ep, unsigned ne,
-                                     float2* __restrict__ out) {
+__global__ void tileT_permute_kernel(const float2* __restrict__ coefA, const float2* __restrict__ coefB, const int* __restrict__ edge,
+                                     long ep, unsigned ne, float2* __restrict__ outA, float2* __restrict__ outB) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t < ep) {
         const unsigned e = (unsigned)edge[t];
-        out[t] = e < ne ? coef[e] : make_float2(0.f, 0.f);
+        const bool ok = e < ne;
+        outA[t] = ok ? coefA[e] : make_float2(0.f, 0.f);
+        if (coefB) outB[t] = ok ? coefB[e] : make_float2(0.f, 0.f);
     }
 }
 
@@ -434,22 +476,24 @@ DC_EXPORT int dc_tile_plan_T_build(const int32_t* plan, const int32_t* tptr, con
     const int T = dc_tile_plan_num_tiles(num_points, num_clouds, max_cloud, P);
     const DcTilePlan L = dc_tile_plan_layout(T, k, P);
     const DcTilePlanT LT = dc_tile_plan_T_layout(num_points, num_clouds, T, k, P);
-    hipLaunchKernelGGL(tileT_build_kernel, dim3(T), dim3(256), 0, s, plan, L, tptr, tedge, cloud_ptr, num_clouds, planT, LT);
+    hipLaunchKernelGGL(tileT_build_kernel, dim3(T), dim3(1024), 0, s, plan, L, tptr, tedge, cloud_ptr, num_clouds, planT, LT);
     DC_CHECK_LAUNCH("dc_tile_plan_T_build");
     return DC_OK;
 }
 
 // coefTt[EP, 2] = the operator's coefficients coef[Nt * k, 2] in the tile order of planT (EP = dc_tile_plan_T_edges).
-// Once per batch and operator, like dc_csc_permute_coef for the CSC order.
-DC_EXPORT int dc_tile_plan_T_permute_coef(const float* coef, const int32_t* planT, int32_t num_points, int32_t num_clouds,
-                                          int32_t num_tiles, int32_t k, int32_t P, float* coefTt, void* stream) {
-    DC_REQUIRE(coef && planT && coefTt, "dc_tile_plan_T_permute_coef: null pointer");
+// Once per batch and operator, like dc_csc_permute_coef for the CSC order; coefB / coefBTt (may be NULL) = a second
+// operator over the same graph in the same launch (grad and div of a batch).
+DC_EXPORT int dc_tile_plan_T_permute_coef(const float* coef, const float* coefB, const int32_t* planT, int32_t num_points,
+                                          int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P, float* coefTt,
+                                          float* coefBTt, void* stream) {
+    DC_REQUIRE(coef && planT && coefTt && (!coefB || coefBTt), "dc_tile_plan_T_permute_coef: null pointer");
     if (int rc = check_plan_args("dc_tile_plan_T_permute_coef", num_points, num_clouds, k, P)) return rc;
     if (num_points == 0) return DC_OK;
     const DcTilePlanT LT = dc_tile_plan_T_layout(num_points, num_clouds, num_tiles, k, P);
     hipLaunchKernelGGL(tileT_permute_kernel, dim3(dc_cdiv(LT.EP, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const float2*>(coef), planT + LT.o_edge, LT.EP, (unsigned)((long)num_points * k),
-                       reinterpret_cast<float2*>(coefTt));
+                       reinterpret_cast<const float2*>(coef), reinterpret_cast<const float2*>(coefB), planT + LT.o_edge, LT.EP,
+                       (unsigned)((long)num_points * k), reinterpret_cast<float2*>(coefTt), reinterpret_cast<float2*>(coefBTt));
     DC_CHECK_LAUNCH("dc_tile_plan_T_permute_coef");
     return DC_OK;
 }

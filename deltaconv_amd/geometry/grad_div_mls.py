@@ -5,6 +5,8 @@ defaults); the work is done by dc_tangent_basis / dc_estimate_basis / dc_mls_ass
 (deltaconv_amd/csrc/{basis,mls}.hip).  ``edge_index`` may be the reference's [2,E] tensor or a
 ``Graph``; operators come back as ``SparseOp`` (ELL coefficients, supports ``.size(i)`` and ``@``).
 """
+import weakref
+
 import torch
 
 from .._lib import lib, require_gpu
@@ -23,13 +25,19 @@ class SparseOp:
         self.kind, self.graph, self.coef = kind, graph, coef
         self._coefT = None
         self._coefTt = None
+        self._sibling = None
 
     def coefTt(self):
         """Coefficients in the TILE order of the graph's transposed tile plan (transposed applies from LDS); built once."""
         if self._coefTt is None:
             pt = self.graph.tile_plan_T()
             self._coefTt = torch.empty(pt.edges, 2, dtype=torch.float32, device=self.coef.device)
-            lib.call("dc_tile_plan_T_permute_coef", self.coef, pt.blob, *pt.args, self._coefTt)
+            sib = self._sibling() if self._sibling is not None else None   # grad and div of one build_grad_div call: one launch
+            if sib is not None and sib._coefTt is None and sib.graph is self.graph:
+                sib._coefTt = torch.empty_like(self._coefTt)
+                lib.call("dc_tile_plan_T_permute_coef", self.coef, sib.coef, pt.blob, *pt.args, self._coefTt, sib._coefTt)
+            else:
+                lib.call("dc_tile_plan_T_permute_coef", self.coef, None, pt.blob, *pt.args, self._coefTt, None)
         return self._coefTt
 
     def coefT(self):
@@ -116,4 +124,6 @@ def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel
         lib.call("dc_mls_assemble_shape", pos, normal.contiguous().float(), x_basis.contiguous().float(),
                  y_basis.contiguous().float(), g.nbr, g.ptr, g.num_clouds, n, g.max_cloud, g.k, float(kernel_width),
                  float(regularizer), float(shape_regularizer), int(bool(normalized)), G, D, ws, ws.numel() * 8)
-    return SparseOp("grad", g, G), SparseOp("div", g, D)
+    grad, div = SparseOp("grad", g, G), SparseOp("div", g, D)
+    grad._sibling, div._sibling = weakref.ref(div), weakref.ref(grad)
+    return grad, div

@@ -40,7 +40,8 @@ const char* dc_last_error(void);
  * the bf16 split products (three bf16 planes per fp32 operand, six partial products, fp32 accumulation: error against
  * fp64 no larger than the chain's); 4: first-round phase shift of every second 128 x 128 GEMM workgroup of a CU in
  * percent of a K loop (0 = default 50, negative = off); 5 / 6: force the weight-gradient tile (1..4) / slab count;
- * 7: units (tile x 64-channel slab) per workgroup of the persistent two-piece tiled applies (0 = launcher's choice). */
+ * 7: units (tile x 64-channel slab) per workgroup of the persistent two-piece tiled applies (0 = launcher's choice);
+ * 8: value 1 = CSC count / scan / fill by one workgroup per cloud (round 3) instead of eight column ranges per cloud. */
 int dc_set_option(int32_t key, int32_t value);
 
 /* ---- graph ------------------------------------------------------------------------------- */
@@ -177,8 +178,9 @@ int64_t dc_tile_plan_T_edge_offset(int32_t num_points, int32_t num_clouds, int32
 int dc_tile_plan_T_build(const int32_t* plan, const int32_t* tptr, const int32_t* tedge, const int32_t* cloud_ptr,
                          int32_t num_clouds, int32_t num_points, int32_t max_cloud, int32_t k, int32_t P, int32_t* planT,
                          void* stream);
-int dc_tile_plan_T_permute_coef(const float* coef, const int32_t* planT, int32_t num_points, int32_t num_clouds,
-                                int32_t num_tiles, int32_t k, int32_t P, float* coefTt, void* stream);
+int dc_tile_plan_T_permute_coef(const float* coef, const float* coefB, const int32_t* planT, int32_t num_points,
+                                int32_t num_clouds, int32_t num_tiles, int32_t k, int32_t P, float* coefTt, float* coefBTt,
+                                void* stream);   /* coefB / coefBTt (may be NULL): a second operator of the same graph in the same launch */
 int dc_apply_grad_T_tiled(const float* GTt, const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles,
                           int32_t k, int32_t P, const float* dy, int32_t C, int64_t ldy, float* dx, int64_t ldx,
                           int32_t accumulate, void* stream);

@@ -4,7 +4,7 @@ TAG=${1:-r04a}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 ulimit -c 0
-timeout 900 python -m pytest tests/test_gpu_tileT.py tests/test_gpu_tile.py tests/test_gpu_model.py -q --tb=short -p no:cacheprovider > $OUT/pytest_tileT.log 2>&1
+timeout 900 python -m pytest tests/test_gpu_tileT.py tests/test_gpu_tile.py tests/test_gpu_geometry.py tests/test_gpu_model.py -q --tb=short -p no:cacheprovider > $OUT/pytest_tileT.log 2>&1
 tail -15 $OUT/pytest_tileT.log
 grep -q passed $OUT/pytest_tileT.log && ! grep -q 'failed\|Aborted\|error' $OUT/pytest_tileT.log || exit 1
 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log > $OUT/bench.json
