@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--points", type=int, default=1024)
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-chain", action="store_true",
+                    help="skip the second timing of the same step with every dense product on the exact fp32 MFMA chain")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every kernel from Python each step instead of replaying the captured HIP graph")
@@ -130,6 +132,35 @@ def apply_roofline(graph, grad, div, C, iters=200):
         plan, graph._tile_plan = graph._tile_plan, False
         fam_gather = measure()
         graph._tile_plan = plan
+    # The headline kernel on ROTATING buffers: 12 (input, output) sets = 600 MB cycled through, so no launch finds its
+    # operands in the 256 MB Infinity Cache or the L2s -- the condition inside the training step, where every apply reads
+    # what another kernel wrote long before (the back-to-back replay above re-reads the same 50 MB: cache_level).
+    def _rotating(make_call, nbytes, sets=12, rounds=4):
+        calls = [make_call() for _ in range(sets)]
+        for c in calls:
+            c()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(rounds):
+                for c in calls:
+                    c()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / (4 * rounds * sets) * 1e-3
+        return dict(us=round(t * 1e6, 2), bytes=nbytes, GBs=round(nbytes / t / 1e9, 1), frac=round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+                    sets=sets, footprint_MB=round(sets * nbytes / 1e6))
+
+    def _mk_dcn():
+        vv, oo = torch.randn(2 * n, C, device=dev), torch.empty(n, 3 * C, device=dev)
+        return lambda: _ops.fwd_apply("div_curl_norm", div, vv, C, C, oo, 3 * C)
+    in_step = _rotating(_mk_dcn, 20 * C * n + 12 * E)
     tiled_T = graph.tile_plan_T() is not None
     if tiled_T:
         grad.coefTt(), div.coefTt()
@@ -211,6 +242,9 @@ def apply_roofline(graph, grad, div, C, iters=200):
                         "from the per-batch tile plan)" if tiled else
                         "divcurlnorm_fwd (dc_apply_div_curl_norm, fused ELL SpMM)"), channels=C,
                 bytes_per_launch=head["bytes"], us_per_launch=head["us"], family=fam, family_gather_path=fam_gather,
+                in_step=in_step,
+                in_step_note=("the headline kernel on 12 rotating (input, output) sets (600 MB): operands come from HBM as inside the "
+                              "training step; `frac` above is the back-to-back replay on one set"),
                 family_T=fam_T, family_T_gather_path=fam_T_gather,
                 family_T_note=("backward half: transposed applies + max-aggregation backward at the layer node's operand layouts "
                                "(accumulating outputs counted read + written), " +
@@ -370,6 +404,30 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     assert torch.isfinite(loss).item(), "loss is not finite"
+    # The same step with every dense product on the exact fp32 MFMA chain (option 3; bitwise an fmaf chain): the number the
+    # fp32-equivalence claim of the split products travels with.  Not `value`: reported beside it.
+    exact_ms = None
+    if world == 1 and not use_dist and not args.no_exact_chain and os.environ.get("DC_GEMM_EXACT", "0") in ("", "0"):
+        from deltaconv_amd._lib import lib as _lib
+        _lib.raw("dc_set_option")(3, 1)
+        try:
+            estep = eager_step
+            if not args.no_graph:
+                from deltaconv_amd.graph_step import GraphedTrainStep
+                g2 = GraphedTrainStep(model, calc_loss, static, optimizer=opt)
+                estep = lambda: g2(next_batch())
+            for _ in range(max(2, args.warmup)):
+                estep()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                estep()
+            torch.cuda.synchronize()
+            exact_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        except Exception as e:
+            print(f"[bench] exact-chain timing failed: {e!r}", file=sys.stderr)
+        finally:
+            _lib.raw("dc_set_option")(3, 0)
     if rank == 0:
         graph, grad, div = model.deltanet_base.build_operators(data)
         roof = apply_roofline(graph, grad, div, 64)
@@ -387,6 +445,7 @@ def main():
                                    + launch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": roof,
+            "exact_chain_ms_per_step": exact_ms,
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is timed at N=1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(args)

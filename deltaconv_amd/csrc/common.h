@@ -23,8 +23,18 @@ void dc_set_error(const char* fmt, ...);
         }                                     \
     } while (0)
 
+// Large dynamic LDS (> 64 KiB) needs a per-kernel, per-device opt-in: dc_ensure_lds() sets it once per device and, when the
+// device cannot give the bytes (anything but gfx950's 160 KiB per workgroup), records a clear message that the next
+// DC_CHECK_LAUNCH returns instead of an opaque launch failure.
+bool dc_ensure_lds(unsigned long long* done_mask, const void* kernel, size_t bytes, const char* what);
+bool dc_take_lds_failure();
+
 #define DC_CHECK_LAUNCH(name)                                                   \
     do {                                                                        \
+        if (dc_take_lds_failure()) {                                            \
+            (void)hipGetLastError();                                            \
+            return DC_ERR_LAUNCH;                                               \
+        }                                                                       \
         hipError_t e_ = hipGetLastError();                                      \
         if (e_ != hipSuccess) {                                                 \
             dc_set_error("%s: %s", name, hipGetErrorString(e_));                \

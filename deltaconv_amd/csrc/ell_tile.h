@@ -91,7 +91,7 @@ __global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const i
     }
     const int U = plan[L.o_nu + tile];
     if (U == 0) return;                                                   // empty tile (block-uniform)
-    const int UL = min(U, CAP), nrow = UL * R;
+    const int UL = min(min(U, CAP), PK), nrow = UL * R;                   // rows held in LDS (the plan lists at most P * k)
     int mypt = -1;
     unsigned short mysl = 0;
     if (tid < P) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const i
     const int c = cb + l16 * 4;
     body.init(c);
     Vec<4> s0 = vzero<4>(), s1 = vzero<4>();
-    if (U <= CAP) {
+    if (U <= UL) {
 #pragma unroll 4
         for (int s = 0; s < k; ++s) {
             const int l = lp[s];
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const i
         for (int s = 0; s < k; ++s) {
             const int l = lp[s];
             Vec<4> p0, p1;
-            if (l < CAP) {
+            if (l < UL) {
                 p0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
                 p1 = R == 2 ? *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4) : p0;
             } else {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
         asm volatile("" : "+v"(cur.mypt), "+v"(cur.U));
         asm volatile("" : "+v"(cur.cpt[0]), "+v"(cur.cpt[1]));
         const int U = __builtin_amdgcn_readfirstlane(cur.U);              // block-uniform
-        const int UL = min(U, CAP), nrow = UL * R;
+        const int UL = min(min(U, CAP), PK), nrow = UL * R;               // rows held in LDS (the plan lists at most P * k)
         // the next unit's tile: its ids travel while this unit's rows land (requested BEFORE the pieces: older than them)
         Ids nxt = cur;
         if (u + 1 < u1 && (u + 1) / slabs != tile) load_ids((u + 1) / slabs, nxt);
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
                 const int c = cb + l16 * 4;
                 body.init(c);
                 Vec<4> s0 = vzero<4>(), s1 = vzero<4>();
-                if (U <= CAP) {
+                if (U <= UL) {
 #pragma unroll 4
                     for (int s = 0; s < k; ++s) {
                         const int l = lp[s];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
                     for (int s = 0; s < k; ++s) {
                         const int l = lp[s];
                         Vec<4> p0, p1;
-                        if (l < CAP) {
+                        if (l < UL) {
                             p0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
                             p1 = R == 2 ? *reinterpret_cast<const Vec<4>*>(rows + (l * R + R - 1) * 64 + l16 * 4) : p0;
                         } else {
@@ -453,15 +453,11 @@ template <int R, int P, class BODY>
 inline void launch_one(const DcTilePlan& L, const int* plan, const float* coef, const int* nbr, int C, BODY body, hipStream_t s) {
     const int slabs = C / CS;
     const size_t lds = lds_bytes<R, P>(L.k, BODY::COEF);
-    static bool attr_set = false;                       // > 64 KiB of dynamic LDS needs the attribute once per kernel
-    if (!attr_set) {
-        if constexpr (R == 1)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_unit_kernel<R, P, BODY>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        else
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fwd_kernel<R, P, BODY>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    static unsigned long long attr_set = 0;             // > 64 KiB of dynamic LDS needs the attribute once per kernel and device
+    if constexpr (R == 1) {
+        if (!dc_ensure_lds(&attr_set, reinterpret_cast<const void*>(&tile_unit_kernel<R, P, BODY>), 160 * 1024, "tiled apply")) return;
+    } else {
+        if (!dc_ensure_lds(&attr_set, reinterpret_cast<const void*>(&tile_fwd_kernel<R, P, BODY>), 160 * 1024, "tiled apply")) return;
     }
     const long units = (long)L.T * slabs;
     if constexpr (R == 1) {

@@ -326,12 +326,8 @@ template <int R, int P, class BODY>
 inline void launch_one(const DcTilePlanT& L, const int* plan, const float* coefT, int C, BODY body, hipStream_t s) {
     const int slabs = C / CS;
     const size_t lds = lds_bytes<R, P>(BODY::COEF, BODY::ARG);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tileT_kernel<R, P, BODY>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    static unsigned long long attr_set = 0;             // > 64 KiB of dynamic LDS: once per kernel and device (common.h)
+    if (!dc_ensure_lds(&attr_set, reinterpret_cast<const void*>(&tileT_kernel<R, P, BODY>), 160 * 1024, "tiled transposed apply")) return;
     const long units = (long)L.T * slabs;
     const long per_cu = std::max<long>(1, std::min<long>(2048 / (P * 16), (160 * 1024) / (long)lds));
     const long capacity = per_cu * dctile::device_cus();

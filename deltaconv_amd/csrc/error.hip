@@ -22,3 +22,27 @@ DC_EXPORT int dc_set_option(int32_t key, int32_t value) {
     g_opt[key] = value;
     return DC_OK;
 }
+
+// ---- dynamic LDS opt-in (common.h) ---------------------------------------------------------------------------------------
+static thread_local bool g_lds_failed = false;
+bool dc_take_lds_failure() {
+    const bool f = g_lds_failed;
+    g_lds_failed = false;
+    return f;
+}
+bool dc_ensure_lds(unsigned long long* done_mask, const void* kernel, size_t bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const unsigned long long bit = dev < 64 ? 1ull << dev : 0ull;
+    if (bit && (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit)) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dc_set_error("%s: needs %zu KiB of LDS per workgroup (MI355X / gfx950 offers 160 KiB); device %d refused: %s", what,
+                     bytes / 1024, dev, hipGetErrorString(e));
+        g_lds_failed = true;
+        return false;
+    }
+    if (bit) __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return true;
+}

@@ -864,13 +864,9 @@ size_t lds_bytes(int bm, int bn, int al, int bl) {
 
 template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO, int X3>
 void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
-    static bool configured = false;
+    static unsigned long long configured = 0;
     const size_t lds = lds_bytes(BM, BN, AL, BL);
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
+    if (!dc_ensure_lds(&configured, reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>), lds, "dense product")) return;
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>),
                        dim3((unsigned)(tiles_m * p.tiles_n) + (unsigned)p.red_blocks, (unsigned)slabs), dim3(NT), lds, s, p);
 }

@@ -147,11 +147,9 @@ int launch_knn(const float* pos, const int* cloud_ptr, int num_clouds, int max_c
     constexpr int Q = KNN_THREADS / P;
     size_t lds = 3 * KNN_TILE * sizeof(float);
     if (P > 1) lds += (size_t)KNN_THREADS * K * 8;
-    static bool attr_done = false;
-    if (!attr_done) {  // > 64 KiB of dynamic LDS needs an explicit opt-in
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_kernel<K, P>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
+    static unsigned long long attr_done = 0;   // > 64 KiB of dynamic LDS needs an explicit opt-in (per kernel and device)
+    if (!dc_ensure_lds(&attr_done, reinterpret_cast<const void*>(&knn_kernel<K, P>), lds, "dc_knn")) {
+        DC_CHECK_LAUNCH("dc_knn");
     }
     dim3 grid(dc_cdiv(max_cloud, Q), num_clouds);
     hipLaunchKernelGGL((knn_kernel<K, P>), grid, dim3(KNN_THREADS), lds, stream, pos, cloud_ptr, k, nbr);

@@ -294,11 +294,10 @@ DC_EXPORT int dc_rowblock_forward(const float* X, int64_t ldx, const float* W, i
     DC_REQUIRE(mode != 1 || M > 1, "dc_rowblock_forward: batch statistics need more than one row");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = 128 * 1024;              // KS staging areas: 4 x [32][64] or 2 x [64][64] float4
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_fwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_fwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+    static unsigned long long attr2 = 0, attr1 = 0;
+    if (!(M <= 32 ? dc_ensure_lds(&attr2, reinterpret_cast<const void*>(&rowblock_fwd_kernel<2>), lds, "dc_rowblock_forward")
+                  : dc_ensure_lds(&attr1, reinterpret_cast<const void*>(&rowblock_fwd_kernel<1>), lds, "dc_rowblock_forward"))) {
+        DC_CHECK_LAUNCH("dc_rowblock_forward");
     }
     if (M <= 32)
         hipLaunchKernelGGL((rowblock_fwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB * 4), lds, s, X, (long)ldx, W, (long)ldw, bias, M, N, K,
@@ -324,11 +323,10 @@ DC_EXPORT int dc_rowblock_backward(const float* dY, int64_t lddy, const float* H
     DC_REQUIRE(mode >= 0 && mode <= 2, "dc_rowblock_backward: bad mode");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t lds = 128 * 1024;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_bwd_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowblock_bwd_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
+    static unsigned long long attr2 = 0, attr1 = 0;
+    if (!(M <= 32 ? dc_ensure_lds(&attr2, reinterpret_cast<const void*>(&rowblock_bwd_kernel<2>), lds, "dc_rowblock_backward")
+                  : dc_ensure_lds(&attr1, reinterpret_cast<const void*>(&rowblock_bwd_kernel<1>), lds, "dc_rowblock_backward"))) {
+        DC_CHECK_LAUNCH("dc_rowblock_backward");
     }
     if (M <= 32)
         hipLaunchKernelGGL((rowblock_bwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB * 2), lds, s, dY, (long)lddy, H, (long)ldh, coef, gamma,

@@ -10,7 +10,8 @@
 // The plan depends only on positions + graph, is built once per batch beside the CSC (tileplan.hip) and is one
 // int32 device blob whose section offsets follow from (num_points, num_clouds, k, P):
 //   pts  [T][P]     int32   point ids of the tile in Morton order, -1 = padding (last tile of a cloud / unused tile)
-//   nu   [T]        int32   number of unique rows U of the tile (0 = empty tile)
+//   nu   [T]        int32   number of unique rows U of the tile (0 = empty tile; may exceed P*k when points are not their own
+//                           neighbours: uniq then lists the first P*k and the kernels fetch the other rows by neighbour id)
 //   uniq [T][P*k]   int32   the unique row ids, ascending (the tile's own points are members); tail = last id
 //   loc  [T][P*k]   uint16  tile-local index of neighbour (p, s) in uniq
 //   self [T][P]     uint16  tile-local index of the point itself

@@ -208,9 +208,9 @@ __global__ __launch_bounds__(256) void tile_unique_kernel(const int* __restrict_
     // (U <= P + P*k can exceed the uniq section by at most P entries when a point is not its own neighbour, i.e.
     //  more than k coincident points; the section holds P*k: such a tile keeps its first P*k rows in the list and the
     //  kernels fetch rows whose local index is not below min(U, P*k, capacity) from global memory by id -- see
-    //  ell_tile.h.  nu is stored clamped.)
+    //  ell_tile.h.  nu holds the unclamped count: a tile with U > min(P*k, capacity) takes the kernels' by-id path.)
     const int Uc = min(U, PK);
-    if (tid == 0) plan[L.o_nu + t] = Uc;
+    if (tid == 0) plan[L.o_nu + t] = U;                     // the TRUE count: the kernels compare it with what they hold
     int* uq_g = plan + L.o_uniq + (long)t * PK;
     for (int q = tid; q < PK; q += 256) uq_g[q] = uq[min(q, Uc - 1)];
     unsigned short* loc_g = reinterpret_cast<unsigned short*>(plan + L.o_loc) + (long)t * PK;

@@ -160,6 +160,13 @@ class Graph:
         apply or does not pay: positions unknown, clouds beyond the builder's limit, k > 24, fewer than 8192 points, or
         the switch is off.  force_P = 32 | 64 builds a plan regardless of the pay-off heuristic."""
         if force_P is not None and (self._tile_plan is None or not self._tile_plan or self._tile_plan.P != force_P):
+            # (tests / A-B runs) the same applicability checks as the policy path, as errors instead of a silent None
+            if self.pos is None or not self.nbr.is_cuda:
+                raise ValueError("tile_plan(force_P): the graph has no positions (Morton order) or is not on a HIP device")
+            if force_P not in (32, 64) or self.k % 2 or self.k < 2 or force_P * self.k > 2048 or self.n == 0:
+                raise ValueError(f"tile_plan(force_P={force_P}): needs P in (32, 64), k even, P * k <= 2048 (k = {self.k})")
+            if self.max_cloud > int(lib.raw("dc_tile_plan_max_cloud")()):
+                raise ValueError(f"tile_plan(force_P): clouds of more than {int(lib.raw('dc_tile_plan_max_cloud')())} points")
             words = int(lib.raw("dc_tile_plan_words")(int(lib.raw("dc_tile_plan_tiles")(self.n, self.num_clouds, self.max_cloud, force_P)), self.k, force_P))
             blob = torch.empty(words, dtype=torch.int32, device=self.nbr.device)
             lib.call("dc_tile_plan_build", self.pos, self.nbr, self.ptr, self.num_clouds, self.n, self.max_cloud,

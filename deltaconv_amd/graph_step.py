@@ -68,6 +68,9 @@ class GraphedTrainStep:
             self.loss, self.out = self._step(capture=True)
         torch.cuda.synchronize()
         if self.reducer is not None:            # graph B: scale + update, reading .grad = views of the flat buffer
+            # the graphs hold the ADDRESS of the flat buffer that exists now: keep it, and notice when an eager
+            # reduce_gradients() / pack() with another parameter set made the reducer allocate a new one
+            self.flat = self.reducer.flat
             self.reducer.repoint()
             self.graph_update = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_update):
@@ -112,6 +115,10 @@ class GraphedTrainStep:
             self.load(batch)
         self.graph.replay()
         if self.graph_update is not None:
+            if self.reducer.flat is not self.flat:
+                raise RuntimeError("GraphedTrainStep: the gradient reducer re-allocated its flat buffer after capture (an eager "
+                                   "reduce_gradients() with a different set of live parameters); the captured graphs still use "
+                                   "the old one -- build a new GraphedTrainStep")
             self.reducer.all_reduce()           # the one collective of the step, between the two replays
             self.graph_update.replay()
         invalidate_eval_coeffs()      # the replay moved running statistics (and parameters) without a version bump

@@ -137,7 +137,11 @@ class DeltaConv(torch.nn.Module):
         x_edge = (x[nbr] - x.unsqueeze(1)).reshape(n * k, x.shape[1])
         h = self.s_mlp_max(x_edge).view(n, k, -1)                   # edges are centre-major, k contiguous
         if self.aggr == 'max':
-            return h.max(dim=1).values
+            vals, idx = h.max(dim=1)
+            from . import layer as _layer
+            if _layer.SLOT_TAP[0] is not None:          # test hook (layer.py)
+                _layer.SLOT_TAP[0].append(idx.to(torch.uint8))
+            return vals
         if self.aggr == 'min':
             return h.min(dim=1).values
         return h.mean(dim=1) if self.aggr == 'mean' else h.sum(dim=1)

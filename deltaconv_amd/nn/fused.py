@@ -351,8 +351,10 @@ def gemm_tn(a, b):
     # measured (profiles/r01i_kernels.log, r01n, gpurun r02c): the MFMA kernels win or tie against the TUNED library
     # up to 256K outputs (e.g. 256x128: 31 vs 62 us; 512x256: 91 vs 88 us; 64x64: 11 vs 10 us) and by 5-18x against
     # its default heuristic (448x256: 1.5 ms); the 1024x512 embedding is ~4 % behind the tuned library (312 vs ~300 us)
-    # and ahead of the untuned one.  Only per-cloud problems (few rows) stay with the library.
-    if (USE_MFMA_TN and a.is_cuda and r >= 8192 and m * n <= OWN_TN_MAX_OUTPUTS
+    # and ahead of the untuned one.  Round 4: EVERY row count runs here (the kernel guards ragged shapes): the library's fp32
+    # product came back 7e-3 off at [4096, 128]^T [4096, 256] (a reduced-precision algorithm: the pinned-slot gradient test
+    # of tests/test_gpu_configs.py caught it on the 2-cloud ShapeNet step) -- no vendor GEMM is reachable for fp32 GPU inputs.
+    if (USE_MFMA_TN and a.is_cuda and r >= 1 and m * n <= OWN_TN_MAX_OUTPUTS
             and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
         nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, n)
@@ -364,7 +366,7 @@ def gemm_tn(a, b):
 
 # ---- dense products of the per-point Linear layers: hand-written fp32-MFMA kernels (csrc/gemm.hip) --------------
 USE_OWN_GEMM = True        # A/B switch: False = vendor library (torch.mm) for the forward / input-gradient products
-OWN_GEMM_MIN_ROWS = 1024   # per-cloud rows (classification head: B rows) stay with the library: launch-latency bound
+OWN_GEMM_MIN_ROWS = 1      # every row count (<= 64 rows normally run on csrc/rowblock.hip before they get here); the kernels guard ragged shapes
 
 
 # Every per-point product runs on the hand-written kernels, the embedding MLP included: against the per-shape TUNED
@@ -585,9 +587,15 @@ ROWBLOCK_MAX_ROWS = 64
 USE_ROWBLOCK = True        # A/B switch: False = the composed path (library GEMM + statistics + finaliser + activation)
 
 
+def _rows16(t):
+    """rows of a row-major fp32 matrix start on 16-byte boundaries (what dc_rowblock_* require of X and W)"""
+    return t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
 def _rowblock_ok(x, w):
     return (USE_ROWBLOCK and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
-            and 1 <= x.shape[0] <= ROWBLOCK_MAX_ROWS and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and sync_group() is None)
+            and 1 <= x.shape[0] <= ROWBLOCK_MAX_ROWS and x.shape[1] % 4 == 0 and x.shape[1] >= 4 and sync_group() is None
+            and _rows16(x) and _rows16(w))
 
 
 def _rowblock_dx(dh, w):

@@ -33,6 +33,9 @@ from .. import _ops
 from . import fused
 
 _F32 = torch.float32
+# Test hook: a list here receives, per DeltaConv layer in call order, a copy of the slot the max aggregation selected per
+# (point, channel) -- tests pin the CPU oracle to the same selection (tests/test_gpu_configs.py: pinned-slot gradients).
+SLOT_TAP = [None]
 
 
 def _rows(t):
@@ -176,12 +179,16 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], slope_m,
                      x_max, co, argsel)
                 max_saved = (stat, args, argsel)
+                if SLOT_TAP[0] is not None:
+                    SLOT_TAP[0].append(argsel.clone())
                 saved_m.append((inp, y0, coef_m, use_m))
             else:
                 hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
                 arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
                 _ops.fwd_knn_max(g, hm, co, co, x_max, co, arg, affine=(coef_m[2], coef_m[3], slope_m))
                 max_saved = (arg,)
+                if SLOT_TAP[0] is not None:
+                    SLOT_TAP[0].append(arg.clone())
                 saved_m.append((inp, hm, coef_m, use_m))
 
         # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)

@@ -71,6 +71,10 @@ class DeltaConv(tnn.Module):
         super().__init__()
         assert aggr in ('max', 'min', 'sum', 'add', 'mean')            # torch_scatter reduce names (deltaconv.py:52,54)
         self.aggr = aggr
+        # test hook: [Nt, C] slot per (point, channel) that the max aggregation must take instead of its own arg-max
+        # (tests pin both sides of a comparison to the same selection: gradients of a max are piecewise, a near-tie that
+        # flips under rounding otherwise dominates every gradient comparison)
+        self.pinned_slots = None
         self.in_channels, self.out_channels, self.centralized = in_channels, out_channels, centralized
         self.s_mlp_max = MLP([in_channels] + [out_channels] * depth)
         self.s_mlp = MLP([in_channels * 4] + [out_channels] * depth)
@@ -79,6 +83,8 @@ class DeltaConv(tnn.Module):
     def _reduce(self, h):
         """scatter(..., reduce=aggr) over the k contiguous edges of every centre point: h [Nt, k, C] -> [Nt, C]."""
         if self.aggr == 'max':
+            if self.pinned_slots is not None:
+                return h.gather(1, self.pinned_slots.long()[:, None, :]).squeeze(1)
             return h.max(dim=1).values
         if self.aggr == 'min':
             return h.min(dim=1).values

@@ -236,6 +236,91 @@ def test_split_products_no_worse_than_exact_chain(M, N, K, binades):
     assert not torch.equal(split["fwd"], exact["fwd"])            # 128-column tiles: the split path ran
 
 
+@pytest.mark.parametrize("M", [65, 333, 1000, 4096])
+@pytest.mark.parametrize("N,K", [(128, 256), (50, 70)])
+def test_small_row_counts_run_on_the_own_kernels(M, N, K):
+    """Products with few rows (a single small cloud; 2 clouds of a segmentation net) through the Python dispatch of
+    nn/fused.py: forward, input gradient, weight gradient against fp64 at fp32 accuracy.  Until round 4 row counts below
+    1024 (forward / input gradient) and 8192 (weight gradient) went to the vendor library, whose fp32 product at
+    [4096, 128]^T [4096, 256] came back 7e-3 off (tests/test_gpu_configs.py::test_pinned_slots_step_vs_oracle[C4])."""
+    from deltaconv_amd.nn import fused
+    g = torch.Generator().manual_seed(M + N)
+    x, dy = torch.randn(M, K, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    import unittest.mock as mock
+    with mock.patch.object(torch, "mm", side_effect=AssertionError("vendor GEMM reached")), \
+            mock.patch.object(torch.Tensor, "__matmul__", side_effect=AssertionError("vendor GEMM reached")):
+        y, dx, dw = fused.mm_nt(x, w), fused.mm_nn(dy, w), fused.gemm_tn(dy, x)
+    assert rel_err(y, x.double() @ w.double().t()) < _tol(K)
+    assert rel_err(dx, dy.double() @ w.double()) < _tol(N)
+    assert rel_err(dw, dy.double().t() @ x.double()) < _tol(M)
+
+
+@pytest.mark.parametrize("log2_scale", [-100, -120, 100])
+def test_split_products_extreme_scales(log2_scale):
+    """Split products on operands far from 1 (round-3 verdict: the edges of the three-plane split were untested).
+    bfloat16 shares fp32's exponent range, so the split is scale-invariant as long as the THIRD plane (2^-16 of the
+    operand) stays a normal number: at 2^-100 and 2^+100 the error bound of the O(1) test holds unchanged.  Below ~2^-110
+    the third plane is a bf16 subnormal; the measured error is printed and must stay within 2^-15 of the product scale
+    (the two leading planes) -- documented in DESIGN.md section 3, gradients of that magnitude do not occur in the step."""
+    M, N, K = 8192, 128, 256
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(M, K, generator=g) * 2.0 ** log2_scale).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+    assert bool(torch.isfinite(x).all()) and float(x.abs().max()) > 0
+    ref = x.double() @ w.double().t()
+    opt = lib.raw("dc_set_option")
+    ys = {}
+    try:
+        for name, o in (("exact", 1), ("split", 0)):
+            opt(3, o)
+            y = torch.empty(M, N, device=DEV)
+            lib.call("dc_linear_forward", x, K, w, K, M, N, K, y, N, 0)
+            ys[name] = y
+    finally:
+        opt(3, 0)
+    e_exact, e_split = rel_err(ys["exact"], ref), rel_err(ys["split"], ref)
+    print(f"scale 2^{log2_scale}: exact chain {e_exact:.3e}  split {e_split:.3e}")
+    assert bool(torch.isfinite(ys["split"]).all())
+    if log2_scale > -110:
+        assert e_split < 1.5 * e_exact + 1e-7
+    else:
+        assert e_split < 2.0 ** -15
+
+
+def test_split_products_nonfinite_operands():
+    """inf / values beyond the bfloat16 range in an operand: the documented behaviour.  The row that
+    holds the value comes back non-finite (NaN from inf - inf in the residual planes, where the exact chain returns +-inf);
+    every other row is bit-identical to the product without it -- nothing leaks across rows."""
+    M, N, K = 4096, 128, 128
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV)
+
+    def fwd(xx):
+        y = torch.empty(M, N, device=DEV)
+        lib.call("dc_linear_forward", xx, K, w, K, M, N, K, y, N, 0)
+        return y
+    clean = fwd(x)
+    for bad in (float("inf"), -float("inf"), 3.4e38):
+        xb = x.clone()
+        xb[5, 7] = bad
+        y = fwd(xb)
+        assert not bool(torch.isfinite(y[5]).any()), bad
+        keep = torch.ones(M, dtype=torch.bool, device=DEV)
+        keep[5] = False
+        assert torch.equal(y[keep], clean[keep]), bad
+    opt = lib.raw("dc_set_option")
+    try:
+        opt(3, 1)
+        xb = x.clone()
+        xb[5, 7] = float("inf")
+        y = fwd(xb)
+        assert bool(torch.isinf(y[5]).all())                       # the exact chain: inf * w (w has no exact zeros)
+    finally:
+        opt(3, 0)
+
+
 @pytest.mark.parametrize("R,N,K", [(32768, 128, 256), (32768, 1024, 448), (16384, 64, 64), (9000, 40, 70), (8192, 256, 12)])
 @pytest.mark.parametrize("bn", [False, True])
 @pytest.mark.parametrize("acc", [0, 1])

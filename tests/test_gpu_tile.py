@@ -187,6 +187,41 @@ def test_tiled_overflow_tiles(k):
           torch.empty(n, C, device=DEV), torch.empty(n, C, dtype=torch.uint8, device=DEV))
 
 
+@pytest.mark.parametrize("k,P", [(2, 64), (4, 32)])
+def test_tiled_more_unique_rows_than_the_plan_lists(k, P):
+    """A user graph WITHOUT self loops and a small k: a tile of P points can have up to P + P*k unique rows while the plan
+    lists P*k (< the LDS capacity here: 128 rows).  The plan stores the true count; such tiles take the by-id path for the
+    rows the list does not hold (round-3 advisor finding: the count used to be clamped and the kernels read stale LDS)."""
+    from deltaconv_amd._lib import lib
+    from deltaconv_amd.geometry import Graph
+    from deltaconv_amd.geometry.grad_div_mls import SparseOp
+    torch.manual_seed(k)
+    n = 1024
+    pos = torch.randn(n, 3)
+    idx = torch.arange(n)
+    nbr = torch.stack([(idx + 37 * (s + 1) + (idx % 5)) % n for s in range(k)], 1).to(torch.int32)   # never the point itself
+    assert not bool((nbr == idx[:, None]).any())
+    ei = torch.stack([idx.repeat_interleave(k), nbr.reshape(-1).long()]).to(DEV)
+    gr = Graph.from_edge_index(ei, n, k=k)
+    gr.pos = pos.to(DEV)
+    plan = gr.tile_plan(force_P=P)
+    assert int(plan.section("nu").max()) > P * k                       # more unique rows than the list holds
+    C = 64
+    coef = _rand(n, k, 2)
+    grad, div = SparseOp("grad", gr, coef), SparseOp("div", gr, coef.flip(2).contiguous())
+    x, v = _rand(n, C), _rand(2 * n, C)
+    a = plan.args
+    _pair(lambda o: lib.call("dc_apply_grad", grad.coef, gr.nbr, n, k, x, C, C, o, C),
+          lambda o: lib.call("dc_apply_grad_tiled", grad.coef, plan.blob, gr.nbr, *a, x, C, C, o, C),
+          torch.empty(2 * n, C, device=DEV))
+    _pair(lambda o: lib.call("dc_apply_div_curl_norm", div.coef, gr.nbr, n, k, v, C, C, o, 3 * C),
+          lambda o: lib.call("dc_apply_div_curl_norm_tiled", div.coef, plan.blob, gr.nbr, *a, v, C, C, o, 3 * C),
+          torch.empty(n, 3 * C, device=DEV))
+    _pair(lambda o, ar: lib.call("dc_knn_max", gr.nbr, n, k, x, C, C, o, C, ar),
+          lambda o, ar: lib.call("dc_knn_max_tiled", plan.blob, gr.nbr, *a, x, C, C, o, C, ar),
+          torch.empty(n, C, device=DEV), torch.empty(n, C, dtype=torch.uint8, device=DEV))
+
+
 @pytest.mark.parametrize("kind", ["cls", "seg"])
 def test_model_identical_with_and_without_plan(kind):
     """Train-mode forward + backward of whole models: logits and every parameter gradient identical bit for bit with the
