@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every kernel from Python each step instead of replaying the captured HIP graph")
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct synthetic batches cycled through")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="BatchNorm statistics over the global batch (all-reduced fp64 sums); the data-parallel step is then ONE "
+                         "graph with its collectives captured")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
     return ap.parse_args()
@@ -340,7 +343,7 @@ def main():
 
     torch.manual_seed(1)
     model = dc.models.DeltaNetClassification(3, 40, num_neighbors=args.k).to(dev).train()
-    ddp = FlatGradDataParallel(model, always_reduce=args.force_dist)
+    ddp = FlatGradDataParallel(model, always_reduce=args.force_dist, sync_bn=args.sync_bn and use_dist)
     # train_modelnet.py:67 hyper-parameters; fused=True = the same update as one multi-tensor kernel
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
     # Inputs resident in HBM before the timed region; every step consumes a different batch.
@@ -380,7 +383,9 @@ def main():
 
             def step():
                 return gstep(next_batch())
-            launch = "HIP-graph replay" if not use_dist else "HIP-graph replay x2 around the gradient all-reduce"
+            launch = ("HIP-graph replay" if not use_dist else
+                      "one HIP graph with the BatchNorm-statistics and gradient all-reduces captured" if gstep.capture_collectives
+                      else "HIP-graph replay x2 around the gradient all-reduce")
         except Exception as e:                               # keep measuring (eagerly) and say so in the output
             print(f"[bench] HIP-graph capture failed, falling back to eager launches: {e!r}", file=sys.stderr)
             torch.cuda.synchronize()

@@ -35,7 +35,7 @@ using dctile::CS;
 using dctile::dma16;
 using dctile::Geom;
 
-constexpr int ECAP = 2048;   // in-edge entries of a tile kept in LDS (mean P * k = 1280 at P = 64, k = 20)
+constexpr int ECAP = 2560;   // in-edge entries of a tile kept in LDS (mean P * k: 1280 at P = 64, k = 20; 1920 at k = 30)
 
 template <int FAMILY>
 __device__ __forceinline__ void st16(float* p, const Vec<4>& a) { dc_store16<FAMILY>(p, *reinterpret_cast<const dc_f32x4*>(&a)); }

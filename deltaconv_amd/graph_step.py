@@ -30,21 +30,31 @@ _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 
 
 class GraphedTrainStep:
-    def __init__(self, model, loss_fn, sample_batch, optimizer=None, warmup=3, reducer=None):
+    def __init__(self, model, loss_fn, sample_batch, optimizer=None, warmup=3, reducer=None, capture_collectives=None):
         """sample_batch: a deltaconv_amd.Batch on the GPU whose tensors become the static inputs.
         optimizer: captured into the graph when given (its first `warmup` steps are real updates, so
         lazily created state such as momentum buffers exists before the capture).
         reducer: a dp.FlatGradDataParallel whose all-reduce runs between TWO captured graphs -- graph A = forward +
         loss + backward + the gradient pack into the flat buffer, graph B = the 1/world scale + the optimizer update
         on views of that buffer: a data-parallel step is replay -> all-reduce -> replay, three host calls instead of
-        the eager pack / div / multi-tensor-update launches behind every replay (1-2 clouds per rank: host-bound)."""
+        the eager pack / div / multi-tensor-update launches behind every replay (1-2 clouds per rank: host-bound).
+        capture_collectives: ONE graph holding the whole data-parallel step, collectives included -- the statistics
+        all-reduces of synchronised BatchNorm inside forward and backward, the gradient all-reduce, the scale and the
+        optimizer update (round 4: RCCL collectives are capturable when the capture runs in `thread_local` error mode --
+        the process group's watchdog thread queries events, which a global-mode capture forbids).  Default: on when the
+        reducer synchronises BatchNorm statistics (that step cannot be split around its ~40 collectives: eager it is
+        host-bound at 9-13 ms for one or two clouds per rank, captured 2.8-4.5 ms: profiles/r04_dp_proxy.txt), off
+        otherwise (the two-graph form keeps the one gradient all-reduce an ordinary eager collective)."""
         if os.environ.get(_FLAG, "1") != "0":
             raise RuntimeError(f"GraphedTrainStep needs {_FLAG}=0 in the environment before the HIP runtime "
                                "starts (import deltaconv_amd before the first torch.cuda call, or export it)")
         self.model, self.loss_fn, self.optimizer = model, loss_fn, optimizer
         self.reducer = reducer if (reducer is not None and reducer.active()) else None
         if self.reducer is not None:
-            assert optimizer is not None, "the two-graph data-parallel step captures the optimizer update"
+            assert optimizer is not None, "the data-parallel graph step captures the optimizer update"
+        if capture_collectives is None:
+            capture_collectives = bool(self.reducer is not None and getattr(self.reducer, "sync_bn", False))
+        self.capture_collectives = bool(capture_collectives and self.reducer is not None)
         self.static = sample_batch
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.warmup = warmup
@@ -64,6 +74,14 @@ class GraphedTrainStep:
         self._zero()
         self.graph = torch.cuda.CUDAGraph()
         self.graph_update = None
+        if self.capture_collectives:            # the whole data-parallel step, collectives included, in one graph
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss, self.out = self._step(capture=False)
+            torch.cuda.synchronize()
+            self.flat = self.reducer.flat
+            invalidate_eval_coeffs()
+            self.grads = [(p, p.grad) for p in self.params if p.grad is not None]
+            return
         with torch.cuda.graph(self.graph):
             self.loss, self.out = self._step(capture=True)
         torch.cuda.synchronize()

@@ -66,7 +66,7 @@ def _sync_stats(kernel_args, c, rows, dev, group):
     Returns (global stats, local stats)."""
     from .. import dp
     local = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-    local[2 * c] = float(rows)
+    local[2 * c:].fill_(float(rows))          # (a fill kernel: `local[i] = x` is a host-to-device copy, not capturable)
     name, args = kernel_args
     lib.call(name, *args(local))
     return dp.all_reduce_stats(local.clone(), group), local

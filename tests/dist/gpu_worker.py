@@ -7,6 +7,7 @@ RCCL process group with one rank, so every collective code path executes.
      scale + optimizer update captured as a second graph, the all-reduce between the replays == eager, bit-identical.
   2. sync_bn=True (split statistics kernels + all-reduce of the fp64 sums, composed layer path) on one rank
      == per-rank statistics (fused layer path): logits / gradients agree to fp32 rounding.
+  3. the sync_bn step captured in ONE graph (statistics + gradient collectives inside) == the same steps eagerly, bit-identical.
 Prints one JSON line."""
 import json
 import os
@@ -98,7 +99,31 @@ def main():
     rb3 = {n: t for n, t in m3.named_buffers() if "running" in n}
     rb4 = {n: t for n, t in m4.named_buffers() if "running" in n}
     res["sync_running_err"] = max(float((rb3[n] - rb4[n]).abs().max() / rb3[n].abs().max().clamp_min(1e-6)) for n in rb3)
-    print(json.dumps(res))
+    # ---- 3. synchronised BatchNorm INSIDE ONE GRAPH (round 4): forward + backward with their statistics all-reduces, the
+    # gradient all-reduce, scale and optimizer update captured together == the same steps run eagerly, bit for bit
+    m6, o6 = make(seed=7)
+    d6 = dp.FlatGradDataParallel(m6, always_reduce=True, sync_bn=True)
+    for b_ in [batches[0]] * 2 + batches:
+        d6.zero_grad()
+        calc_loss(d6(b_), b_.y).backward()
+        d6.reduce_gradients()
+        o6.step()
+    m7, o7 = make(seed=7)
+    d7 = dp.FlatGradDataParallel(m7, always_reduce=True, sync_bn=True)
+    static7 = synthetic_batch(4, 256, seed=60).to("cuda")
+    step7 = GraphedTrainStep(m7, calc_loss, static7, optimizer=o7, warmup=2, reducer=d7)
+    assert step7.capture_collectives and step7.graph_update is None
+    for b_ in batches:
+        step7(b_)
+    dp.set_sync_bn(False)
+    sd6, sd7 = m6.state_dict(), m7.state_dict()
+    res["sync_graph_mismatches"] = [k for k in sd6 if not torch.equal(sd6[k], sd7[k])]
+    print(json.dumps(res), flush=True)
+    # graphs that hold captured collectives go before the communicator does
+    del step7, step5, step
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
 

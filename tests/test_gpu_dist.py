@@ -41,6 +41,22 @@ def test_graph_replay_with_gradient_reducer_and_sync_bn():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["graph_dp_mismatches"] == []
     assert d["two_graph_dp_mismatches"] == []
+    assert d["sync_graph_mismatches"] == []          # sync_bn step with its collectives captured in one graph == eager
     # (gradients: the synchronised path runs the composed blocks, the per-rank path the fused layer nodes; with
     # max-aggregation a near-tie can pick another neighbour under different fp32 rounding -- measured 9e-3)
     assert d["sync_logits_err"] < 1e-4 and d["sync_grad_err"] < 3e-2 and d["sync_running_err"] < 1e-5, d
+
+
+def test_sync_bn_world2_on_one_gpu_equals_single_process():
+    """Two ranks (gloo, both on the one GPU of the test box), each with half of the batch and sync_bn=True: the HIP
+    synchronised-BatchNorm path (split statistics kernels, all-reduced fp64 sums, gradients averaged by the flat
+    all-reduce) reproduces ONE process on the full batch -- /root/reference/deltaconv/nn/nonlin.py:24-35 semantics of the
+    global batch: logits 2e-4, gradients (L1 per parameter) 5e-3, running statistics 1e-5; the replicas stay bit-equal."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tests", "dist", "gpu_worker2.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["logits_err"] < 2e-4 and d["grad_l1_err"] < 5e-3 and d["running_err"] < 1e-5, d
+    assert d["replicas_equal"] and d["params_after_step_err"] < 2e-2, d     # (one SGD step from zero-initialised biases: = the gradient error)
