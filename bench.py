@@ -94,7 +94,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
     def measure(passes=2, cases=None):
         cases = cases or cases_F
         # two passes over the family, the second one reported: the first replay series of a case in a process runs
-        # 1 - 1.5 us slower than every later one (r03 lab, tools/tile_upw.py: 14.6 then 13.1 x 7 for the fused apply --
+        # 1 - 1.5 us slower than every later one (r03 lab, tools/archive/tile_upw.py: 14.6 then 13.1 x 7 for the fused apply --
         # fresh allocations / cold translation caches), and the training step launches these kernels every iteration
         out = {}
         for rep in range(passes):

@@ -467,7 +467,7 @@ inline void launch_one(const DcTilePlan& L, const int* plan, const float* coef, 
     const long per_cu = std::max<long>(1, std::min<long>(2048 / (P * 16), (160 * 1024) / (long)lds));
     const long capacity = per_cu * device_cus();
     // units per workgroup: fill the resident slots once; at least 2 as soon as that still leaves a workgroup per CU (the second
-    // unit's ids ride on the first one's pieces: -8 .. -11 % per launch at 32 x 1024 points, r03 sweep tools/tile_upw.py)
+    // unit's ids ride on the first one's pieces: -8 .. -11 % per launch at 32 x 1024 points, r03 sweep tools/archive/tile_upw.py)
     int upw = (int)((units + capacity - 1) / capacity);
     if (upw < 2 && units >= 2L * device_cus()) upw = 2;
     if (dc_option(7) > 0) upw = dc_option(7);           // option 7 (lab): forced

@@ -511,9 +511,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
                         const u32x4 b = pr == 1 ? cb[jn].l : (pr == 2 || pr == 4 ? cb[jn].m : cb[jn].h);
                         acc[i][jn] = mfma_bf16(a, b, acc[i][jn]);
                     }
+#if defined(DC_LAB_X3) && DC_LAB_X3 >= 3                 /* lab: no split at all (wrong results, timing only) */
+                    if (f < TM) { na[f].h = __builtin_bit_cast(u32x4, qa[f][0]); na[f].m = __builtin_bit_cast(u32x4, qa[f][1]); na[f].l = na[f].h; }
+                    else { nb[f - TM].h = __builtin_bit_cast(u32x4, qb[f - TM][0]); nb[f - TM].m = __builtin_bit_cast(u32x4, qb[f - TM][1]); nb[f - TM].l = nb[f - TM].h; }
+                    read_frag(f, rbuf, rks);
+#elif defined(DC_LAB_X3) && DC_LAB_X3 >= 1               /* lab: the B fragments are not split (1) and not even read (2) */
+                    if (f < TM) split8(qa[f][0], qa[f][1], na[f]);
+                    else { nb[f - TM].h = __builtin_bit_cast(u32x4, qb[f - TM][0]); nb[f - TM].m = __builtin_bit_cast(u32x4, qb[f - TM][1]); nb[f - TM].l = nb[f - TM].h; }
+                    if (DC_LAB_X3 == 1 || f < TM) read_frag(f, rbuf, rks);
+#else
                     if (f < TM) split8(qa[f][0], qa[f][1], na[f]);
                     else split8(qb[f - TM][0], qb[f - TM][1], nb[f - TM]);
                     read_frag(f, rbuf, rks);
+#endif
                     stage(f);
                 }
 #pragma unroll
