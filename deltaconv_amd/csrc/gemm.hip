@@ -87,12 +87,11 @@ struct GemmP {
     float slope;
     double* part; int chunks, stat_cols;   // statistics partials [2][stat_cols][chunks]
     int stagger, resident;                 // first-round phase shift (shader cycles) of every second workgroup of a CU
-    // Side job: the first `red_blocks` workgroups of the grid do not multiply -- they sum the slab partials of the weight
-    // gradient that the PREVIOUS launch left in its workspace (the ordered reduction of gemm_tn.hip, same association, same
-    // bits), under this product's last tiles instead of in a launch of their own between the two products.
-    const float* red_src; float* red_dst; long red_ldc, red_mn; int red_n, red_slabs, red_acc, red_blocks, red_chunks;
+    // BP kernels: the B operand (a weight matrix) arrives PRE-SPLIT: three bf16 planes [rows = output columns][reduction index]
+    // (row stride ldb elements, plane stride bps elements), written once per step by dc_presplit_weights -- no B staging, no B
+    // tile in LDS, no B split in the K loop: every wave loads the plane fragments of its columns straight from L2
+    const unsigned short* Bp; long bps;
 };
-constexpr int RED_CHUNKS = 8;              // 64-element chunks per tail workgroup, at most (32 KB of the operand ring)
 
 // Fast-path load: buffer_load through a descriptor built from the wave-uniform tile origin (SGPRs), a wave-uniform
 // byte offset (soff: which of the thread's loads) and ONE 32-bit per-thread byte offset per operand (voff) -- no 64-bit
@@ -182,47 +181,9 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// C[e] (+)= sum over slabs of partial[slab][e] for the 64 * red_chunks elements of tail workgroup tb.  The association of
-// gemm_tn_reduce_kernel (16 interleaved chains: chain q sums the slabs q, q + 16, ..., then the chains are added in order),
-// carried by 4 waves x 4 chains: bit-identical to the stand-alone reduction.  All chunks advance together (one memory
-// round trip per 16 slabs for the whole workgroup, not per chunk).
-__device__ __forceinline__ void tail_reduce(const GemmP& p, long tb, float* sm /* [16][64 * RED_CHUNKS] */) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nch = p.red_chunks;
-    const long e0 = tb * nch * 64 + lane;
-    float s[RED_CHUNKS][4];
-#pragma unroll
-    for (int ch = 0; ch < RED_CHUNKS; ++ch)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[ch][j] = 0.f;
-    for (int sl0 = 0; sl0 < p.red_slabs; sl0 += 16)
-#pragma unroll
-        for (int ch = 0; ch < RED_CHUNKS; ++ch)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sl = sl0 + w + 4 * j;
-                const long e = e0 + ch * 64;
-                if (ch < nch && sl < p.red_slabs && e < p.red_mn) s[ch][j] += p.red_src[(long)sl * p.red_mn + e];
-            }
-#pragma unroll
-    for (int ch = 0; ch < RED_CHUNKS; ++ch)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sm[(w + 4 * j) * (64 * RED_CHUNKS) + ch * 64 + lane] = s[ch][j];
-    __syncthreads();
-    for (int ch = w; ch < nch; ch += 4) {
-        const long e = e0 + ch * 64;
-        if (e < p.red_mn) {
-            float t = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) t += sm[q * (64 * RED_CHUNKS) + ch * 64 + lane];
-            float* dst = p.red_dst + (e / p.red_n) * p.red_ldc + (e % p.red_n);
-            *dst = p.red_acc ? *dst + t : t;
-        }
-    }
-}
-
-template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0, int X3 = 0>
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0, int X3 = 0, int BP = 0>
 __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
+    static_assert(!BP || (X3 == 2 && AL == A_MK && BL == B_NK && MODE == 0), "pre-split B planes: pipelined split loop, K-contiguous operands, whole tiles");
     constexpr bool FAST = MODE == 0;               // no guards anywhere (loads, statistics, stores)
     // guarded modes per operand: 1 = 16-byte loads, 2 = dword loads.  MODE 1: both vector, 2: both scalar, 3: A vector /
     // B scalar, 4: A scalar / B vector
@@ -231,7 +192,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     constexpr int TM = WM / 32, TN = WN / 32;      // 32 x 32 accumulators per wave
     constexpr int A_FL = AL == A_MK ? BM * LDK : BK * BM;
     constexpr int B_FL = BL == B_NK ? BN * LDK : BK * BN;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // 16-byte loads per thread and K tile
+    constexpr int A_IT = BM / 32, B_IT = BP ? 0 : BN / 32;  // 16-byte loads per thread and K tile (BP: B is never staged)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][A_FL]
     float* Bs = smem + 2 * A_FL;       // [2][B_FL]
@@ -243,15 +204,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     // tile's first loads (pipe idle).  Holding back the workgroup in the ODD wave slot (HW_ID.WAVE_ID: the second
     // workgroup placed on the CU) by about half a K loop in the first round puts one workgroup's epilogue under the
     // other's K loop for the rest of the launch.
-    // (the FIRST red_blocks workgroups of the grid, a multiple of 8: dispatched before the products, their few microseconds
-    // disappear in the first of the product's rounds; as the last workgroups they were a round of their own behind it)
     DC_STAMP(0);
-    const unsigned gemm_blocks = gridDim.x - (unsigned)p.red_blocks;
-    if (blockIdx.x < (unsigned)p.red_blocks) {       // side job (block-uniform)
-        tail_reduce(p, (long)blockIdx.x, smem);
-        return;
-    }
-    const unsigned bid = blockIdx.x - (unsigned)p.red_blocks;
+    const unsigned gemm_blocks = gridDim.x;
+    const unsigned bid = blockIdx.x;
     if (p.stagger > 0 && (long)blockIdx.y * gridDim.x + bid < p.resident) {
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_REG_HW_ID bits [3:0]
         if (slot & 1) {
@@ -286,7 +241,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     // One set where a second does not fit the 256-register budget (2 workgroups per CU) without spilling: the
     // prologue variants (h tile + coefficients) and the 128 x 128 tile with a reduction-major B operand.
     constexpr int STG = (X3 || PRO || (BM == 128 && BN == 128 && BL == B_KN)) ? 1 : 2;
-    f32x4 sa[STG][A_IT], sb[STG][B_IT];
+    f32x4 sa[STG][A_IT], sb[STG][B_IT ? B_IT : 1];
     f32x4 sa2[PRO ? A_IT : 1], cf[5];          // prologue: h tile, per-column coefficients of this thread's 4 columns
     if (PRO && AL == A_KM) {                    // reduction-major A: the thread's columns never change
 #pragma unroll
@@ -417,7 +372,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
                 }
             }
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) {
+            for (int jn = 0; jn < (BP ? 0 : TN); ++jn) {
                 if (BL == B_NK) {
                     const float* b = Bs + buf * B_FL + (wn0 + 32 * jn + li) * LDK + 16 * ks + 8 * lh;
                     qb[jn][0] = *reinterpret_cast<const f32x4*>(b);
@@ -433,7 +388,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) split8(qa[i][0], qa[i][1], pa[i]);
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) split8(qb[jn][0], qb[jn][1], pb[jn]);
+            for (int jn = 0; jn < (BP ? 0 : TN); ++jn) split8(qb[jn][0], qb[jn][1], pb[jn]);
+        };
+        // BP: plane fragments of the wave's columns for the k-step at reduction index k, straight from global memory (L2).
+        // The planes are stored FRAGMENT-MAJOR (dc_presplit_weights): the 64 x 16 bytes that the lanes of a wavefront hold of
+        // (32 columns, 16 reduction indices) are 1 KiB contiguous -- one fully coalesced load per plane (a row-major layout
+        // costs 32 cache lines of 32 useful bytes per load: the first build ran 10-30 % SLOWER than the in-loop split on it).
+        const __amdgpu_buffer_rsrc_t rbp = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(BP ? p.Bp : nullptr), 0,
+                                                                              0x7FFFFFFF, 0x00020000);
+        const unsigned vobp = (unsigned)(lane * 16);
+        const unsigned ksteps = (unsigned)(p.ldb >> 4);                       // k-steps of the whole reduction (ldb = its length)
+        auto load_bp = [&](int jn, Planes& o, long k) {
+            const unsigned so = (((unsigned)((n0 + wn0) >> 5) + (unsigned)jn) * ksteps + (unsigned)(k >> 4)) * 1024u;
+            o.h = __builtin_amdgcn_raw_buffer_load_b128(rbp, (int)vobp, (int)so, 0);
+            o.m = __builtin_amdgcn_raw_buffer_load_b128(rbp, (int)vobp, (int)(so + (unsigned)(p.bps * 2)), 0);
+            o.l = __builtin_amdgcn_raw_buffer_load_b128(rbp, (int)vobp, (int)(so + (unsigned)(p.bps * 4)), 0);
         };
         // smallest partial products first; consecutive MFMAs go to different accumulators
         auto mfma_all = [&]() {
@@ -468,7 +437,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
             // of one fragment, then the LDS reads that refill its fp32 registers for the step after -- so the split runs
             // in the shadow of the matrix pipe inside ONE wave.  The LDS ring is two tiles deep: tile kt+2 is stored into
             // the buffer of tile kt during tile kt (all of that buffer was read before the previous barrier).
-            Planes pa1[TM], pb1[TN];
+            Planes pa1[TM], pb1[TN], pb2[TN];             // (pb2: third B set of the pre-split form)
+            constexpr bool RING3 = BP && !PRO;
             constexpr int NF = TM + TN, NM = 6 * TM * TN, VPM = 36 * NF / NM;
             auto read_frag = [&](int f, int buf, int ks) {
                 if (f < TM) {
@@ -499,10 +469,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
             // (rbuf, rks) -- unconditionally: past the last tile they read stale LDS and nothing consumes the result
             // `stage(f)`: the share of fragment group f in moving the operand ring on (LDS stores of tile kt+2, global loads of
             // tile kt+3): issued between the MFMAs of the k-step instead of in a burst behind it, where the matrix pipe idled
+            // (BP: `kb` = reduction index of the k-step being PREPARED; its B plane fragments are requested in the first slots
+            //  of this step -- a whole k-step of MFMAs covers their L2 round trip -- the A fragments are split in the last ones)
             auto step = [&](const Planes (&ca)[TM], const Planes (&cb)[TN], Planes (&na)[TM], Planes (&nb)[TN], int rbuf, int rks,
-                            auto stage) {
+                            auto stage, long kb = 0) {
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
+                    const int fr = BP ? (f < TN ? TM + f : f - TN) : f;           // fragment handled in slot f
 #pragma unroll
                     for (int g = f * NM / NF; g < (f + 1) * NM / NF; ++g) {
                         const int pr = g / (TM * TN), r = g % (TM * TN), i = r / TN, jn = r % TN;
@@ -520,20 +493,36 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
                     else { nb[f - TM].h = __builtin_bit_cast(u32x4, qb[f - TM][0]); nb[f - TM].m = __builtin_bit_cast(u32x4, qb[f - TM][1]); nb[f - TM].l = nb[f - TM].h; }
                     if (DC_LAB_X3 == 1 || f < TM) read_frag(f, rbuf, rks);
 #else
-                    if (f < TM) split8(qa[f][0], qa[f][1], na[f]);
-                    else split8(qb[f - TM][0], qb[f - TM][1], nb[f - TM]);
-                    read_frag(f, rbuf, rks);
+                    if (fr < TM) {
+                        split8(qa[fr][0], qa[fr][1], na[fr]);
+                        read_frag(fr, rbuf, rks);
+                    } else if (BP) {
+                        load_bp(fr - TM, nb[fr - TM], kb);
+                    } else {
+                        split8(qb[fr - TM][0], qb[fr - TM][1], nb[fr - TM]);
+                        read_frag(fr, rbuf, rks);
+                    }
 #endif
                     stage(f);
                 }
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
+                    if (BP && f < TN) {                                      // a B slot of the pre-split form: three plane loads
+                        __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
 #pragma unroll
-                    for (int g = 0; g < NM / NF; ++g) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0); // its share of the split
+                        for (int g = 0; g < NM / NF; ++g) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < NM / NF; ++g) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, BP ? 36 * NF / NM : VPM, 0); // its share of the split
+                        }
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x200, (NST + NF - 1) / NF, 0);     // LDS stores of the group
+                    if (PRO) {                                                               // LDS stores of the group
+                        if (f == 0) __builtin_amdgcn_sched_group_barrier(0x200, NST, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x200, (NST + NF - 1) / NF, 0);
+                    }
                     __builtin_amdgcn_sched_group_barrier(0x020, (NLD + NF - 1) / NF, 0);     // global loads of the group
                 }
             };
@@ -555,28 +544,53 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
             DC_STAMP(7);
             read_raw(0, 0);
             split_all();
+            if (BP) {                                       // the planes of the first two k-steps
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) load_bp(jn, pb[jn], kbeg);
+                if (RING3) {
+#pragma unroll
+                    for (int jn = 0; jn < TN; ++jn) load_bp(jn, pb1[jn], kbeg + 16);
+                }
+            }
             read_raw(0, 1);
-            for (int kt = 0; kt < nk; ++kt) {
+            // one K tile = two k-steps.  ba / bb: the B plane sets the two steps multiply; la / lb: the sets they PREPARE -- in the
+            // in-loop form the set of the next step (cut from the fragments in flight), with pre-split planes (BP) the set of the
+            // step after next, loaded from global memory: a ring of three sets, two k-steps of MFMAs over every L2 round trip
+            auto tile_steps = [&](int kt, const Planes (&ba)[TN], const Planes (&bb)[TN], Planes (&la)[TN], Planes (&lb)[TN]) {
                 const int cur = kt & 1;
                 // (unconditional: past the last tiles the stores refill a buffer nobody reads again and the loads re-read the last
                 // tile -- no branches inside the pinned instruction stream)
                 const long k3 = kbeg + (long)min(kt + 3, nk - 1) * BK;
                 auto none = [&](int) {};
                 auto stores_loads = [&](int f) {                           // (piece n is stored before its registers are reloaded)
+                    if (PRO) {
+                        // the prologue forms load more pieces (h tile, coefficients) than they store and every store reads the
+                        // coefficients: ALL stores go in front of the first reload (per-slot shares would reload sa[1..] in slot 0
+                        // before slot 1 stored them -- found by the pre-split-plane A/B at 64-row tiles, round 4)
+                        if (f == 0) {
 #pragma unroll
-                    for (int n = f * NST / NF; n < (f + 1) * NST / NF; ++n) store_piece(n, cur, S0{});
+                            for (int n = 0; n < NST; ++n) store_piece(n, cur, S0{});
+                        }
+                    } else {
+#pragma unroll
+                        for (int n = f * NST / NF; n < (f + 1) * NST / NF; ++n) store_piece(n, cur, S0{});
+                    }
 #pragma unroll
                     for (int n = f * NLD / NF; n < (f + 1) * NLD / NF; ++n) load_piece(n, k3, S0{});
                 };
                 // (the weight gradient's reduction-major form spills with the pieces inside the stream: it keeps the burst behind it)
                 constexpr bool INSIDE = AL == A_MK;
+                // (BP: the planes requested now belong to tile kt + 1 -- ring of three sets -- or, where the prologue's registers
+                //  leave room for two sets only, to the next k-step; past the end the last tile again)
+                const long kn = kbeg + (long)min(kt + 1, nk - 1) * BK;
+                const long kb1 = RING3 ? kn : kbeg + (long)kt * BK + 16, kb2 = RING3 ? kn + 16 : kn;
                 __builtin_amdgcn_sched_barrier(0);
-                step(pa, pb, pa1, pb1, cur ^ 1, 0, none);
+                step(pa, ba, pa1, la, cur ^ 1, 0, none, kb1);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (INSIDE) {
-                    step(pa1, pb1, pa, pb, cur ^ 1, 1, stores_loads);
+                    step(pa1, bb, pa, lb, cur ^ 1, 1, stores_loads, kb2);
                 } else {
-                    step(pa1, pb1, pa, pb, cur ^ 1, 1, none);
+                    step(pa1, bb, pa, lb, cur ^ 1, 1, none);
                     __builtin_amdgcn_sched_barrier(0);
                     if (kt + 2 < nk) {
 #pragma unroll
@@ -589,6 +603,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 lds_barrier();
+            };
+            if constexpr (RING3) {
+                int kt = 0;
+                for (; kt + 3 <= nk; kt += 3) {
+                    tile_steps(kt, pb, pb1, pb2, pb);
+                    tile_steps(kt + 1, pb2, pb, pb1, pb2);
+                    tile_steps(kt + 2, pb1, pb2, pb, pb1);
+                }
+                if (kt < nk) tile_steps(kt, pb, pb1, pb2, pb);
+                if (kt + 1 < nk) tile_steps(kt + 1, pb2, pb, pb1, pb2);
+            } else {
+                for (int kt = 0; kt < nk; ++kt) tile_steps(kt, pb, pb1, pb1, pb);
             }
         } else {
 #pragma unroll
@@ -872,21 +898,21 @@ size_t lds_bytes(int bm, int bn, int al, int bl) {
     return std::max(2 * (a + b), (size_t)bm * bn) * sizeof(float);      // operand ring | output staging
 }
 
-template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO, int X3>
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO, int X3, int BP = 0>
 void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
     static unsigned long long configured = 0;
     const size_t lds = lds_bytes(BM, BN, AL, BL);
-    if (!dc_ensure_lds(&configured, reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>), lds, "dense product")) return;
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3>),
-                       dim3((unsigned)(tiles_m * p.tiles_n) + (unsigned)p.red_blocks, (unsigned)slabs), dim3(NT), lds, s, p);
+    if (!dc_ensure_lds(&configured, reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>), lds, "dense product")) return;
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>),
+                       dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs), dim3(NT), lds, s, p);
 }
 
-template <int AL, int BL, int MODE, int EPI, int PRO, int X3 = 0>
+template <int AL, int BL, int MODE, int EPI, int PRO, int X3 = 0, int BP = 0>
 void launch_tile(const GemmP& p, Tile t, long tiles_m, int slabs, hipStream_t s) {
-    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
-    else if (t.bm == 128) launch_one<128, 64, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
-    else if (t.bn == 128) launch_one<64, 128, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
-    else launch_one<64, 64, AL, BL, MODE, EPI, PRO, X3>(p, tiles_m, slabs, s);
+    if (t.bm == 128 && t.bn == 128) launch_one<128, 128, AL, BL, MODE, EPI, PRO, X3, BP>(p, tiles_m, slabs, s);
+    else if (t.bm == 128) launch_one<128, 64, AL, BL, MODE, EPI, PRO, X3, BP>(p, tiles_m, slabs, s);
+    else if (t.bn == 128) launch_one<64, 128, AL, BL, MODE, EPI, PRO, X3, BP>(p, tiles_m, slabs, s);
+    else launch_one<64, 64, AL, BL, MODE, EPI, PRO, X3, BP>(p, tiles_m, slabs, s);
 }
 
 // The unguarded path (whole tiles: every hot shape of the reference models) multiplies through the split products where
@@ -899,6 +925,15 @@ void launch_fast(const GemmP& p, Tile t, long tiles_m, int slabs, int mode, hipS
     // (DC_OPT_GEMM_EXACT = 2, lab: split on every unguarded tile)
     const bool split = mode == 0 && (dc_option(DC_OPT_GEMM_EXACT) == 2 ||
                                      (dc_option(DC_OPT_GEMM_EXACT) == 0 && t.bn == 128 && (AL == A_MK || t.bm == 128)));
+    // Pre-split weight planes (round 4): the B split and its LDS traffic are gone, so 64-column tiles (6 split instructions per
+    // MFMA like today's 128-column ones) take the split path too.  Plain products only (the BatchNorm-prologue loaders keep the
+    // simple loop: their registers).
+    if constexpr (AL == A_MK && BL == B_NK) {
+        if (p.Bp && mode == 0 && dc_option(DC_OPT_GEMM_EXACT) == 0) {
+            launch_tile<AL, BL, 0, EPI, PRO, 2, 1>(p, t, tiles_m, slabs, s);
+            return;
+        }
+    }
     if (split) launch_tile<AL, BL, 0, EPI, PRO, (PRO ? DC_X3_PRO : DC_X3_PLAIN)>(p, t, tiles_m, slabs, s);
     else if (mode == 0) launch_tile<AL, BL, 0, EPI, PRO>(p, t, tiles_m, slabs, s);
     else if (mode == 1) launch_tile<AL, BL, 1, EPI, PRO>(p, t, tiles_m, slabs, s);
@@ -932,15 +967,21 @@ bool al16p(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 // bl: operand layout of W; epi: fused statistics; part/chunks filled by the caller for epi != 0
 struct Prologue { const float* h; long ldh; const float* coefs; int ncoef; float slope; };
-struct TailReduce { const float* partial; int slabs; long mn; int n; float* dst; long ldc; int accumulate; };
-void clear_tail(GemmP& p) {
-    p.red_src = nullptr; p.red_dst = nullptr; p.red_ldc = 0; p.red_mn = 0; p.red_n = 1; p.red_slabs = 0; p.red_acc = 0;
-    p.red_blocks = 0; p.red_chunks = 1;
-}
+// Hint for the NEXT product enqueued by this thread: the bf16 planes of its weight operand (dc_presplit_weights).
+//   transposed == 0: planes of W[N, K] as stored (forward products: the rows are the output columns);
+//   transposed != 0: planes of W^T [K, N] (input-gradient products dX = dY W: their output columns are W's columns).
+// ld = reduction length of the planes (K resp. N of W), plane_elems = distance between two planes = N * K.  Consumed (and cleared) by the next
+// dc_linear_* call whatever its outcome; ignored where the planes do not apply (ragged shapes, exact chain, prologue forms).
+struct BHint { const unsigned short* p; long stride, ld; int transposed; };
+thread_local BHint g_bhint = {nullptr, 0, 0, 0};
 
 int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const float* B, long ldb, long M, int N, int K,
              float* C, long ldc, int accumulate, int tile, double* part, int stat_cols, hipStream_t s,
-             const Prologue* pro = nullptr, const TailReduce* tail = nullptr) {
+             const Prologue* pro = nullptr) {
+    const BHint hint = g_bhint;
+    g_bhint = BHint{nullptr, 0, 0, 0};
+    // (round 4 lab: N = q * 128 + 64 output columns as two launches -- q * 128 columns on 128-column split tiles + 64 on 64-column
+    //  tiles -- is 27 us faster in isolation for 32768 x 448 x 1024 and 8 us SLOWER inside the step, same-box A/B: not used)
     const Tile t = pick_tile(M, N, K, tile);
     const long tiles_m = (M + t.bm - 1) / t.bm;
     GemmP p;
@@ -952,16 +993,8 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
     p.k_per_slab = K; p.slab_stride = 0;
     p.part = part; p.chunks = (int)tiles_m; p.stat_cols = stat_cols;
     p.A2 = nullptr; p.lda2 = 0; p.pc = nullptr; p.pcn = 0; p.slope = 0.f;
+    p.Bp = nullptr; p.bps = 0;
     set_stagger(p, t, tiles_m * p.tiles_n, (long)K);
-    clear_tail(p);
-    if (tail) {
-        p.red_src = tail->partial; p.red_dst = tail->dst; p.red_ldc = tail->ldc; p.red_mn = tail->mn; p.red_n = tail->n;
-        p.red_slabs = tail->slabs; p.red_acc = tail->accumulate;
-        // ~512 tail workgroups (one resident round), 1 .. RED_CHUNKS chunks of 64 elements each
-        p.red_chunks = (int)std::min<long>(RED_CHUNKS, std::max<long>(1, (tail->mn / 64 + 511) / 512));
-        p.red_blocks = (int)((tail->mn + 64L * p.red_chunks - 1) / (64L * p.red_chunks));
-        p.red_blocks = (p.red_blocks + 7) & ~7;       // keeps block id mod 8 (= the XCD) of the products' workgroups
-    }
     if (lda >= (1 << 21) || ldb >= (1 << 21) || (pro && pro->ldh >= (1 << 21))) {     // 32-bit in-tile byte offsets
         dc_set_error("%s: leading dimension above 2^21 elements", name);
         return DC_ERR_ARG;
@@ -973,7 +1006,23 @@ int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const 
         p.A2 = pro->h; p.lda2 = pro->ldh; p.pc = pro->coefs; p.pcn = pro->ncoef; p.slope = pro->slope;
         a4 = a4 && pro->ldh % 4 == 0 && al16p(pro->h);
         const int fast = load_mode(whole && al16p(pro->coefs) && pro->ncoef % 4 == 0, a4, b4);
-        launch_fast<A_MK, B_KN, EPI_NONE, 1>(p, t, tiles_m, 1, fast, s);
+        if (hint.p && hint.transposed && hint.ld == K && N % 32 == 0 && K % 16 == 0 && al16p(hint.p) && hint.stride == (long)N * K &&
+            hint.stride * 6 < (1L << 31) && load_mode(whole && al16p(pro->coefs) && pro->ncoef % 4 == 0, a4, true) == 0 &&
+            dc_option(DC_OPT_GEMM_EXACT) == 0 && dc_option(DC_OPT_NO_PLANES) == 0) {
+            p.Bp = hint.p; p.bps = hint.stride; p.ldb = hint.ld; p.B = nullptr;       // forward form over W^T's planes
+            launch_fast<A_MK, B_NK, EPI_NONE, 1>(p, t, tiles_m, 1, 0, s);
+        } else {
+            launch_fast<A_MK, B_KN, EPI_NONE, 1>(p, t, tiles_m, 1, fast, s);
+        }
+    } else if (hint.p && hint.transposed == (bl == B_KN) && hint.ld == K && N % 32 == 0 && K % 16 == 0 && al16p(hint.p) &&
+               hint.stride == (long)N * K && hint.stride * 6 < (1L << 31) &&
+               load_mode(whole, a4, true) == 0 && dc_option(DC_OPT_GEMM_EXACT) == 0 && dc_option(DC_OPT_NO_PLANES) == 0) {
+        // pre-split planes: forward products as they are; input-gradient products in the forward form over W^T's planes
+        p.Bp = hint.p; p.bps = hint.stride; p.ldb = hint.ld; p.B = nullptr;
+        if (epi == EPI_COLSTATS) launch_fast<A_MK, B_NK, EPI_COLSTATS>(p, t, tiles_m, 1, 0, s);
+        else if (epi == EPI_VNSTATS) launch_fast<A_MK, B_NK, EPI_VNSTATS>(p, t, tiles_m, 1, 0, s);
+        else if (epi == EPI_VNSTATS0) launch_fast<A_MK, B_NK, EPI_VNSTATS0>(p, t, tiles_m, 1, 0, s);
+        else launch_fast<A_MK, B_NK, EPI_NONE>(p, t, tiles_m, 1, 0, s);
     } else if (bl == B_NK) {
         const int fast = load_mode(whole, a4, b4);
         if (epi == EPI_COLSTATS) launch_fast<A_MK, B_NK, EPI_COLSTATS>(p, t, tiles_m, 1, fast, s);
@@ -1000,9 +1049,14 @@ int chunks_for(long M, int N, int K, int tile) {
 
 // ---- weight gradient through the LDS-staged kernel (called by dc_gemm_tn, gemm_tn.hip) ----------------------------
 // partial[slab][M][N] = A[rows of the slab, M]^T B[rows of the slab, N];  returns the number of slabs.
-struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
+struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; int split; /* N - 64 columns on 128 x 128 tiles + 64 on 64 x 64 */ };
+int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial, hipStream_t s,
+                     const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f,
+                     const DcTnPlan* forced = nullptr, int ldp = 0);
 DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     DcTnPlan pl;
+    pl.split = 0;      // (round 4 lab: N - 64 columns on 128 x 128 split tiles + 64 on 64 x 64 tiles over the same slabs was no faster
+                       //  than 128 x 64 exact tiles for the [1024, 448] embedding weight, 237 vs 237 us: not used)
     // r02r sweep (profiles/r02r_tn_sweep.txt): outputs below 64K elements run best on 64 x 64 tiles (more workgroups
     // per slab, shorter epilogues; 4 fit a CU) with ~768 workgroups; larger ones on 128 x 128 tiles with at most 512
     // workgroups = ONE resident wave of 2 per CU (576 cost +25 %: a second, nearly empty round); <= 128 slabs
@@ -1027,23 +1081,33 @@ DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     return pl;
 }
 int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial,
-                     hipStream_t s, const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f) {
-    const DcTnPlan pl = dc_tn_lds_plan(R, M, N);
+                     hipStream_t s, const float* h, long ldh, const float* coefs, float slope, const DcTnPlan* forced, int ldp) {
+    if (!forced) {
+        const DcTnPlan whole_plan = dc_tn_lds_plan(R, M, N);
+        if (whole_plan.split) {                                // two launches over the same slabs (see dc_tn_lds_plan)
+            const int n1 = N - 64;
+            const DcTnPlan a{128, 128, whole_plan.slabs, whole_plan.rows_per_slab, 0}, b{64, 64, whole_plan.slabs, whole_plan.rows_per_slab, 0};
+            if (dc_tn_lds_launch(A, lda, B, ldb, R, M, n1, partial, s, h, ldh, coefs, slope, &a, N) < 0) return -1;
+            if (dc_tn_lds_launch(A, lda, B + n1, ldb, R, M, 64, partial + n1, s, h, ldh, coefs, slope, &b, N) < 0) return -1;
+            return whole_plan.slabs;
+        }
+    }
+    const DcTnPlan pl = forced ? *forced : dc_tn_lds_plan(R, M, N);
     const Tile t{pl.bm, pl.bn};
+    const int ldpart = forced ? ldp : N;                       // row stride of the partial tiles (the FULL output width)
     const long tiles_m = (M + t.bm - 1) / t.bm;
     GemmP p;
-    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = partial; p.ldc = N;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = partial; p.ldc = ldpart;
     p.M = M; p.N = N; p.K = R;
     p.tiles_n = (N + t.bn - 1) / t.bn;
     p.remap = 0;                       // tiles x slabs: every workgroup streams its own rows, nothing to co-locate
     p.accumulate = 0;
-    p.k_per_slab = pl.rows_per_slab; p.slab_stride = (long)M * N;
+    p.k_per_slab = pl.rows_per_slab; p.slab_stride = (long)M * ldpart;
     p.part = nullptr; p.chunks = 0; p.stat_cols = 0;
     p.A2 = h; p.lda2 = ldh; p.pc = coefs; p.pcn = M; p.slope = slope;
     set_stagger(p, t, tiles_m * p.tiles_n * pl.slabs, pl.rows_per_slab);
-    clear_tail(p);
     if (lda >= (1 << 21) || ldb >= (1 << 21) || ldh >= (1 << 21)) return -1;      // 32-bit in-tile byte offsets
-    const bool whole = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && N % 4 == 0 &&
+    const bool whole = M % t.bm == 0 && N % t.bn == 0 && R % BK == 0 && pl.rows_per_slab % BK == 0 && ldpart % 4 == 0 &&
                        al16p(partial);
     bool a4 = M % 4 == 0 && lda % 4 == 0 && al16p(A);                       // reduction-major: 4-vectors run along M / N
     const bool b4 = N % 4 == 0 && ldb % 4 == 0 && al16p(B);
@@ -1090,42 +1154,6 @@ DC_EXPORT int dc_linear_bn_backward_input(const float* dy, int64_t lddy, const f
     const Prologue pro{h, (long)ldh, coefs, N, slope};
     return run_gemm("dc_linear_bn_backward_input", B_KN, EPI_NONE, dy, lddy, W, ldw, M, K, N, dX, lddx, accumulate, tile,
                     nullptr, 0, static_cast<hipStream_t>(stream), &pro);
-}
-
-// Both gradients of y = x W^T for the incoming dY [R, N] (or, with h / coefs, dh = BatchNorm/activation backward of (dY, h)
-// formed in the operand loaders: dc_linear_bn_backward_weight / _input):
-//   dW[N, K] (lddw) (+)= dh^T X      slab partials into the workspace (dc_gemm_tn_workspace_bytes(R, N, K)),
-//   dX[R, K] (lddx) (+)= dh W        and the ordered slab reduction of dW runs as the TAIL workgroups of this launch --
-// the same results, bit for bit, as the two separate entry points, one launch less per layer (the reduction is a
-// 5 - 20 us launch of its own otherwise, 12 per step of the ModelNet40 model).
-DC_EXPORT int dc_linear_backward_pair(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
-                                      float slope, const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t R,
-                                      int32_t N, int32_t K, float* dW, int64_t lddw, int32_t accumulate_w, float* dX,
-                                      int64_t lddx, int32_t accumulate_x, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
-    DC_REQUIRE(dy && X && W && dW && dX, "dc_linear_backward_pair: null pointer");
-    DC_REQUIRE((h == nullptr) == (coefs == nullptr), "dc_linear_backward_pair: h and coefs go together");
-    DC_REQUIRE(R >= 1 && N >= 1 && K >= 1 && lddy >= N && (!h || ldh >= N) && ldx >= K && ldw >= K && lddw >= K && lddx >= K,
-               "dc_linear_backward_pair: bad size");
-    DC_REQUIRE(lddy < (1 << 21) && ldh < (1 << 21) && ldx < (1 << 21) && ldw < (1 << 21),
-               "dc_linear_backward_pair: leading dimension above 2^21 elements");
-    const DcTnPlan pl = dc_tn_lds_plan((long)R, N, K);
-    if (!workspace || workspace_bytes < (size_t)pl.slabs * N * K * sizeof(float)) {
-        dc_set_error("dc_linear_backward_pair: workspace too small");
-        return DC_ERR_WORKSPACE;
-    }
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    float* partial = static_cast<float*>(workspace);
-    const int slabs = dc_tn_lds_launch(dy, (long)lddy, X, (long)ldx, (long)R, N, K, partial, s, h, (long)ldh, coefs, slope);
-    if (slabs < 0) {
-        dc_set_error("dc_linear_backward_pair: weight-gradient launch failed");
-        return DC_ERR_LAUNCH;
-    }
-    const TailReduce tail{partial, slabs, (long)N * K, K, dW, (long)lddw, accumulate_w};
-    const Prologue pro{h, (long)ldh, coefs, N, slope};
-    // dX as a product: C[R, K] = A[R, N] B[N, K] -- reduction over N, B stored reduction-major
-    return run_gemm("dc_linear_backward_pair", B_KN, EPI_NONE, dy, lddy, W, ldw, R, K, N, dX, lddx, accumulate_x, 0, nullptr, 0,
-                    s, h ? &pro : nullptr, &tail);
 }
 
 DC_EXPORT size_t dc_linear_stats_workspace_bytes(int64_t M, int32_t N, int32_t K, int32_t tile) {
@@ -1185,6 +1213,73 @@ DC_EXPORT int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const floa
     hipLaunchKernelGGL((dccol::colreduce_final_kernel<dccol::BnFin>), dim3(co), dim3(64), 0, s, part,
                        chunks_for(M, N, K, tile), co, fin);
     DC_CHECK_LAUNCH("dc_linear_vn_stats_forward");
+    return DC_OK;
+}
+
+// ---- pre-split weight planes (round 4) ------------------------------------------------------------------------------------
+// A weight matrix is the B operand of hundreds of workgroups per product and of several products per step; cutting it into
+// its three bf16 planes once per step (instead of in every wave's K loop) removes half of the split instructions and the whole
+// B tile from LDS: profiles/r04_gemm_split_bounds.txt (lab1) put that at 10-15 % of the split products, and it makes the split
+// path pay on 64-column tiles as well.  The planes are bit-identical to what split_pair() produces in the K loop (same
+// roundings), the MFMA order is unchanged: a product from planes returns the SAME BITS as the in-loop split.
+namespace {
+struct PresplitEntry { const float* src; unsigned short* fwd; unsigned short* bwd; long n, k, ld; };
+__device__ __forceinline__ void split1(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+    const unsigned hp = pk_bf16(x, 0.f);
+    const float r = x - __builtin_bit_cast(float, hp << 16);
+    const unsigned mp = pk_bf16(r, 0.f);
+    const float q = r - __builtin_bit_cast(float, mp << 16);
+    h = (unsigned short)(hp & 0xffffu); m = (unsigned short)(mp & 0xffffu); l = (unsigned short)(pk_bf16(q, 0.f) & 0xffffu);
+}
+// one workgroup = 1024 consecutive elements of one matrix; chunk_start[e] = first chunk of entry e (ascending)
+__global__ __launch_bounds__(256) void presplit_kernel(const PresplitEntry* __restrict__ table, const int* __restrict__ chunk_start,
+                                                       int n_entries) {
+    int lo = 0, hi = n_entries;                             // entry of this chunk (<= ~6 steps on cached words)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const PresplitEntry e = table[lo];
+    const long total = e.n * e.k, c0 = ((long)blockIdx.x - chunk_start[lo]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long i = c0 + u * 256 + threadIdx.x;
+        if (i < total) {
+            const long r = i / e.k, c = i - r * e.k;
+            unsigned short h, m, l;
+            split1(e.src[r * e.ld + c], h, m, l);
+            // fragment-major: (row block of 32, k-step of 16) -> 64 lanes x 8 elements; lane = 32 * (k-half) + row % 32
+            if (e.fwd) {
+                const long j = (((r >> 5) * (e.k >> 4) + (c >> 4)) * 64 + ((c & 15) >> 3) * 32 + (r & 31)) * 8 + (c & 7);
+                e.fwd[j] = h; e.fwd[total + j] = m; e.fwd[2 * total + j] = l;
+            }
+            if (e.bwd) {                                    // the same for the transpose: rows <-> columns
+                const long j = (((c >> 5) * (e.n >> 4) + (r >> 4)) * 64 + ((r & 15) >> 3) * 32 + (c & 31)) * 8 + (r & 7);
+                e.bwd[j] = h; e.bwd[total + j] = m; e.bwd[2 * total + j] = l;
+            }
+        }
+    }
+}
+}  // namespace
+
+// table: device array of n_entries records {src, fwd planes or NULL, bwd (transposed) planes or NULL, rows, cols, row stride}
+// (six 64-bit words each); chunk_start: device int32 [n_entries + 1], chunk_start[e + 1] - chunk_start[e] = ceil(rows * cols / 1024).
+// fwd = three planes of rows x cols bf16, bwd = three planes of the transpose, both FRAGMENT-MAJOR (see presplit_kernel); rows
+// and cols multiples of 32.
+DC_EXPORT int dc_presplit_weights(const int64_t* table, const int32_t* chunk_start, int32_t n_entries, int32_t total_chunks,
+                                  void* stream) {
+    DC_REQUIRE(table && chunk_start && n_entries >= 0 && total_chunks >= 0, "dc_presplit_weights: bad arguments");
+    if (n_entries == 0 || total_chunks == 0) return DC_OK;
+    static_assert(sizeof(PresplitEntry) == 48, "table record = six 64-bit words");
+    hipLaunchKernelGGL(presplit_kernel, dim3(total_chunks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const PresplitEntry*>(table), chunk_start, n_entries);
+    DC_CHECK_LAUNCH("dc_presplit_weights");
+    return DC_OK;
+}
+
+// Planes of the weight operand of the NEXT dc_linear_* product enqueued by the calling thread (see BHint above).
+DC_EXPORT int dc_gemm_next_b_planes(const void* planes, int64_t plane_elems, int64_t ld, int32_t transposed) {
+    g_bhint = BHint{static_cast<const unsigned short*>(planes), (long)plane_elems, (long)ld, transposed ? 1 : 0};
     return DC_OK;
 }
 

@@ -78,6 +78,8 @@ class DeltaNetBase(torch.nn.Module):
         return graph, grad, div
 
     def forward(self, data):
+        from ..nn import fused as _fused
+        _fused.presplit_begin()      # bf16 planes of every weight the products have asked for: one launch per forward pass
         graph, grad, div = self.build_operators(data)
         x = data.x if hasattr(data, 'x') and data.x is not None else data.pos   # deltanet_base.py:76
         v = grad @ x                                                             # deltanet_base.py:78

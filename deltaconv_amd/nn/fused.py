@@ -79,6 +79,7 @@ def invalidate_eval_coeffs():
     """Drop every cached inference-mode BatchNorm map.  Needed whenever parameters / running statistics change through
     raw pointers, i.e. without a tensor version bump: a HIP-graph replay of a training step (graph_step.py)."""
     _EVAL_EPOCH[0] += 1
+    _PL["epoch"] += 1        # the pre-split weight planes as well: a replayed optimizer update moved the weights under them
 
 
 def eval_coeffs(gamma, beta, rm, rv, eps, c):
@@ -339,6 +340,127 @@ def edge_max_bn(y, graph, bn, slope):
     return _EdgeMaxBN.apply(y, graph, bn.weight, bn.bias, rm, rv, use_batch, mom, float(bn.eps), float(slope))
 
 
+# ---- pre-split weight planes (csrc/gemm.hip: dc_presplit_weights, BP kernels) -----------------------------------------------
+# The split products cut every fp32 operand into three bf16 planes; for a WEIGHT matrix that work is identical in every
+# workgroup of every product of a step.  `presplit_begin()` (called at the start of a model forward) cuts all weights that
+# products have asked for -- as stored [N, K] for the forward products and transposed [K, N] for the input gradients -- in ONE
+# launch; `_hint_planes(w, transposed)` in front of a product hands the library the planes of its weight operand.  Same bits
+# as the in-loop split.  A weight the cache does not know yet is registered at its first use and served from the next step on
+# (never during a graph capture: registration copies a table to the device); planes are used only when they were cut after
+# the last modification of the weight (version counter + step epoch), else the product splits in its K loop as before.
+USE_WEIGHT_PLANES = os.environ.get("DC_WEIGHT_PLANES", "1") != "0"
+_PL = {"entries": {}, "order": [], "table": None, "chunks": None, "n_chunks": 0, "epoch": 0, "dirty": False}
+
+
+def _planes_reset():
+    _PL.update(entries={}, order=[], table=None, chunks=None, n_chunks=0, dirty=False)
+
+
+def presplit_begin():
+    """Cut every registered weight into its bf16 planes (one launch).  Call once per forward pass, before its first product."""
+    if not USE_WEIGHT_PLANES or not _PL["entries"]:
+        return
+    capturing = torch.cuda.is_current_stream_capturing()
+    ents = _PL["entries"]
+    if not capturing:
+        dead = [k for k, e in ents.items() if e["wref"]() is None]
+        for k in dead:
+            del ents[k]
+        if dead or _PL["dirty"] or _PL["table"] is None:
+            rows, starts, total = [], [0], 0
+            for e in ents.values():
+                n, k = e["n"], e["k"]
+                for need in ("fwd", "bwd"):
+                    if e["want_" + need] and e[need] is None:
+                        e[need] = torch.empty(3 * n * k, dtype=torch.int16, device=e["dev"])
+                rows.append([e["ptr"], e["fwd"].data_ptr() if e["fwd"] is not None else 0,
+                             e["bwd"].data_ptr() if e["bwd"] is not None else 0, n, k, k])
+                total += (n * k + 1023) // 1024
+                starts.append(total)
+            if not rows:
+                _PL.update(table=None, chunks=None, n_chunks=0, dirty=False)
+                return
+            dev = next(iter(ents.values()))["dev"]
+            _PL["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+            _PL["chunks"] = torch.tensor(starts, dtype=torch.int32).to(dev)
+            _PL["n_chunks"], _PL["dirty"] = total, False
+            _PL["order"] = list(ents.keys())
+    if _PL["table"] is None:
+        return
+    if not capturing:        # nothing changed since the last cut (inference, repeated forward passes): the planes stand
+        cur = True
+        for key in _PL["order"]:
+            e = ents.get(key)
+            w = e["wref"]() if e is not None else None
+            if w is None or e["epoch"] != _PL["epoch"] or e["version"] != w._version:
+                cur = False
+                break
+        if cur:
+            return
+    lib.call("dc_presplit_weights", _PL["table"], _PL["chunks"], len(_PL["order"]), _PL["n_chunks"])
+    _PL["epoch"] += 1
+    for key in _PL["order"]:
+        e = ents.get(key)
+        if e is not None:
+            w = e["wref"]()
+            e["epoch"], e["version"] = _PL["epoch"], (w._version if w is not None else -1)
+
+
+def _split_one(e, base):
+    """Cut ONE weight now (its first use, or a use after it changed without a presplit_begin): a one-record table."""
+    n, k = e["n"], e["k"]
+    for need in ("fwd", "bwd"):
+        if e["want_" + need] and e[need] is None:
+            e[need] = torch.empty(3 * n * k, dtype=torch.int16, device=e["dev"])
+    row = [[e["ptr"], e["fwd"].data_ptr() if e["fwd"] is not None else 0, e["bwd"].data_ptr() if e["bwd"] is not None else 0, n, k, k]]
+    chunks = (n * k + 1023) // 1024
+    lib.call("dc_presplit_weights", torch.tensor(row, dtype=torch.int64).to(e["dev"]),
+             torch.tensor([0, chunks], dtype=torch.int32).to(e["dev"]), 1, chunks)
+    e["epoch"], e["version"] = _PL["epoch"], base._version
+
+
+def _hint_planes(w, transposed):
+    """In front of a dc_linear_* call: hand the library the pre-split planes of its weight operand `w` [N, K] (transposed: the
+    planes of w^T, for the input-gradient product).  Outside a graph capture the planes are ALWAYS current when this returns
+    (a weight seen for the first time, or changed since the last cut, is cut on the spot), so a product's arithmetic never
+    depends on the call history; inside a capture only planes cut earlier in the capture (or still current) are offered."""
+    if not USE_WEIGHT_PLANES or w.dim() != 2 or not w.is_cuda or w.dtype != torch.float32 or not w.is_contiguous():
+        return
+    base = w._base if w._base is not None else w
+    if not (isinstance(base, torch.nn.Parameter) or (base.is_leaf and base.requires_grad)):
+        return                                            # temporaries would churn the table
+    n, k = w.shape
+    if n % 32 or k % 32:
+        return                                            # the fragment-major plane layout wants whole 32 x 16 blocks
+    key = (w.data_ptr(), n, k)
+    need = "bwd" if transposed else "fwd"
+    e = _PL["entries"].get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if e is not None and e["wref"]() is not base:
+        # the address was recycled: ANOTHER tensor with this shape lives here now (the parameter the entry was made for is
+        # gone).  Same key, same version counter value are possible -- never trust the old planes.
+        if capturing:
+            return
+        import weakref
+        e["wref"], e["version"], e["epoch"] = weakref.ref(base), -1, -1
+    if e is None or e[need] is None:
+        if capturing:
+            return
+        if e is None:
+            import weakref
+            e = dict(wref=weakref.ref(base), ptr=w.data_ptr(), n=n, k=k, dev=w.device, fwd=None, bwd=None, want_fwd=False,
+                     want_bwd=False, epoch=-1, version=-1)
+            _PL["entries"][key] = e
+        e["want_" + need] = True
+        _PL["dirty"] = True                               # joins the one-launch table at the next presplit_begin()
+        _split_one(e, base)
+    elif e["epoch"] != _PL["epoch"] or e["version"] != base._version:
+        if capturing:
+            return
+        _split_one(e, base)
+    lib.raw("dc_gemm_next_b_planes")(e[need].data_ptr(), n * k, n if transposed else k, 1 if transposed else 0)
+
+
 USE_MFMA_TN = True      # A/B switch: hand-written fp32-MFMA kernel for the tall-skinny weight gradients
 OWN_TN_MAX_OUTPUTS = 1 << 21
 
@@ -399,6 +521,7 @@ def mm_nt(x, w, out=None):
         return out
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    _hint_planes(w, False)
     lib.call("dc_linear_forward", x, x.stride(0), w, w.stride(0), m, n, k, out, out.stride(0), 0)
     return out
 
@@ -419,46 +542,17 @@ def mm_nn(dy, w, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty(m, k, dtype=torch.float32, device=dy.device)
+    _hint_planes(w, True)
     lib.call("dc_linear_backward_input", dy, dy.stride(0), w, w.stride(0), m, n, k, out, out.stride(0), int(accumulate), 0)
     return out
 
 
-# Both gradients of a Linear layer from one entry point (dc_linear_backward_pair: the weight gradient's slab reduction runs
-# as side workgroups of the input-gradient launch).  Same bits, 11 launches fewer per ModelNet40 step -- and 50 - 70 us SLOWER
-# per step in every placement tried (side workgroups last: an extra round behind the product; first: they delay its first
-# round and evict the operands from L2; profiles/r03_pair_ab.txt): off by default, env DC_PAIR=1 switches it on.
-USE_PAIR = os.environ.get("DC_PAIR", "0") == "1"
-
-
-def _pair_ok(dh, x, w, out):
-    r, n = dh.shape
-    k = w.shape[1]
-    return (USE_PAIR and USE_MFMA_TN and _own_gemm(dh) and r >= 8192 and n * k <= min(OWN_TN_MAX_OUTPUTS, OWN_GEMM_MAX_WEIGHT)
-            and x.dtype == torch.float32 and x.stride(1) == 1 and (out is None or out.stride(1) == 1))
-
-
-def linear_grads(dh, x, w, dx_out=None, accumulate=False, bn=None):
+def linear_grads(dh, x, w, dx_out=None, accumulate=False):
     """Both gradients of y = x w^T for the incoming dh [R, N]: -> (dW [N, K], dX [R, K]); dX lands in `dx_out`
-    (+= when accumulate) if given.  bn = (h, ldh, coefs, slope): dh is the BatchNorm/activation backward of (dh, h), formed
-    in the operand loaders (bn_block_backward).  One entry point (dc_linear_backward_pair): the ordered slab reduction of
-    dW runs as the tail workgroups of the dX launch; where that does not apply, the two separate products."""
+    (+= when accumulate) if given."""
     dh, w = _rowmajor(dh), _rowmajor(w)
-    if bn is None and not _pair_ok(dh, x, w, dx_out):
-        xx = x if x.stride(1) == 1 else x.contiguous()
-        return gemm_tn(dh, xx), mm_nn(dh, w, out=dx_out, accumulate=accumulate)
-    x = _rowmajor(x)
-    r, n = dh.shape
-    k = w.shape[1]
-    dev = dh.device
-    dW = torch.empty(n, k, dtype=torch.float32, device=dev)
-    dX = dx_out if dx_out is not None else torch.empty(r, k, dtype=torch.float32, device=dev)
-    assert dx_out is not None or not accumulate
-    nb = lib.raw("dc_gemm_tn_workspace_bytes")(r, n, k)
-    ws = torch.empty((nb + 3) // 4, dtype=torch.float32, device=dev)
-    h, ldh, coefs, slope = bn if bn is not None else (None, 0, None, 0.0)
-    lib.call("dc_linear_backward_pair", dh, dh.stride(0), h, ldh, coefs, slope, x, x.stride(0), w, w.stride(0), r, n, k, dW, k, 0,
-             dX, dX.stride(0), int(accumulate), ws, ws.numel() * 4)
-    return dW, dX
+    xx = x if x.stride(1) == 1 else x.contiguous()
+    return gemm_tn(dh, xx), mm_nn(dh, w, out=dx_out, accumulate=accumulate)
 
 
 def linear_stats(x, w, bn, gamma, beta, vn=0):
@@ -487,6 +581,7 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
     if use_batch and _own_gemm(x) and sync_group() is None:
         nb = lib.raw("dc_linear_stats_workspace_bytes")(m, n, k, 0)
         ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
+        _hint_planes(w, False)
         if vn:
             lib.call("dc_linear_vn_stats_forward", x, x.stride(0), w, w.stride(0), rows, c, k, h, n, int(vn == 2), gamma,
                      beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
@@ -530,9 +625,6 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
         coefs = torch.empty(5 * c, dtype=torch.float32, device=dev)
         lib.call("dc_bn_act_backward_reduce", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
                  int(use_batch), dg, db, coefs, ws, nb)
-        if want_dinp and USE_PAIR and lddy == dy.stride(0):
-            dW, dinp = linear_grads(dy, inp, W, dx_out=dinp_out, accumulate=accumulate, bn=(h, c, coefs, slope))
-            return dW, dg, db, dinp
         dW = torch.empty(c, k, dtype=torch.float32, device=dev)
         nb2 = lib.raw("dc_gemm_tn_workspace_bytes")(r, c, k)
         ws2 = torch.empty((nb2 + 3) // 4, dtype=torch.float32, device=dev)
@@ -542,6 +634,7 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
         if want_dinp:
             dinp = dinp_out if dinp_out is not None else torch.empty(r, k, dtype=torch.float32, device=dev)
             W = _rowmajor(W)
+            _hint_planes(W, True)
             lib.call("dc_linear_bn_backward_input", dy, lddy, h, c, coefs, slope, W, W.stride(0), r, c, k, dinp,
                      dinp.stride(0), int(accumulate), 0)
         return dW, dg, db, dinp

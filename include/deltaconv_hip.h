@@ -41,7 +41,8 @@ const char* dc_last_error(void);
  * fp64 no larger than the chain's); 4: first-round phase shift of every second 128 x 128 GEMM workgroup of a CU in
  * percent of a K loop (0 = default 50, negative = off); 5 / 6: force the weight-gradient tile (1..4) / slab count;
  * 7: units (tile x 64-channel slab) per workgroup of the persistent two-piece tiled applies (0 = launcher's choice);
- * 8: value 1 = CSC count / scan / fill by one workgroup per cloud (round 3) instead of eight column ranges per cloud. */
+ * 8: value 1 = CSC count / scan / fill by one workgroup per cloud (round 3) instead of eight column ranges per cloud;
+ * 9: value 1 = ignore pre-split weight planes (every product splits its weight operand in the K loop, as in round 3). */
 int dc_set_option(int32_t key, int32_t value);
 
 /* ---- graph ------------------------------------------------------------------------------- */
@@ -332,6 +333,16 @@ int dc_vn_backward_apply(const float* dout, int64_t lddo, const float* in, int64
                          const float* gamma, int32_t training, const float* m1, const float* m2, float* din,
                          int64_t lddi, void* stream);
 
+/* ---- pre-split weight planes (round 4) -----------------------------------------------------------------------------
+ * The split products cut every fp32 operand into three bfloat16 planes.  For the WEIGHT operand of the Linear layers
+ * (nn/mlp.py:9,15) that work is the same in every workgroup of every product of a step: dc_presplit_weights cuts all
+ * registered weight matrices once (one launch; table = device records {src, fwd planes | NULL, bwd planes | NULL, rows, cols,
+ * row stride}, chunk_start = prefix of ceil(rows * cols / 1024) per record), dc_gemm_next_b_planes hands the planes of the
+ * next dc_linear_* product of the calling thread to the library (transposed = planes of W^T, for dc_linear_backward_input).
+ * Same bits as the in-loop split; the hint is ignored where it does not apply. */
+int dc_presplit_weights(const int64_t* table, const int32_t* chunk_start, int32_t n_entries, int32_t total_chunks, void* stream);
+int dc_gemm_next_b_planes(const void* planes, int64_t plane_elems, int64_t ld, int32_t transposed);
+
 /* ---- forward / input-gradient GEMMs of the per-point Linear layers on the fp32 matrix cores -------------
  * Replace ATen addmm / mm behind every `Linear(bias=False)` of deltaconv/nn/mlp.py:9,15 (forward product and the
  * input-gradient product of its autograd).  v_mfma_f32_32x32x2_f32 (exact fp32), LDS-staged, any M, N, K and
@@ -378,15 +389,6 @@ int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const float* h, int
 int dc_linear_bn_backward_input(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
                                 float slope, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K, float* dX,
                                 int64_t lddx, int32_t accumulate, int32_t tile, void* stream);
-/* Both gradients of y = x W^T in one call: dW[N,K] (+)= dh^T X and dX[R,K] (+)= dh W, dh = dy (h == coefs == NULL) or
- * the BatchNorm/activation backward of (dy, h) formed in the operand loaders (coefs: dc_bn_act_backward_reduce).  Same
- * results, bit for bit, as dc_gemm_tn / dc_linear_bn_backward_weight followed by dc_linear_[bn_]backward_input; the
- * ordered slab reduction of dW runs as the tail workgroups of the dX launch (one launch less per layer).  Replaces the
- * autograd of nn.Linear inside the reference's MLP blocks (nn/mlp.py:9-16).  Workspace: dc_gemm_tn_workspace_bytes(R, N, K). */
-int dc_linear_backward_pair(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs, float slope,
-                            const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t R, int32_t N, int32_t K,
-                            float* dW, int64_t lddw, int32_t accumulate_w, float* dX, int64_t lddx, int32_t accumulate_x,
-                            void* workspace, size_t workspace_bytes, void* stream);
 int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
                                  float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K, float* dW,
                                  int64_t lddw, int32_t accumulate, void* workspace, size_t workspace_bytes,

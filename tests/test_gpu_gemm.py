@@ -321,32 +321,93 @@ def test_split_products_nonfinite_operands():
         opt(3, 0)
 
 
-@pytest.mark.parametrize("R,N,K", [(32768, 128, 256), (32768, 1024, 448), (16384, 64, 64), (9000, 40, 70), (8192, 256, 12)])
-@pytest.mark.parametrize("bn", [False, True])
-@pytest.mark.parametrize("acc", [0, 1])
-def test_backward_pair_equals_separate_products(R, N, K, bn, acc):
-    """dc_linear_backward_pair (weight-gradient slab reduction as tail workgroups of the input-gradient launch) returns the
-    bits of the two separate entry points: plain and BatchNorm-prologue forms, accumulate on / off, ragged shapes."""
-    g = torch.Generator().manual_seed(R + N + K)
-    dy, x = torch.randn(R, N, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
-    w = torch.randn(N, K, generator=g).to(DEV)
-    h = torch.randn(R, N, generator=g).to(DEV) if bn else None
-    coefs = torch.randn(5 * N, generator=g).to(DEV) if bn else None
-    slope = 0.2
-    nb = lib.raw("dc_gemm_tn_workspace_bytes")(R, N, K)
-    ws = torch.empty((nb + 3) // 4, device=DEV)
-    base_w, base_x = torch.randn(N, K, generator=g).to(DEV), torch.randn(R, K, generator=g).to(DEV)
-    dW1, dX1 = base_w.clone(), base_x.clone()
-    if bn:
-        lib.call("dc_linear_bn_backward_weight", dy, N, h, N, coefs, slope, x, K, R, N, K, dW1, K, acc, ws, ws.numel() * 4)
-        lib.call("dc_linear_bn_backward_input", dy, N, h, N, coefs, slope, w, K, R, N, K, dX1, K, acc, 0)
+@pytest.mark.parametrize("M,N,K", [(32768, 1024, 448), (16384, 256, 512), (8192, 128, 128), (8192, 64, 256), (4096, 64, 64),
+                                   (8192, 448, 1024)])
+def test_presplit_weight_planes(M, N, K):
+    """Round 4: the weight operand of a product arrives as bf16 planes cut once per step (dc_presplit_weights +
+    dc_gemm_next_b_planes) instead of being cut by every wave in its K loop.  Same planes, same MFMA order: on 128-column
+    tiles the product from planes returns the SAME BITS as the in-loop split (forward and input gradient); on 64-column
+    tiles (in-loop: exact chain) it is a split product: no further from fp64 than 1.5 x the exact chain + 1e-7.  A weight
+    modified after the cut is cut again at its next use (no stale planes, no dependence on the call history)."""
+    from deltaconv_amd.nn import fused
+    fused._planes_reset()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, dy = torch.randn(M, K, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV))
+    opt = lib.raw("dc_set_option")
+
+    def products():
+        with torch.no_grad():
+            return fused.mm_nt(x, w), fused.mm_nn(dy, w)
+    try:
+        opt(9, 1)
+        y0, dx0 = products()                    # in-loop split / exact chain; also registers the weight
+        opt(9, 0)
+        fused.presplit_begin()                  # cuts the planes
+        e = next(iter(fused._PL["entries"].values()))
+        assert e["fwd"] is not None and e["bwd"] is not None and e["epoch"] == fused._PL["epoch"]
+        y1, dx1 = products()
+        # the planes themselves (fragment-major: [row block of 32][k-step of 16][k-half][row % 32][8]): hi + mid + lo
+        # reconstructs the weight to 2^-24, and the backward planes are those of the transpose
+        def unblock(pl, rows, cols):
+            return pl.view(torch.bfloat16).view(3, rows // 32, cols // 16, 2, 32, 8).permute(0, 1, 4, 2, 3, 5).reshape(3, rows, cols)
+        pf, pb = unblock(e["fwd"], N, K), unblock(e["bwd"], K, N)
+        assert rel_err(pf.double().sum(0), w.detach().double()) < 2.0 ** -23
+        assert torch.equal(pb, pf.transpose(1, 2))
+        with torch.no_grad():
+            w.mul_(1.5)                         # version bump: the planes are stale now ...
+        y2, dx2 = products()                    # ... and are cut again on the spot (never used stale)
+        fused.presplit_begin()
+        y3, dx3 = products()
+    finally:
+        opt(9, 0)
+        fused._planes_reset()
+    ref_y, ref_dx = x[:2048].double() @ (w.detach().double() / 1.5).t(), dy[:2048].double() @ (w.detach().double() / 1.5)
+    for name, a, b, ref, cols, red in (("fwd", y0, y1, ref_y, N, K), ("dx", dx0, dx1, ref_dx, K, N)):
+        if cols % 128 == 0:
+            assert torch.equal(a, b), name      # same bits as the in-loop split
+        else:
+            e0, e1 = rel_err(a[:2048], ref), rel_err(b[:2048], ref)
+            assert e1 < 1.5 * e0 + 1e-7 and e1 < _tol(red), (name, e0, e1)
+            assert not torch.equal(a, b), name  # the 64-column tiles really took the split path
+    assert torch.equal(y2, y3) and torch.equal(dx2, dx3)      # stale planes are never used: refreshed at the use == refreshed by the batch cut
+    assert rel_err(y2[:2048], 1.5 * ref_y) < _tol(K) and rel_err(dx2[:2048], 1.5 * ref_dx) < _tol(N)
+
+
+@pytest.mark.parametrize("R,C,K", [(16384, 256, 512), (8192, 128, 64), (8192, 64, 256)])
+def test_presplit_planes_with_batchnorm_prologue(R, C, K):
+    """The input-gradient product whose operand loader rebuilds the BatchNorm / activation backward (dc_linear_bn_backward_input)
+    from the transposed weight planes: same bits as without planes on 128-column outputs (same planes, same MFMA order; the
+    pipelined loop instead of the simple one), fp32-accurate on 64-column outputs."""
+    from deltaconv_amd.nn import fused
+    fused._planes_reset()
+    g = torch.Generator().manual_seed(R + C + K)
+    dy, h = torch.randn(R, C, generator=g).to(DEV), torch.randn(R, C, generator=g).to(DEV)
+    coefs = torch.randn(5 * C, generator=g).to(DEV)
+    w = torch.nn.Parameter((torch.randn(C, K, generator=g) / math.sqrt(C)).to(DEV))
+    opt = lib.raw("dc_set_option")
+
+    def dx():
+        out = torch.empty(R, K, device=DEV)
+        with torch.no_grad():
+            fused._hint_planes(w, True)
+            lib.call("dc_linear_bn_backward_input", dy, C, h, C, coefs, 0.2, w, K, R, C, K, out, K, 0, 0)
+        return out
+    try:
+        opt(9, 1)
+        a = dx()
+        opt(9, 0)
+        fused.presplit_begin()
+        b = dx()
+    finally:
+        opt(9, 0)
+        fused._planes_reset()
+    cf = coefs.view(5, C).double()
+    z = cf[0] * h.double() + cf[1]
+    dh = cf[2] * dy.double() * torch.where(z > 0, 1.0, 0.2) + cf[3] * h.double() + cf[4]
+    ref = dh[:2048] @ w.detach().double()
+    assert rel_err(b[:2048], ref) < _tol(C)
+    if K % 128 == 0:
+        assert torch.equal(a, b)
     else:
-        lib.call("dc_gemm_tn", dy, N, x, K, R, N, K, dW1, K, acc, ws, ws.numel() * 4)
-        lib.call("dc_linear_backward_input", dy, N, w, K, R, N, K, dX1, K, acc, 0)
-    dW2, dX2 = base_w.clone(), base_x.clone()
-    lib.call("dc_linear_backward_pair", dy, N, h, N if bn else 0, coefs, slope, x, K, w, K, R, N, K, dW2, K, acc, dX2, K, acc,
-             ws, ws.numel() * 4)
-    assert torch.equal(dW1, dW2) and torch.equal(dX1, dX2)
-    ref_w = (dy.double().t() @ x.double()) if not bn else None
-    if ref_w is not None and not acc:
-        assert rel_err(dW2, ref_w) < _tol(R)
+        assert rel_err(b[:2048], ref) < 1.5 * rel_err(a[:2048], ref) + 1e-7
