@@ -1231,39 +1231,58 @@ __device__ __forceinline__ void split1(float x, unsigned short& h, unsigned shor
     const float q = r - __builtin_bit_cast(float, mp << 16);
     h = (unsigned short)(hp & 0xffffu); m = (unsigned short)(mp & 0xffffu); l = (unsigned short)(pk_bf16(q, 0.f) & 0xffffu);
 }
-// one workgroup = 1024 consecutive elements of one matrix; chunk_start[e] = first chunk of entry e (ascending)
+// one workgroup = one 32 x 32 tile of one matrix (rows and columns are multiples of 32); chunk_start[e] = first tile of entry e.
+// Thread (r, c4) reads four consecutive columns of row r (coalesced 128-byte rows), cuts them, and
+//   * stores its 4 consecutive plane elements of the FORWARD layout with one 8-byte store per plane (fragment-major: (row block
+//     of 32, k-step of 16) -> 64 lanes x 8 elements, lane = 32 * (k-half) + row % 32: the 32 rows of a tile are 32 consecutive lanes);
+//   * passes the tile through LDS for the planes of the TRANSPOSE: there a lane holds 8 consecutive ROWS of one column -- 16-byte
+//     stores, 32 columns = 32 consecutive lanes.  (The first version wrote 2-byte elements at scattered addresses: 15 us per step.)
 __global__ __launch_bounds__(256) void presplit_kernel(const PresplitEntry* __restrict__ table, const int* __restrict__ chunk_start,
                                                        int n_entries) {
-    int lo = 0, hi = n_entries;                             // entry of this chunk (<= ~6 steps on cached words)
+    __shared__ unsigned short tl[3][32][34];
+    int lo = 0, hi = n_entries;                             // entry of this tile (<= ~6 steps on cached words)
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (chunk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
     }
     const PresplitEntry e = table[lo];
-    const long total = e.n * e.k, c0 = ((long)blockIdx.x - chunk_start[lo]) * 1024;
+    const long total = e.n * e.k;
+    const int tiles_c = (int)(e.k >> 5);
+    const int t = (int)blockIdx.x - chunk_start[lo];
+    const long rb = t / tiles_c, cb = t - rb * tiles_c;     // tile = rows 32 rb .., columns 32 cb ..
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(e.src + (rb * 32 + r) * e.ld + cb * 32 + c0);
+    unsigned short h[4], m[4], l[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const long i = c0 + u * 256 + threadIdx.x;
-        if (i < total) {
-            const long r = i / e.k, c = i - r * e.k;
-            unsigned short h, m, l;
-            split1(e.src[r * e.ld + c], h, m, l);
-            // fragment-major: (row block of 32, k-step of 16) -> 64 lanes x 8 elements; lane = 32 * (k-half) + row % 32
-            if (e.fwd) {
-                const long j = (((r >> 5) * (e.k >> 4) + (c >> 4)) * 64 + ((c & 15) >> 3) * 32 + (r & 31)) * 8 + (c & 7);
-                e.fwd[j] = h; e.fwd[total + j] = m; e.fwd[2 * total + j] = l;
-            }
-            if (e.bwd) {                                    // the same for the transpose: rows <-> columns
-                const long j = (((c >> 5) * (e.n >> 4) + (r >> 4)) * 64 + ((r & 15) >> 3) * 32 + (c & 31)) * 8 + (r & 7);
-                e.bwd[j] = h; e.bwd[total + j] = m; e.bwd[2 * total + j] = l;
-            }
+    for (int q = 0; q < 4; ++q) split1(x[q], h[q], m[q], l[q]);
+    if (e.fwd) {
+        const long c = cb * 32 + c0;                        // global column of element 0: same k-step / k-half for all four
+        const long j = (((rb * (e.k >> 4) + (c >> 4)) * 64 + ((c & 15) >> 3) * 32 + r) * 8) + (c & 7);
+        *reinterpret_cast<uint2*>(e.fwd + j) = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        *reinterpret_cast<uint2*>(e.fwd + total + j) = make_uint2(m[0] | ((unsigned)m[1] << 16), m[2] | ((unsigned)m[3] << 16));
+        *reinterpret_cast<uint2*>(e.fwd + 2 * total + j) = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+    }
+    if (e.bwd) {                                            // block-uniform
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { tl[0][r][c0 + q] = h[q]; tl[1][r][c0 + q] = m[q]; tl[2][r][c0 + q] = l[q]; }
+        __syncthreads();
+        // transposed planes: rows <-> columns.  Item = (plane, column c, octet of rows): 3 x 32 x 4 = 384 items of 16 bytes
+        for (int idx = threadIdx.x; idx < 384; idx += 256) {
+            const int p = idx >> 7, rem = idx & 127, c = rem & 31, oct = rem >> 5;
+            unsigned w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = tl[p][oct * 8 + 2 * q][c] | ((unsigned)tl[p][oct * 8 + 2 * q + 1][c] << 16);
+            const long rg = rb * 32 + oct * 8;              // first of the eight rows: k-step rg / 16, k-half (rg % 16) / 8
+            const long j = ((cb * (e.n >> 4) + (rg >> 4)) * 64 + ((rg & 15) >> 3) * 32 + c) * 8;
+            *reinterpret_cast<uint4*>(e.bwd + (long)p * total + j) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
 }
 }  // namespace
 
 // table: device array of n_entries records {src, fwd planes or NULL, bwd (transposed) planes or NULL, rows, cols, row stride}
-// (six 64-bit words each); chunk_start: device int32 [n_entries + 1], chunk_start[e + 1] - chunk_start[e] = ceil(rows * cols / 1024).
+// (six 64-bit words each); chunk_start: device int32 [n_entries + 1], chunk_start[e + 1] - chunk_start[e] = rows * cols / 1024
+// (tiles of 32 x 32; rows, cols multiples of 32, src rows 16-byte aligned).
 // fwd = three planes of rows x cols bf16, bwd = three planes of the transpose, both FRAGMENT-MAJOR (see presplit_kernel); rows
 // and cols multiples of 32.
 DC_EXPORT int dc_presplit_weights(const int64_t* table, const int32_t* chunk_start, int32_t n_entries, int32_t total_chunks,

@@ -133,7 +133,8 @@ class FlatGradDataParallel:
             set_sync_bn(True, process_group)    # stays on for this process: backward runs outside __call__
         if broadcast and (self.world > 1 or (always_reduce and dist.is_initialized())):   # identical weights / buffers
             for t in list(module.parameters()) + list(module.buffers()):
-                dist.broadcast(t.data, 0, group=self.group)
+                dist.broadcast(t.detach(), 0, group=self.group)     # (detach() shares the version counter, .data does not:
+                #  caches keyed on it -- inference BatchNorm maps, pre-split weight planes -- see the new contents)
 
     def __call__(self, *a, **kw):
         return self.module(*a, **kw)

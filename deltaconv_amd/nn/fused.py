@@ -356,6 +356,13 @@ def _planes_reset():
     _PL.update(entries={}, order=[], table=None, chunks=None, n_chunks=0, dirty=False)
 
 
+def invalidate_planes():
+    """Declare every pre-split plane stale.  Only needed after weights were written behind autograd's back (`p.data...`,
+    raw pointers): in-place updates through tracked tensors (optimizers, load_state_dict, `copy_`) bump the version counter
+    the cache watches, and graph replays bump the epoch themselves."""
+    _PL["epoch"] += 1
+
+
 def presplit_begin():
     """Cut every registered weight into its bf16 planes (one launch).  Call once per forward pass, before its first product."""
     if not USE_WEIGHT_PLANES or not _PL["entries"]:
