@@ -971,15 +971,17 @@ struct Prologue { const float* h; long ldh; const float* coefs; int ncoef; float
 //   transposed == 0: planes of W[N, K] as stored (forward products: the rows are the output columns);
 //   transposed != 0: planes of W^T [K, N] (input-gradient products dX = dY W: their output columns are W's columns).
 // ld = reduction length of the planes (K resp. N of W), plane_elems = distance between two planes = N * K.  Consumed (and cleared) by the next
-// dc_linear_* call whatever its outcome; ignored where the planes do not apply (ragged shapes, exact chain, prologue forms).
-struct BHint { const unsigned short* p; long stride, ld; int transposed; };
-thread_local BHint g_bhint = {nullptr, 0, 0, 0};
+// dc_linear_* call whatever its outcome; ignored where the planes do not apply (ragged shapes, exact chain, prologue forms) and when
+// that product's weight operand is not `src` (a hint left behind by a call that failed before its product was enqueued).
+struct BHint { const void* src; const unsigned short* p; long stride, ld; int transposed; };
+thread_local BHint g_bhint = {nullptr, nullptr, 0, 0, 0};
 
 int run_gemm(const char* name, int bl, int epi, const float* A, long lda, const float* B, long ldb, long M, int N, int K,
              float* C, long ldc, int accumulate, int tile, double* part, int stat_cols, hipStream_t s,
              const Prologue* pro = nullptr) {
-    const BHint hint = g_bhint;
-    g_bhint = BHint{nullptr, 0, 0, 0};
+    BHint hint = g_bhint;
+    g_bhint = BHint{nullptr, nullptr, 0, 0, 0};
+    if (hint.src != static_cast<const void*>(B)) hint.p = nullptr;
     // (round 4 lab: N = q * 128 + 64 output columns as two launches -- q * 128 columns on 128-column split tiles + 64 on 64-column
     //  tiles -- is 27 us faster in isolation for 32768 x 448 x 1024 and 8 us SLOWER inside the step, same-box A/B: not used)
     const Tile t = pick_tile(M, N, K, tile);
@@ -1297,8 +1299,8 @@ DC_EXPORT int dc_presplit_weights(const int64_t* table, const int32_t* chunk_sta
 }
 
 // Planes of the weight operand of the NEXT dc_linear_* product enqueued by the calling thread (see BHint above).
-DC_EXPORT int dc_gemm_next_b_planes(const void* planes, int64_t plane_elems, int64_t ld, int32_t transposed) {
-    g_bhint = BHint{static_cast<const unsigned short*>(planes), (long)plane_elems, (long)ld, transposed ? 1 : 0};
+DC_EXPORT int dc_gemm_next_b_planes(const void* weight, const void* planes, int64_t plane_elems, int64_t ld, int32_t transposed) {
+    g_bhint = BHint{weight, static_cast<const unsigned short*>(planes), (long)plane_elems, (long)ld, transposed ? 1 : 0};
     return DC_OK;
 }
 

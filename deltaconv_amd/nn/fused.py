@@ -369,6 +369,8 @@ def presplit_begin():
         return
     capturing = torch.cuda.is_current_stream_capturing()
     ents = _PL["entries"]
+    if capturing:
+        _PL["captured_epoch"] = None             # set below once this capture has cut its own planes
     if not capturing:
         dead = [k for k, e in ents.items() if e["wref"]() is None]
         for k in dead:
@@ -406,6 +408,8 @@ def presplit_begin():
             return
     lib.call("dc_presplit_weights", _PL["table"], _PL["chunks"], len(_PL["order"]), _PL["n_chunks"])
     _PL["epoch"] += 1
+    if capturing:
+        _PL["captured_epoch"] = _PL["epoch"]     # planes cut INSIDE the capture: the only ones a captured product may use
     for key in _PL["order"]:
         e = ents.get(key)
         if e is not None:
@@ -439,7 +443,7 @@ def _hint_planes(w, transposed):
     n, k = w.shape
     if n % 32 or k % 32:
         return                                            # the fragment-major plane layout wants whole 32 x 16 blocks
-    key = (w.data_ptr(), n, k)
+    key = (w.device.index, w.data_ptr(), n, k)
     need = "bwd" if transposed else "fwd"
     e = _PL["entries"].get(key)
     capturing = torch.cuda.is_current_stream_capturing()
@@ -465,7 +469,11 @@ def _hint_planes(w, transposed):
         if capturing:
             return
         _split_one(e, base)
-    lib.raw("dc_gemm_next_b_planes")(e[need].data_ptr(), n * k, n if transposed else k, 1 if transposed else 0)
+    if capturing and e["epoch"] != _PL.get("captured_epoch"):
+        # cut before the capture began: a replay would read them again after a captured optimizer update moved the weight --
+        # only planes that the captured presplit_begin() rewrites in every replay are safe inside a graph
+        return
+    lib.raw("dc_gemm_next_b_planes")(w.data_ptr(), e[need].data_ptr(), n * k, n if transposed else k, 1 if transposed else 0)
 
 
 USE_MFMA_TN = True      # A/B switch: hand-written fp32-MFMA kernel for the tall-skinny weight gradients

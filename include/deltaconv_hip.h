@@ -339,9 +339,11 @@ int dc_vn_backward_apply(const float* dout, int64_t lddo, const float* in, int64
  * registered weight matrices once (one launch; table = device records {src, fwd planes | NULL, bwd planes | NULL, rows, cols,
  * row stride}, chunk_start = prefix of ceil(rows * cols / 1024) per record), dc_gemm_next_b_planes hands the planes of the
  * next dc_linear_* product of the calling thread to the library (transposed = planes of W^T, for dc_linear_backward_input).
+ * `weight` is the fp32 matrix the planes were cut from: the hint is dropped unless the next product's weight operand is that
+ * pointer (a hint left behind by a call that failed before its product cannot reach another product of the same shape).
  * Same bits as the in-loop split; the hint is ignored where it does not apply. */
 int dc_presplit_weights(const int64_t* table, const int32_t* chunk_start, int32_t n_entries, int32_t total_chunks, void* stream);
-int dc_gemm_next_b_planes(const void* planes, int64_t plane_elems, int64_t ld, int32_t transposed);
+int dc_gemm_next_b_planes(const void* weight, const void* planes, int64_t plane_elems, int64_t ld, int32_t transposed);
 
 /* ---- forward / input-gradient GEMMs of the per-point Linear layers on the fp32 matrix cores -------------
  * Replace ATen addmm / mm behind every `Linear(bias=False)` of deltaconv/nn/mlp.py:9,15 (forward product and the

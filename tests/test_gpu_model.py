@@ -356,6 +356,50 @@ def test_graphed_training_matches_eager():
         assert torch.equal(sd1[key], sd2[key]), key
 
 
+def test_graph_capture_does_not_reuse_weight_planes_cut_before_it():
+    """One eager step registers the weights with the pre-split plane cache and cuts their planes on the spot, but the
+    one-launch table only exists from the SECOND forward pass on.  A capture right after that first step (warmup=0) must not
+    bake those planes into the graph: replays would multiply by the weights of the capture instant while the captured SGD
+    update moves the real ones.  The losses of the replayed steps follow the eager ones (2e-3 relative: the captured products
+    split in their K loop, the eager ones read planes -- same bits on 128-column tiles, rounding-level elsewhere; stale planes
+    show as the loss of an OLDER step, several percent off at this learning rate)."""
+    from deltaconv_amd.graph_step import GraphedTrainStep
+    from deltaconv_amd.nn import fused
+    from deltaconv_amd.utils import calc_loss
+    batches = [synthetic_batch(4, 256, seed=60 + i).to(DEV) for i in range(2)]
+
+    def make():
+        torch.manual_seed(6)
+        m = _no_dropout(_model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).train())
+        return m, torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+
+    def eager_step(m, opt, b):
+        for p in m.parameters():
+            p.grad = None
+        loss = calc_loss(m(b), b.y)
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    order = (batches[1], batches[0], batches[1], batches[0], batches[1])
+    m1, o1 = make()
+    ref = [eager_step(m1, o1, batches[0])] + [eager_step(m1, o1, b) for b in order]
+    assert abs(ref[1] - ref[-1]) > 0.02 * abs(ref[1])           # the loss moves: a stale forward pass would be visible
+
+    fused._planes_reset()
+    m2, o2 = make()
+    first = eager_step(m2, o2, batches[0])
+    assert first == ref[0]
+    static = synthetic_batch(4, 256, seed=60).to(DEV)
+    step = GraphedTrainStep(m2, calc_loss, static, optimizer=o2, warmup=0)    # the capture itself does not execute a step
+    got = [float(step(b)) for b in order]
+    for a, b in zip(got, ref[1:]):
+        assert abs(a - b) <= 2e-3 * abs(b), (got, ref[1:])
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        err = float((p1 - p2).abs().sum() / p1.abs().sum().clamp_min(1e-12))
+        assert err < 2e-2, (n1, err)
+
+
 # ---- C1 (ModelNet40, 1024 points, k = 20, batch 1: BASELINE.json configs[0]) ----------------------------
 def _oracle_pair(kind, kw, k, seed=1):
     """(oracle model fp32, deltaconv_amd model on the GPU) with identical weights."""
