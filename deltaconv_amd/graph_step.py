@@ -58,11 +58,14 @@ class GraphedTrainStep:
         self.static = sample_batch
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.warmup = warmup
+        self._one = None                        # the seed of the backward pass, made once (see _step)
         self.recapture()
 
     def recapture(self):
         if self.reducer is not None and self.reducer.flat is None and self.warmup == 0:
             self.warmup = 1                     # the flat gradient buffer must exist before the capture
+        if self._one is None:                   # made outside the capture (inside, it would be a captured fill again)
+            self._one = torch.ones((), dtype=torch.float32, device=self.static.pos.device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up outside the capture (allocator, tuning)
@@ -105,7 +108,13 @@ class GraphedTrainStep:
     def _step(self, capture=False):
         out = self.model(self.static)
         loss = self.loss_fn(out, self.static.y)
-        loss.backward()
+        if loss.dim() == 0 and loss.is_floating_point():
+            # loss.backward() seeds the pass with ones_like(loss): a fill launch in every replay (~5 us of launch floor)
+            if self._one is None or self._one.dtype != loss.dtype or self._one.device != loss.device:
+                self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+            torch.autograd.backward(loss, grad_tensors=(self._one,))
+        else:
+            loss.backward()
         if self.reducer is not None:
             self.reducer.pack()                 # captured: one multi-tensor copy into the flat buffer
             if not capture:                     # warm-up steps: the rest of the reduction + the update, eagerly
