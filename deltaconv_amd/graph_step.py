@@ -64,6 +64,9 @@ class GraphedTrainStep:
     def recapture(self):
         if self.reducer is not None and self.reducer.flat is None and self.warmup == 0:
             self.warmup = 1                     # the flat gradient buffer must exist before the capture
+        if hasattr(self.static, "pos") and hasattr(self.static, "batch"):
+            from .models.deltanet_base import _ptr_info
+            _ptr_info(self.static)              # cloud offsets of the static batch: a host read, never inside the capture
         if self._one is None:                   # made outside the capture (inside, it would be a captured fill again)
             self._one = torch.ones((), dtype=torch.float32, device=self.static.pos.device)
         side = torch.cuda.Stream()

@@ -357,12 +357,14 @@ def test_graphed_training_matches_eager():
 
 
 def test_graph_capture_does_not_reuse_weight_planes_cut_before_it():
-    """One eager step registers the weights with the pre-split plane cache and cuts their planes on the spot, but the
-    one-launch table only exists from the SECOND forward pass on.  A capture right after that first step (warmup=0) must not
-    bake those planes into the graph: replays would multiply by the weights of the capture instant while the captured SGD
-    update moves the real ones.  The losses of the replayed steps follow the eager ones (2e-3 relative: the captured products
-    split in their K loop, the eager ones read planes -- same bits on 128-column tiles, rounding-level elsewhere; stale planes
-    show as the loss of an OLDER step, several percent off at this learning rate)."""
+    """One eager forward/backward pass (no update) registers the weights with the pre-split plane cache and cuts their planes
+    on the spot, but the one-launch table only exists from the SECOND forward pass on.  A capture right after that pass
+    (warmup=0) finds those planes current -- and must still not bake them into the graph: replays would multiply by the weights
+    of the capture instant while the captured SGD update moves the real ones (tools/debug/stale_planes_control.py: with the
+    rule defeated this test fails).  Checked without following a trajectory (at this learning rate two runs drift apart from
+    rounding alone): the logits a replay produces == an eager forward pass of a second model holding the weights and
+    BatchNorm state the captured model had right before that replay (1e-4 of the largest logit; stale planes are the
+    weights of four updates earlier)."""
     from deltaconv_amd.graph_step import GraphedTrainStep
     from deltaconv_amd.nn import fused
     from deltaconv_amd.utils import calc_loss
@@ -371,33 +373,27 @@ def test_graph_capture_does_not_reuse_weight_planes_cut_before_it():
     def make():
         torch.manual_seed(6)
         m = _no_dropout(_model("cls", dict(in_channels=3, num_classes=40), 20, 1e-3).to(DEV).train())
-        return m, torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
-
-    def eager_step(m, opt, b):
-        for p in m.parameters():
-            p.grad = None
-        loss = calc_loss(m(b), b.y)
-        loss.backward()
-        opt.step()
-        return float(loss)
-
-    order = (batches[1], batches[0], batches[1], batches[0], batches[1])
-    m1, o1 = make()
-    ref = [eager_step(m1, o1, batches[0])] + [eager_step(m1, o1, b) for b in order]
-    assert abs(ref[1] - ref[-1]) > 0.02 * abs(ref[1])           # the loss moves: a stale forward pass would be visible
+        return m, torch.optim.SGD(m.parameters(), lr=0.05, weight_decay=1e-4)     # (no state to create inside the capture)
 
     fused._planes_reset()
     m2, o2 = make()
-    first = eager_step(m2, o2, batches[0])
-    assert first == ref[0]
     static = synthetic_batch(4, 256, seed=60).to(DEV)
+    calc_loss(m2(static), static.y).backward()                  # the one eager pass: planes cut, weights untouched since
     step = GraphedTrainStep(m2, calc_loss, static, optimizer=o2, warmup=0)    # the capture itself does not execute a step
-    got = [float(step(b)) for b in order]
-    for a, b in zip(got, ref[1:]):
-        assert abs(a - b) <= 2e-3 * abs(b), (got, ref[1:])
-    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
-        err = float((p1 - p2).abs().sum() / p1.abs().sum().clamp_min(1e-12))
-        assert err < 2e-2, (n1, err)
+    w0 = m2.deltanet_base.convs[1].s_mlp[0][0].weight.detach().clone()
+    for b in (batches[1], batches[0], batches[1]):
+        step(b)
+    sd = {k_: t.detach().clone() for k_, t in m2.state_dict().items()}
+    moved = float((sd["deltanet_base.convs.1.s_mlp.0.0.weight"] - w0).abs().max() / w0.abs().max())
+    assert moved > 1e-3, moved                                  # the weights did move under the replays
+    step(batches[0])
+    got = step.out.clone()
+    m3, _ = make()
+    m3.load_state_dict(sd)
+    with torch.no_grad():
+        ref = m3(batches[0])
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err < 1e-4, err
 
 
 # ---- C1 (ModelNet40, 1024 points, k = 20, batch 1: BASELINE.json configs[0]) ----------------------------
