@@ -134,12 +134,22 @@ __global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const i
         sl[tid] = mysl;
     }
     __syncthreads();
+    const int c = cb + l16 * 4;
+    body.init(c);
+    if constexpr (BODY::ROWPASS) {                                        // every thread, padded points included
+        static_assert(R == 1, "row pass: one row per point");
+        for (int idx = tid; idx < nrow * 16; idx += P * 16) {             // P * 16 is a multiple of 16: idx % 16 == l16
+            Vec<4>* q = reinterpret_cast<Vec<4>*>(rows + (idx >> 4) * 64 + l16 * 4);
+            Vec<4> h = *q;
+            body.cook(h);
+            *q = h;
+        }
+        __syncthreads();
+    }
     const long i = pts[grp];
     if (i < 0) return;
     const G2* cp = reinterpret_cast<const G2*>(cfb + (grp / ppi) * 1024 + (grp % ppi) * (k * 8));
     const unsigned short* lp = reinterpret_cast<const unsigned short*>(lcb) + grp * k;
-    const int c = cb + l16 * 4;
-    body.init(c);
     Vec<4> s0 = vzero<4>(), s1 = vzero<4>();
     if (U <= UL) {
 #pragma unroll 4
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const i
             } else {
                 const float* g = body.in + (long)nbr[i * k + s] * body.ldj + c;
                 p0 = dcell::vload<4>(g);
+                if constexpr (BODY::ROWPASS) body.cook(p0);               // a row that LDS does not hold: raw from memory
                 p1 = R == 2 ? dcell::vload<4>(g + body.hs) : p0;
             }
             body.step(s, BODY::COEF ? cp[s] : G2{0.f, 0.f}, p0, p1);
@@ -345,6 +356,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
 // grad @ x (ell_math.h: grad_fwd)
 struct GradB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr bool ROWPASS = false;
     static constexpr int NST = 2;                      // vector-memory store instructions of finish()
     const float* in; long ldj, hs; float* out; long ldo;
     Vec<4> au, av;
@@ -358,6 +370,7 @@ struct GradB {
 // div @ v (div_fwd)
 struct DivB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr bool ROWPASS = false;
     static constexpr int NST = 1;
     const float* in; long ldj, hs; float* out; long ldo;
     Vec<4> acc;
@@ -368,6 +381,7 @@ struct DivB {
 // [div v | curl v | norm v] (divcurlnorm_fwd)
 struct DivCurlNormB {
     static constexpr bool COEF = true, SELF = true;
+    static constexpr bool ROWPASS = false;
     static constexpr int NST = 3;
     const float* in; long ldj, hs; float* out; long ldo; int C;
     Vec<4> dv, cv;
@@ -390,6 +404,7 @@ struct DivCurlNormB {
 // hodge Laplacian from [div v | curl v] (hodge_fwd): pieces = the two column blocks of one row
 struct HodgeB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr bool ROWPASS = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; float* out; long ldo;
     Vec<4> hu, hv;
@@ -409,6 +424,10 @@ struct HodgeB {
 template <bool AFFINE>
 struct KnnMaxB {
     static constexpr bool COEF = false, SELF = false;
+    // ROWPASS: BatchNorm + activation of the producing block are applied ONCE per unique row, in place in LDS, before the walk
+    // (the same fmaf and select per element as per gathered value before: same bits; ~165 rows instead of 64 x k gathers per tile --
+    // the walk was VALU-bound: 9 of its 12 instructions per gathered value were this transform)
+    static constexpr bool ROWPASS = AFFINE;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const float *scale, *shift; float slope; float* out; long ldo; unsigned char* arg; long lda;
     Vec<4> best; unsigned slot[4]; float sc[4], sh[4];
@@ -417,14 +436,17 @@ struct KnnMaxB {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { sc[q] = scale[c + q]; sh[q] = shift[c + q]; }
     }
+    __device__ void cook(Vec<4>& h) const {                 // a row piece of this thread's four channels, raw -> activated
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float z = fmaf(sc[q], h.v[q], sh[q]);
+            h.v[q] = z > 0.f ? z : slope * z;
+        }
+    }
     __device__ void step(int s, G2, const Vec<4>& h, const Vec<4>&) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float y = h.v[q];
-            if (AFFINE) {
-                const float z = fmaf(sc[q], y, sh[q]);
-                y = z > 0.f ? z : slope * z;
-            }
+            const float y = h.v[q];
             const bool up = s == 0 || y > best.v[q];
             best.v[q] = up ? y : best.v[q];
             slot[q] = up ? (unsigned)s : slot[q];
