@@ -1051,14 +1051,13 @@ int chunks_for(long M, int N, int K, int tile) {
 
 // ---- weight gradient through the LDS-staged kernel (called by dc_gemm_tn, gemm_tn.hip) ----------------------------
 // partial[slab][M][N] = A[rows of the slab, M]^T B[rows of the slab, N];  returns the number of slabs.
-struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; int split; /* N - 64 columns on 128 x 128 tiles + 64 on 64 x 64 */ };
+struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
 int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial, hipStream_t s,
-                     const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f,
-                     const DcTnPlan* forced = nullptr, int ldp = 0);
+                     const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f);
 DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     DcTnPlan pl;
-    pl.split = 0;      // (round 4 lab: N - 64 columns on 128 x 128 split tiles + 64 on 64 x 64 tiles over the same slabs was no faster
-                       //  than 128 x 64 exact tiles for the [1024, 448] embedding weight, 237 vs 237 us: not used)
+    // (round 4 lab: N - 64 output columns on 128 x 128 split tiles + 64 on 64 x 64 tiles over the same slabs was no faster than
+    //  128 x 64 exact tiles for the [1024, 448] embedding weight, 237 vs 237 us: removed, profiles/r04_gemm_planes_ab.txt)
     // r02r sweep (profiles/r02r_tn_sweep.txt): outputs below 64K elements run best on 64 x 64 tiles (more workgroups
     // per slab, shorter epilogues; 4 fit a CU) with ~768 workgroups; larger ones on 128 x 128 tiles with at most 512
     // workgroups = ONE resident wave of 2 per CU (576 cost +25 %: a second, nearly empty round); <= 128 slabs
@@ -1083,20 +1082,10 @@ DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     return pl;
 }
 int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial,
-                     hipStream_t s, const float* h, long ldh, const float* coefs, float slope, const DcTnPlan* forced, int ldp) {
-    if (!forced) {
-        const DcTnPlan whole_plan = dc_tn_lds_plan(R, M, N);
-        if (whole_plan.split) {                                // two launches over the same slabs (see dc_tn_lds_plan)
-            const int n1 = N - 64;
-            const DcTnPlan a{128, 128, whole_plan.slabs, whole_plan.rows_per_slab, 0}, b{64, 64, whole_plan.slabs, whole_plan.rows_per_slab, 0};
-            if (dc_tn_lds_launch(A, lda, B, ldb, R, M, n1, partial, s, h, ldh, coefs, slope, &a, N) < 0) return -1;
-            if (dc_tn_lds_launch(A, lda, B + n1, ldb, R, M, 64, partial + n1, s, h, ldh, coefs, slope, &b, N) < 0) return -1;
-            return whole_plan.slabs;
-        }
-    }
-    const DcTnPlan pl = forced ? *forced : dc_tn_lds_plan(R, M, N);
+                     hipStream_t s, const float* h, long ldh, const float* coefs, float slope) {
+    const DcTnPlan pl = dc_tn_lds_plan(R, M, N);
     const Tile t{pl.bm, pl.bn};
-    const int ldpart = forced ? ldp : N;                       // row stride of the partial tiles (the FULL output width)
+    const int ldpart = N;                                      // row stride of the partial tiles
     const long tiles_m = (M + t.bm - 1) / t.bm;
     GemmP p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = partial; p.ldc = ldpart;

@@ -211,11 +211,10 @@ Plan make_plan(long R, int M, int N) {
 }  // namespace
 
 // LDS-staged variant (gemm.hip): full-line 16-byte loads into LDS, fragments from LDS, 16-byte stores
-struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; int split; };
+struct DcTnPlan { int bm, bn, slabs; long rows_per_slab; };
 DcTnPlan dc_tn_lds_plan(long R, int M, int N);
 int dc_tn_lds_launch(const float* A, long lda, const float* B, long ldb, long R, int M, int N, float* partial, hipStream_t s,
-                     const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f,
-                     const DcTnPlan* forced = nullptr, int ldp = 0);
+                     const float* h = nullptr, long ldh = 0, const float* coefs = nullptr, float slope = 0.f);
 
 DC_EXPORT size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N) {
     const Plan p = make_plan(R, M, N);
