@@ -88,7 +88,10 @@ class GraphedTrainStep:
             invalidate_eval_coeffs()
             self.grads = [(p, p.grad) for p in self.params if p.grad is not None]
             return
-        with torch.cuda.graph(self.graph):
+        # with a process group alive its watchdog thread may query an event of the last warm-up all-reduce while this thread
+        # captures: a global-mode capture would be invalidated by that call (seen with the captured collectives above)
+        mode = "thread_local" if self.reducer is not None else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.loss, self.out = self._step(capture=True)
         torch.cuda.synchronize()
         if self.reducer is not None:            # graph B: scale + update, reading .grad = views of the flat buffer
@@ -97,7 +100,7 @@ class GraphedTrainStep:
             self.flat = self.reducer.flat
             self.reducer.repoint()
             self.graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_update):
+            with torch.cuda.graph(self.graph_update, capture_error_mode=mode):
                 self.reducer.scale()
                 self.optimizer.step()
             torch.cuda.synchronize()
