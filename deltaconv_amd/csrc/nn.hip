@@ -257,6 +257,9 @@ __global__ __launch_bounds__(TPB) void pool_fwd_kernel(const float* __restrict__
     }
     if (c0 < C) {
         const float* base = h + (long)cloud * N * ldh + c0;
+        // 64 rows per thread at 1024 points, two workgroups per CU: without the unroll one or two 16-byte loads per thread are in
+        // flight (3.5 TB/s); eight of them hoisted: 31.6 -> 22.7 us at [32768, 1024] (same order of the sums and comparisons)
+#pragma unroll 8
         for (int r = rl; r < N; r += RT) {
             const FV<V> x = ldv<V>(base + (long)r * ldh);
 #pragma unroll
