@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -45,7 +45,7 @@ def parse():
                          "graph with its collectives captured")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def apply_roofline(graph, grad, div, C, iters=200):
@@ -324,8 +324,25 @@ def cpu_baseline(args):
                        f"host: {phys} physical cores / {hw} hardware threads")
 
 
-def main():
-    args = parse()
+def self_launch_command(args, argv, port=None):
+    """The command line `python bench.py --gpus N` re-executes itself as when no launcher set WORLD_SIZE: the driver's own
+    multi-GPU form, one rank per GPU of this node over RCCL (rendezvous on 127.0.0.1: the container hostname may not
+    resolve).  Pure function of its arguments (tests/test_bench_launch.py)."""
+    if port is None:
+        port = 29500 + os.getpid() % 2000
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: spawn the N ranks ourselves; rank 0 of the child prints the one JSON line
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+        sys.exit(subprocess.call(self_launch_command(args, argv), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -340,7 +357,8 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus and rank == 0:      # a launcher decides the world size; --gpus only documents it
+        print(f"[bench] WORLD_SIZE={world} (launcher) overrides --gpus {args.gpus}", file=sys.stderr)
 
     import deltaconv_amd as dc
     from deltaconv_amd.utils import calc_loss
