@@ -116,7 +116,7 @@ def convert_sync_batchnorm(module):
 class FlatGradDataParallel:
     """Wraps a module: ``zero_grad()`` -> forward/backward as usual -> ``reduce_gradients()``.
     sync_bn=True: BatchNorm statistics over the global batch (see above); the statistics collectives run inside
-    forward and backward, so the HIP-graph step is not available in that mode.
+    forward and backward; GraphedTrainStep then captures the WHOLE step, collectives included, in one graph.
     With graph_step.GraphedTrainStep(..., optimizer=opt, reducer=this) a data-parallel step is three host calls:
     replay (forward + loss + backward + gradient pack) -> one all-reduce -> replay (scale + optimizer update)."""
 

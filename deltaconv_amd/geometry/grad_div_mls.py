@@ -25,15 +25,18 @@ class SparseOp:
         self.kind, self.graph, self.coef = kind, graph, coef
         self._coefT = None
         self._coefTt = None
+        self._coefTt_plan = None
         self._sibling = None
 
     def coefTt(self):
         """Coefficients in the TILE order of the graph's transposed tile plan (transposed applies from LDS); built once."""
-        if self._coefTt is None:
-            pt = self.graph.tile_plan_T()
+        pt = self.graph.tile_plan_T()
+        if self._coefTt is None or self._coefTt_plan is not pt:     # keyed on the plan OBJECT: Graph.tile_plan(force_P=...)
+            self._coefTt_plan = pt                                  # rebuilds both plans, the tile order changes with them
             self._coefTt = torch.empty(pt.edges, 2, dtype=torch.float32, device=self.coef.device)
             sib = self._sibling() if self._sibling is not None else None   # grad and div of one build_grad_div call: one launch
-            if sib is not None and sib._coefTt is None and sib.graph is self.graph:
+            if sib is not None and (sib._coefTt is None or sib._coefTt_plan is not pt) and sib.graph is self.graph:
+                sib._coefTt_plan = pt
                 sib._coefTt = torch.empty_like(self._coefTt)
                 lib.call("dc_tile_plan_T_permute_coef", self.coef, sib.coef, pt.blob, *pt.args, self._coefTt, sib._coefTt)
             else:

@@ -24,7 +24,7 @@ import os
 
 import torch
 
-from .nn.fused import invalidate_eval_coeffs
+from .nn.fused import invalidate_eval_coeffs, planes_snapshot
 
 _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 
@@ -68,7 +68,7 @@ class GraphedTrainStep:
             from .models.deltanet_base import _ptr_info
             _ptr_info(self.static)              # cloud offsets of the static batch: a host read, never inside the capture
         if self._one is None:                   # made outside the capture (inside, it would be a captured fill again)
-            self._one = torch.ones((), dtype=torch.float32, device=self.static.pos.device)
+            self._one = torch.ones((), dtype=torch.float32, device=self.params[0].device)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up outside the capture (allocator, tuning)
@@ -85,6 +85,7 @@ class GraphedTrainStep:
                 self.loss, self.out = self._step(capture=False)
             torch.cuda.synchronize()
             self.flat = self.reducer.flat
+            self._planes_keepalive = planes_snapshot()      # raw addresses inside the graph (advisor, round 4)
             invalidate_eval_coeffs()
             self.grads = [(p, p.grad) for p in self.params if p.grad is not None]
             return
@@ -104,6 +105,9 @@ class GraphedTrainStep:
                 self.reducer.scale()
                 self.optimizer.step()
             torch.cuda.synchronize()
+        # the captured dc_presplit_weights and the plane-fed products hold RAW addresses of the record / chunk tables and of
+        # every plane buffer: this graph owns a reference to each, whatever later eager passes do to the cache (advisor, round 4)
+        self._planes_keepalive = planes_snapshot()
         invalidate_eval_coeffs()
         self.grads = [(p, p.grad) for p in self.params if p.grad is not None]   # rewritten by every replay
 
@@ -146,12 +150,12 @@ class GraphedTrainStep:
     def __call__(self, batch=None):
         if batch is not None:
             self.load(batch)
+        if self.reducer is not None and self.reducer.flat is not self.flat:      # both forms bake the buffer's address in
+            raise RuntimeError("GraphedTrainStep: the gradient reducer re-allocated its flat buffer after capture (an eager "
+                               "reduce_gradients() with a different set of live parameters); the captured graphs still use "
+                               "the old one -- build a new GraphedTrainStep")
         self.graph.replay()
         if self.graph_update is not None:
-            if self.reducer.flat is not self.flat:
-                raise RuntimeError("GraphedTrainStep: the gradient reducer re-allocated its flat buffer after capture (an eager "
-                                   "reduce_gradients() with a different set of live parameters); the captured graphs still use "
-                                   "the old one -- build a new GraphedTrainStep")
             self.reducer.all_reduce()           # the one collective of the step, between the two replays
             self.graph_update.replay()
         invalidate_eval_coeffs()      # the replay moved running statistics (and parameters) without a version bump

@@ -130,7 +130,7 @@ class DeltaConv(torch.nn.Module):
         slope = fused.slope_of(blk[2]) if isinstance(blk, MLPBlock) else None
         if (self.aggr == 'max' and len(blocks) == 1 and slope is not None and slope >= 0 and blk[0].bias is None
                 and fused.sync_group() is None):
-            y = F.linear(x, blk[0].weight)
+            y = fused.linear(x, blk[0].weight)      # own GEMM kernels (csrc/gemm.hip), any K
             return fused.edge_max_bn(y, graph, blk[1].bn, slope)
         n, k = graph.n, graph.k
         nbr = graph.nbr.long()

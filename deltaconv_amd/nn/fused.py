@@ -363,6 +363,18 @@ def invalidate_planes():
     _PL["epoch"] += 1
 
 
+def planes_snapshot():
+    """Every device tensor a captured `presplit_begin()` / plane-fed product refers to by raw address: the record table, the
+    chunk table and the plane buffers.  A HIP graph that captured them must keep this list alive (graph_step.py): an eager
+    `presplit_begin()` after the capture REPLACES the tables when the set of weights changed (another model, a garbage-collected
+    one) and entries of dead weights drop their planes -- without a holder the old tensors would return to the allocator and the
+    next replay would read recycled memory as records.  Tables are never modified in place, only replaced."""
+    keep = [t for t in (_PL["table"], _PL["chunks"]) if t is not None]
+    for e in _PL["entries"].values():
+        keep.extend(t for t in (e["fwd"], e["bwd"]) if t is not None)
+    return keep
+
+
 def presplit_begin():
     """Cut every registered weight into its bf16 planes (one launch).  Call once per forward pass, before its first product."""
     if not USE_WEIGHT_PLANES or not _PL["entries"]:
@@ -441,8 +453,8 @@ def _hint_planes(w, transposed):
     if not (isinstance(base, torch.nn.Parameter) or (base.is_leaf and base.requires_grad)):
         return                                            # temporaries would churn the table
     n, k = w.shape
-    if n % 32 or k % 32:
-        return                                            # the fragment-major plane layout wants whole 32 x 16 blocks
+    if n % 32 or k % 32 or w.data_ptr() % 16:
+        return    # the fragment-major plane layout wants whole 32 x 16 blocks; presplit_kernel loads the source 16 bytes at a time
     key = (w.device.index, w.data_ptr(), n, k)
     need = "bwd" if transposed else "fwd"
     e = _PL["entries"].get(key)
@@ -491,14 +503,22 @@ def gemm_tn(a, b):
     # and ahead of the untuned one.  Round 4: EVERY row count runs here (the kernel guards ragged shapes): the library's fp32
     # product came back 7e-3 off at [4096, 128]^T [4096, 256] (a reduced-precision algorithm: the pinned-slot gradient test
     # of tests/test_gpu_configs.py caught it on the 2-cloud ShapeNet step) -- no vendor GEMM is reachable for fp32 GPU inputs.
-    if (USE_MFMA_TN and a.is_cuda and r >= 1 and m * n <= OWN_TN_MAX_OUTPUTS
+    if (USE_MFMA_TN and a.is_cuda and r >= 1
             and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
         out = torch.empty(m, n, dtype=torch.float32, device=a.device)
-        nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, n)
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
-        lib.call("dc_gemm_tn", a, a.stride(0), b, b.stride(0), r, m, n, out, n, 0, ws, ws.numel() * 4)
+        # outputs beyond the kernel's workspace budget: column blocks of b, each its own launch into its column block of dW
+        # (round 5: the library fallback above 2^21 outputs is gone -- no vendor GEMM for fp32 GPU inputs, whatever the size)
+        nblk = max(1, min(n, OWN_TN_MAX_OUTPUTS // max(m, 1)))
+        for j0 in range(0, n, nblk):
+            nj = min(nblk, n - j0)
+            nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, nj)
+            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
+            lib.call("dc_gemm_tn", a, a.stride(0), b[:, j0:j0 + nj], b.stride(0), r, m, nj, out[:, j0:j0 + nj], n, 0, ws,
+                     ws.numel() * 4)
         return out
-    return a.t() @ b
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and USE_MFMA_TN:
+        return gemm_tn(_rowmajor(a), _rowmajor(b))
+    return a.t() @ b        # CPU tensors / other dtypes / the lab switch only
 
 
 # ---- dense products of the per-point Linear layers: hand-written fp32-MFMA kernels (csrc/gemm.hip) --------------
@@ -511,7 +531,6 @@ OWN_GEMM_MIN_ROWS = 1      # every row count (<= 64 rows normally run on csrc/ro
 # (profiles/r02f_step_timeline.txt, r02e_gemm_lab.txt) -- 1 % of the step -- but against the library's default
 # heuristic (any shape without a shipped TunableOp entry: the other configurations) the hand-written kernels win by
 # 1.3-1.5x (ShapeNet embedding: 376 + 241 us vs ~250 + ~250 us), and the path no longer depends on tuning files.
-OWN_GEMM_MAX_WEIGHT = 1 << 30
 
 
 def _own_gemm(x):
@@ -546,7 +565,7 @@ def mm_nn(dy, w, out=None, accumulate=False):
     dy, w = _rowmajor(dy), _rowmajor(w)
     m, n = dy.shape
     k = w.shape[1]
-    if not _own_gemm(dy) or n * k > OWN_GEMM_MAX_WEIGHT:
+    if not _own_gemm(dy):
         if out is None:
             return dy @ w
         if accumulate:
