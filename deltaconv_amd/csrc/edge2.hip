@@ -1,0 +1,487 @@
+// Depth-2 centralised edge MLP + max aggregation of DeltaConv's first layer, without ATen and without the [E, C] forward
+// tensors:   out[i] = max_s act2(bn2( W2 act1(bn1( W1 (x_j - x_i) )) )),  j = nbr[i, s],  BatchNorm over all E = N k edges.
+// Reference: /root/reference/deltaconv/nn/deltaconv.py:50-52 with s_mlp_max = MLP([ci, 64, 64]) as built by
+// /root/reference/experiments/train_shapenet.py:77-89 (mlp_depth = 2) -- index_select, two addmm on E rows, two
+// native_batch_norm, two leaky_relu and a scatter_max, each with its backward, over 655 360 x 64 tensors at C4.
+// Algebra pinned on the CPU in fp64 by tests/test_edge_mlp2_spec.py; lane algebra by tools/edge2_layout_sim.py.
+//
+//   z = x W1^T on N rows (W1 (x_j - x_i) = z_j - z_i); statistics of y1 = z_j - z_i: dc_edge_gather_stats (edge.hip).
+//   FORWARD  (edge2_fwd_kernel, one pass over the edges): wave = 16 points, one MFMA block = (16 points) x (slot s):
+//       h1 = act1(sc1 (z_j - z_i) + sh1) in registers (lane = (edge row, 16 channels)), y2^T = W2 h1^T on
+//       v_mfma_f32_16x16x4_f32 (exact fp32, W2 fragments in LDS), and in the D registers: sum y2, sum y2^2 (BatchNorm-2
+//       statistics) and the running max of sign(gamma2) y2 with its first slot.  act2(bn2(.)) is monotone per channel, so
+//       out = act2(sc2 sel + sh2) needs no second pass.
+//   BACKWARD (edge2_bwd_kernel, ONE recompute pass): d z2 sits on the selected edge of every (point, channel): the two
+//       BatchNorm-2 sums come from [N, 64] data; per block h1, y2 are recomputed, dy2 = a hot + b + c y2 (per-column
+//       coefficients), du1 = (dy2 W2) act1'(.) by a second MFMA product whose B operand IS the D layout of the first
+//       (the K index of a product may be permuted: no transposition), dW2 += dy2^T h1 by a third product through an LDS
+//       tile (rows become the K index; wave w owns 16 rows of dW2).  BatchNorm-1's backward is LINEAR in du1, so the pass
+//       does not wait for its two sums: it writes du1 [E, 64] (the one edge-sized tensor of the whole block, scratch),
+//       sum_s du1 and sum_s du1 y1 per point, and
+//   edge2_scatter_kernel closes   dz_p = sc1 [ sum_in du1 - sum_s du1 - n1 (indeg - k) - n2 (colhat - rowhat) ]   with the
+//       same closed forms of the mean / variance terms as the depth-1 kernel (edge_math.h), in-edges in ascending edge id:
+//       bit-reproducible, no fp atomics.   Then dW1 = dz^T x, dx = dz W1 (gemm_tn.hip / gemm.hip).
+// Bound: the fp32 matrix pipe (1 + 3 products of E x 64 x 64: 21.5 GFLOP at C4 = 137 us at 157 TFLOP/s).
+#include "common.h"
+#include "colreduce.h"
+#include "nn_math.h"
+
+namespace {
+using namespace dccol;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CH = 64;             // channels of both blocks (the kernels are specialised: 64 x 64 weights = 16 KB of fragments)
+constexpr int WPB = 4;             // waves per workgroup
+constexpr int PPW = 16;            // points per wave = the N dimension of v_mfma_f32_16x16x4_f32
+constexpr int PPB = WPB * PPW;     // 64 points per workgroup
+constexpr int TLD = CH + 4;        // row stride of the LDS tiles of the third product (floats)
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// Lane l = 16 q + j of a wave holds, for edge row j, the channels 16 b + 4 q + r  (register [b][r]).
+// fragA1[(mb * 4 + cb) * 64 + lane][r] = W2[16 mb + j][16 cb + 4 q + r]:   y2^T = W2 h1^T,  D register [mb][r'] <-> n = 16 mb + 4 q + r'
+// fragA2[(cb * 4 + mb) * 64 + lane][r] = W2[16 mb + 4 q + r][16 cb + j]:   du1^T = W2^T dy2^T, D register [cb][r'] <-> c = 16 cb + 4 q + r'
+__device__ __forceinline__ void load_frags(const float* __restrict__ W2, f32x4* fragA1, f32x4* fragA2) {
+    for (int idx = threadIdx.x; idx < 16 * 64; idx += WPB * 64) {
+        const int f = idx >> 6, l = idx & 63, hi = f >> 2, lo = f & 3, li = l & 15, lq = l >> 4;
+        fragA1[idx] = ld4(W2 + (16 * hi + li) * CH + 16 * lo + 4 * lq);              // (mb, cb) = (hi, lo)
+        if (fragA2) {
+            f32x4 v;                                                                   // (cb, mb) = (hi, lo)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = W2[(16 * lo + 4 * lq + r) * CH + 16 * hi + li];
+            fragA2[idx] = v;
+        }
+    }
+}
+
+struct Rows {   // the 16 channels of one row held by a lane
+    f32x4 v[4];
+};
+__device__ __forceinline__ Rows load_row(const float* __restrict__ base, long row, int q) {
+    Rows r;
+    const float* p = base + row * CH + 4 * q;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r.v[b] = ld4(p + 16 * b);
+    return r;
+}
+__device__ __forceinline__ Rows lds_row(const float* s, int q) {
+    Rows r;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) r.v[b] = *reinterpret_cast<const f32x4*>(s + 16 * b + 4 * q);
+    return r;
+}
+
+// product 1: y2 (register [mb][r']) from h (register [cb][r])
+__device__ __forceinline__ void product1(const f32x4* fragA1, int lane, const Rows& h, Rows& y2) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) y2.v[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        f32x4 a[4];
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) a[mb] = fragA1[(mb * 4 + cb) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) y2.v[mb] = mfma4(a[mb][r], h.v[cb][r], y2.v[mb]);
+    }
+}
+
+// block-level ordered reduction of two per-lane quantities over the 64 rows of the workgroup -> partial[(q * CH + c) * chunks + blk]
+__device__ __forceinline__ void block_sums(float (*red)[2][CH], int wave, int q, int j, const Rows& s0, const Rows& s1, bool live,
+                                           double* __restrict__ partial, int chunks, long blk) {
+    const int row = wave * PPW + j;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&red[row][0][16 * b + 4 * q]) = live ? s0.v[b] : zero;
+        *reinterpret_cast<f32x4*>(&red[row][1][16 * b + 4 * q]) = live ? s1.v[b] : zero;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CH) {
+        const int qn = threadIdx.x >> 6, c = threadIdx.x & 63;
+        double s = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < PPB; ++r) s += (double)red[r][qn][c];
+        partial[((long)qn * CH + c) * chunks + blk] = s;
+    }
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WPB * 64) void edge2_fwd_kernel(const float* __restrict__ z, const int* __restrict__ nbr, long n, int k,
+                                                             const float* __restrict__ W2, const float* __restrict__ scale1,
+                                                             const float* __restrict__ shift1, float slope1,
+                                                             const float* __restrict__ gamma2, float* __restrict__ ysel,
+                                                             unsigned char* __restrict__ arg, double* __restrict__ partial,
+                                                             int chunks, int remap) {
+    __shared__ f32x4 fragA1[16 * 64];
+    __shared__ __attribute__((aligned(16))) float s_sc[CH], s_sh[CH], s_sg[CH];
+    __shared__ __attribute__((aligned(16))) float red[PPB][2][CH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
+    const long blk = dc_xcd_block(remap);
+    load_frags(W2, fragA1, nullptr);
+    if (threadIdx.x < CH) {
+        s_sc[threadIdx.x] = scale1[threadIdx.x];
+        s_sh[threadIdx.x] = shift1[threadIdx.x];
+        s_sg[threadIdx.x] = (gamma2 && gamma2[threadIdx.x] < 0.f) ? -1.f : 1.f;
+    }
+    __syncthreads();
+    const long p = blk * PPB + wave * PPW + j;
+    const bool live = p < n;
+    const long pc = live ? p : n - 1;
+    const Rows zi = load_row(z, pc, q), sc = lds_row(s_sc, q), sh = lds_row(s_sh, q), sg = lds_row(s_sg, q);
+    const int* ids = nbr + pc * k;
+    Rows zn = load_row(z, ids[0], q);
+    int id_next = ids[k > 1 ? 1 : 0];
+    Rows s0, s1, best;
+    unsigned bestarg[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) s0.v[b] = s1.v[b] = best.v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < k; ++s) {
+        const Rows zc = zn;
+        if (s + 1 < k) {
+            zn = load_row(z, id_next, q);
+            id_next = ids[s + 2 < k ? s + 2 : k - 1];
+        }
+        Rows h, y2;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h.v[b][r] = dcnn::act(fmaf(sc.v[b][r], zc.v[b][r] - zi.v[b][r], sh.v[b][r]), slope1);
+        product1(fragA1, lane, h, y2);
+        const unsigned sbytes = (unsigned)s * 0x01010101u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float y = y2.v[b][r];
+                s0.v[b][r] += y;
+                s1.v[b][r] = fmaf(y, y, s1.v[b][r]);
+                const float m = sg.v[b][r] * y;
+                const bool up = s == 0 || m > best.v[b][r];       // strict: ties keep the first slot
+                best.v[b][r] = up ? m : best.v[b][r];
+                const unsigned mask = up ? (0xffu << (8 * r)) : 0u;
+                bestarg[b] = (bestarg[b] & ~mask) | (sbytes & mask);
+            }
+    }
+    if (live) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = sg.v[b][r] * best.v[b][r];
+            *reinterpret_cast<f32x4*>(ysel + p * CH + 16 * b + 4 * q) = o;
+            *reinterpret_cast<unsigned*>(arg + p * CH + 16 * b + 4 * q) = bestarg[b];
+        }
+    }
+    if (partial) block_sums(red, wave, q, j, s0, s1, live, partial, chunks, blk);
+}
+
+// ---- backward, the recompute pass -------------------------------------------------------------------------------------
+// coefs2 = the five rows [scale2 | shift2 | a | c | b] of BwdCoefFin (colreduce.h):  dy2 = a hot + c y2 + b
+__global__ __launch_bounds__(WPB * 64) void edge2_bwd_kernel(const float* __restrict__ z, const int* __restrict__ nbr, long n, int k,
+                                                             const float* __restrict__ W2, const float* __restrict__ scale1,
+                                                             const float* __restrict__ shift1, float slope1,
+                                                             const float* __restrict__ coefs2, const float* __restrict__ dz2,
+                                                             const unsigned char* __restrict__ arg, float* __restrict__ dU,
+                                                             float* __restrict__ csum, double* __restrict__ partial,
+                                                             float* __restrict__ dWpart, int chunks, int remap) {
+    // 68 KiB of LDS (> the 64 KiB a static allocation may take): dynamic, carved here.  Two workgroups per CU.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* fragA1 = reinterpret_cast<f32x4*>(smem);
+    f32x4* fragA2 = fragA1 + 16 * 64;
+    float* s_sc = reinterpret_cast<float*>(fragA2 + 16 * 64);
+    float *s_sh = s_sc + CH, *s_ca = s_sh + CH, *s_cc = s_ca + CH, *s_cb = s_cc + CH;
+    float(*tiles)[PPB][TLD] = reinterpret_cast<float(*)[PPB][TLD]>(s_cb + CH);   // Ty = dy2, Th = h1 (also the scratch of block_sums)
+    static_assert(sizeof(float) * 2 * PPB * TLD >= sizeof(float) * PPB * 2 * CH, "tiles double as the reduction scratch");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane >> 4, j = lane & 15;
+    const long blk = dc_xcd_block(remap);
+    load_frags(W2, fragA1, fragA2);
+    if (threadIdx.x < CH) {
+        const int c = threadIdx.x;
+        s_sc[c] = scale1[c];
+        s_sh[c] = shift1[c];
+        s_ca[c] = coefs2[2 * CH + c];
+        s_cc[c] = coefs2[3 * CH + c];
+        s_cb[c] = coefs2[4 * CH + c];
+    }
+    __syncthreads();
+    const long p = blk * PPB + wave * PPW + j;
+    const bool live = p < n;
+    const long pc = live ? p : n - 1;
+    const int row = wave * PPW + j;
+    const Rows zi = load_row(z, pc, q), dzv = load_row(dz2, pc, q);
+    unsigned argv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) argv[b] = *reinterpret_cast<const unsigned*>(arg + pc * CH + 16 * b + 4 * q);
+    const int* ids = nbr + pc * k;
+    Rows zn = load_row(z, ids[0], q);
+    int id_next = ids[k > 1 ? 1 : 0];
+    Rows cs, cy;
+    f32x4 dw[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cs.v[b] = cy.v[b] = dw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < k; ++s) {
+        const Rows zc = zn;
+        if (s + 1 < k) {
+            zn = load_row(z, id_next, q);
+            id_next = ids[s + 2 < k ? s + 2 : k - 1];
+        }
+        Rows h, y2;
+        {
+            const Rows sc = lds_row(s_sc, q), sh = lds_row(s_sh, q);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h.v[b][r] = dcnn::act(fmaf(sc.v[b][r], zc.v[b][r] - zi.v[b][r], sh.v[b][r]), slope1);
+        }
+        product1(fragA1, lane, h, y2);
+        {   // dy2 in place of y2
+            const Rows ca = lds_row(s_ca, q), cc = lds_row(s_cc, q), cb = lds_row(s_cb, q);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hot = ((argv[b] >> (8 * r)) & 0xffu) == (unsigned)s ? dzv.v[b][r] : 0.f;
+                    const float d = fmaf(ca.v[b][r], hot, fmaf(cc.v[b][r], y2.v[b][r], cb.v[b][r]));
+                    y2.v[b][r] = live ? d : 0.f;
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            *reinterpret_cast<f32x4*>(&tiles[0][row][16 * b + 4 * q]) = y2.v[b];
+            *reinterpret_cast<f32x4*>(&tiles[1][row][16 * b + 4 * q]) = h.v[b];
+        }
+        // product 2: du1 (register [cb][r']) = sum_n W2[n, c] dy2[n]
+        Rows du;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) du.v[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            f32x4 a[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) a[cb] = fragA2[(cb * 4 + mb) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) du.v[cb] = mfma4(a[cb][r], y2.v[mb][r], du.v[cb]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = du.v[b][r] * (h.v[b][r] > 0.f ? 1.f : slope1);      // act1'(pre1): h1 > 0  <=>  pre1 > 0
+                du.v[b][r] = d;
+                cs.v[b][r] += d;
+                cy.v[b][r] = fmaf(d, zc.v[b][r] - zi.v[b][r], cy.v[b][r]);
+            }
+            if (live) *reinterpret_cast<f32x4*>(dU + (p * k + s) * CH + 16 * b + 4 * q) = du.v[b];
+        }
+        __syncthreads();                                              // the two tiles of all 64 rows are in LDS
+        // product 3: wave w owns rows n in [16 w, 16 w + 16) of dW2; K = the 64 edge rows of this slot
+#pragma unroll 4
+        for (int ks = 0; ks < PPB / 4; ++ks) {
+            const float a = tiles[0][4 * ks + q][16 * wave + j];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) dw[cb] = mfma4(a, tiles[1][4 * ks + q][16 * cb + j], dw[cb]);
+        }
+        __syncthreads();                                              // before the next slot overwrites the tiles
+    }
+    if (live) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *reinterpret_cast<f32x4*>(csum + p * CH + 16 * b + 4 * q) = cs.v[b];
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dWpart[blk * (CH * CH) + (16 * wave + 4 * q + r) * CH + 16 * cb + j] = dw[cb][r];
+    block_sums(reinterpret_cast<float(*)[2][CH]>(&tiles[0][0][0]), wave, q, j, cs, cy, live, partial, chunks, blk);
+}
+
+// dW2[idx] = sum over the workgroups' partials, ascending (fixed order)
+__global__ __launch_bounds__(256) void edge2_dw_reduce_kernel(const float* __restrict__ part, int chunks, float* __restrict__ dW) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    double s = 0.0;
+    for (int b = 0; b < chunks; ++b) s += (double)part[(long)b * (CH * CH) + idx];
+    dW[idx] = (float)s;
+}
+
+// finaliser of the BatchNorm-1 backward sums:  s0 = sum_e du1,  s1 = sum_e du1 y1
+struct Bn1BwdFin {
+    long E; const float *mean, *invstd; int training; float *dgamma, *dbeta, *m1, *m2;
+    __device__ void operator()(int c, double s0, double s1) const {
+        const double dg = (double)invstd[c] * (s1 - (double)mean[c] * s0);          // sum du1 xhat1
+        if (dbeta) dbeta[c] = (float)s0;
+        if (dgamma) dgamma[c] = (float)dg;
+        m1[c] = training ? (float)(s0 / (double)E) : 0.f;
+        m2[c] = training ? (float)(dg / (double)E) : 0.f;
+    }
+};
+
+// d z2 = dout act2'(sc2 sel + sh2) written to dzs, and its two BatchNorm-2 sums (dz2, dz2 xhat2)
+template <int V>
+struct Bn2BwdF {
+    const float *dout, *ysel, *scale, *shift, *mean, *invstd; long lddo; float slope; float* dzs;
+    __device__ void operator()(long i, int c0, double (&t)[2][V]) const {
+        const FV<V> g = ldv<V>(dout + i * lddo + c0), y = ldv<V>(ysel + i * CH + c0);
+        FV<V> dz;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            float b;
+            dcnn::bn_bwd_terms(g.v[q], y.v[q], scale[c0 + q], shift[c0 + q], mean[c0 + q], invstd[c0 + q], slope, dz.v[q], b);
+            t[0][q] = dz.v[q];
+            t[1][q] = b;
+        }
+        stv<V>(dzs + i * CH + c0, dz);
+    }
+};
+
+// closing pass: thread = (target point, 4 channels); in-edges in ascending edge id (CSC order)
+__global__ __launch_bounds__(256) void edge2_scatter_kernel(long n, int k, int remap, const int* __restrict__ tptr,
+                                                            const int* __restrict__ tedge, const float* __restrict__ dU,
+                                                            const float* __restrict__ z, const float* __restrict__ csum,
+                                                            const float* __restrict__ s1pt, const float* __restrict__ scale1,
+                                                            const float* __restrict__ mean1, const float* __restrict__ invstd1,
+                                                            const float* __restrict__ m1, const float* __restrict__ m2,
+                                                            int training, float* __restrict__ dz, long lddz) {
+    const long t = dc_xcd_block(remap) * 256 + threadIdx.x;
+    if (t >= n * (CH / 4)) return;
+    const long jp = t / (CH / 4);
+    const int c0 = (int)(t % (CH / 4)) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, T = {0.f, 0.f, 0.f, 0.f};
+    const int p0 = tptr[jp], p1 = tptr[jp + 1];
+    for (int e0 = p0; e0 < p1; ++e0) {
+        const long e = tedge[e0];
+        const long i = e / k;
+        const f32x4 d = ld4(dU + e * CH + c0), zi = ld4(z + i * CH + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[r] += d[r]; T[r] += zi[r]; }
+    }
+    const float indeg = (float)(p1 - p0);
+    const f32x4 zj = ld4(z + jp * CH + c0), cs = ld4(csum + jp * CH + c0), s1 = ld4(s1pt + jp * CH + c0);
+    f32x4 out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = c0 + r;
+        float g = acc[r] - cs[r];
+        if (training) {
+            const float col_hat = (indeg * zj[r] - T[r] - indeg * mean1[c]) * invstd1[c];
+            const float row_hat = (s1[r] - (float)k * mean1[c]) * invstd1[c];
+            g -= m1[c] * (indeg - (float)k) + m2[c] * (col_hat - row_hat);
+        }
+        out[r] = scale1[c] * g;
+    }
+    *reinterpret_cast<f32x4*>(dz + jp * lddz + c0) = out;
+}
+
+constexpr size_t BWD_LDS = 2 * 16 * 64 * 16 + 5 * CH * 4 + 2 * PPB * TLD * 4;
+inline int edge2_chunks(long n) { return dc_cdiv(n, PPB); }
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
+// Workspace of dc_edge2_forward / dc_edge2_backward (bytes): statistics partials (+ in the backward: the [E, 64] scratch of
+// du1, sum_s du1 per point, the workgroups' dW2 partials, the per-column means).
+DC_EXPORT size_t dc_edge2_workspace_bytes(int32_t n, int32_t k, int32_t backward) {
+    const size_t chunks = (size_t)edge2_chunks(n);
+    size_t b = al256(std::max(chunks * 2 * CH * 8, ws_need(n, CH))) + al256(2 * CH * 8);
+    if (backward)
+        b += al256((size_t)n * k * CH * 4) + al256((size_t)n * CH * 4) + al256(chunks * CH * CH * 4) + al256(5 * CH * 4) + al256(2 * CH * 4);
+    return b;
+}
+
+// Forward: z [n, 64] contiguous (= x W1^T), scale1 / shift1 = BatchNorm-1 as an affine map (batch statistics of z_j - z_i from
+// dc_edge_gather_stats, or the running ones), W2 [64, 64].  Outputs ysel [n, 64] = the selected pre-BatchNorm-2 value per
+// (point, channel), arg uint8 [n, 64] its first slot.  stats_mode 1: BatchNorm-2 batch statistics over all n k edges ->
+// mean2 / invstd2 / scale2 / shift2 (+ running statistics); 2: only the fp64 sums [sum y2 | sum y2^2] -> sums[128]
+// (synchronised BatchNorm: all-reduce, then dc_bn_coeffs_from_sums); 0: none (inference: coefficients from the running
+// statistics).  out = act2(scale2 ysel + shift2) is one dc_bn_act call of the caller.
+DC_EXPORT int dc_edge2_forward(const float* z, const int32_t* nbr, int32_t n, int32_t k, const float* W2, const float* scale1,
+                               const float* shift1, float slope1, int32_t stats_mode, const float* gamma2, const float* beta2,
+                               float eps, float momentum, float* running_mean, float* running_var, float* ysel, uint8_t* arg,
+                               float* mean2, float* invstd2, float* scale2, float* shift2, double* sums, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(z && nbr && W2 && scale1 && shift1 && ysel && arg, "dc_edge2_forward: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && k <= 255, "dc_edge2_forward: bad size");
+    DC_REQUIRE(al16(z) && al16(W2) && al16(ysel) && (reinterpret_cast<uintptr_t>(arg) & 3) == 0, "dc_edge2_forward: misaligned");
+    DC_REQUIRE(stats_mode != 1 || (mean2 && invstd2 && scale2 && shift2), "dc_edge2_forward: null pointer");
+    DC_REQUIRE(stats_mode != 2 || sums, "dc_edge2_forward: null pointer");
+    if (stats_mode && (!workspace || workspace_bytes < dc_edge2_workspace_bytes(n, k, 0))) {
+        dc_set_error("dc_edge2_forward: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int chunks = edge2_chunks(n);
+    double* partial = stats_mode ? static_cast<double*>(workspace) : nullptr;
+    hipLaunchKernelGGL(edge2_fwd_kernel, dim3(chunks), dim3(WPB * 64), 0, s, z, nbr, (long)n, k, W2, scale1, shift1, slope1, gamma2,
+                       ysel, arg, partial, chunks, dc_option(DC_OPT_XCD_REMAP));
+    if (stats_mode == 1) {
+        const BnFin fin{(long)n * k, gamma2, beta2, eps, momentum, running_mean, running_var, mean2, invstd2, scale2, shift2};
+        hipLaunchKernelGGL((colreduce_final_kernel<BnFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH, fin);
+    } else if (stats_mode == 2) {
+        hipLaunchKernelGGL((colreduce_final_kernel<SumsFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH, SumsFin{sums, CH});
+    }
+    DC_CHECK_LAUNCH("dc_edge2_forward");
+    return DC_OK;
+}
+
+// Backward of the pair (dc_edge2_forward, out = act2(scale2 ysel + shift2)): dout [n, 64] (row stride lddo) -> dz [n, 64]
+// (gradient w.r.t. z = x W1^T, row stride lddz), dW2 [64, 64], dgamma1 / dbeta1 / dgamma2 / dbeta2 [64] (each may be NULL).
+// coef1 / coef2 = [mean | invstd | scale | shift] rows (4 x 64) of the two BatchNorms as used in the forward pass;
+// training1 / training2: batch statistics (the mean / variance terms of the BatchNorm backward) or running ones;
+// tptr / tedge = the CSC of the graph (dc_csc_build); s1pt = sum_s (z_j - z_i) per point (dc_edge_gather_stats).
+DC_EXPORT int dc_edge2_backward(const float* dout, int64_t lddo, const float* z, const int32_t* nbr, const int32_t* tptr,
+                                const int32_t* tedge, int32_t n, int32_t k, const float* W2, const float* coef1,
+                                const float* coef2, const float* gamma2, float slope1, float slope2, int32_t training1,
+                                int32_t training2, const float* ysel, const uint8_t* arg, const float* s1pt, float* dz,
+                                int64_t lddz, float* dW2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(dout && z && nbr && tptr && tedge && W2 && coef1 && coef2 && ysel && arg && s1pt && dz && dW2,
+               "dc_edge2_backward: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && k <= 255 && lddo >= CH && lddz >= CH && lddo % 4 == 0 && lddz % 4 == 0, "dc_edge2_backward: bad size");
+    DC_REQUIRE(al16(dout) && al16(z) && al16(W2) && al16(ysel) && al16(s1pt) && al16(dz) && (reinterpret_cast<uintptr_t>(arg) & 3) == 0,
+               "dc_edge2_backward: misaligned");
+    if (!workspace || workspace_bytes < dc_edge2_workspace_bytes(n, k, 1)) {
+        dc_set_error("dc_edge2_backward: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int chunks = edge2_chunks(n);
+    char* w = static_cast<char*>(workspace);
+    const size_t part_bytes = al256(std::max((size_t)chunks * 2 * CH * 8, ws_need(n, CH)));
+    double* partial = reinterpret_cast<double*>(w);           w += part_bytes;
+    w += al256(2 * CH * 8);
+    float* dU = reinterpret_cast<float*>(w);                  w += al256((size_t)n * k * CH * 4);
+    float* csum = reinterpret_cast<float*>(w);                w += al256((size_t)n * CH * 4);
+    float* dWpart = reinterpret_cast<float*>(w);              w += al256((size_t)chunks * CH * CH * 4);
+    float* coefs5 = reinterpret_cast<float*>(w);              w += al256(5 * CH * 4);
+    float* m12 = reinterpret_cast<float*>(w);
+    const float *mean1 = coef1, *invstd1 = coef1 + CH, *scale1 = coef1 + 2 * CH, *shift1 = coef1 + 3 * CH;
+    const float *mean2 = coef2, *invstd2 = coef2 + CH, *scale2 = coef2 + 2 * CH, *shift2 = coef2 + 3 * CH;
+    // 1. d z2 (into csum: consumed by the recompute pass before csum is written... no: its own buffer = dz, free until step 4)
+    float* dz2 = dz;                                           // [n, 64] contiguous view needs lddz == CH; else the csum slot
+    DC_REQUIRE(lddz == CH, "dc_edge2_backward: dz must be contiguous [n, 64]");
+    {
+        const Ws ws = carve(partial, n, CH);
+        const BwdCoefFin fin{(long)n * k, gamma2, scale2, shift2, mean2, invstd2, training2, dgamma2, dbeta2, coefs5, CH};
+        run_colreduce<4>(Bn2BwdF<4>{dout, ysel, scale2, shift2, mean2, invstd2, (long)lddo, slope2, dz2}, n, CH, ws, s, fin);
+    }
+    // 2. the recompute pass
+    const int remap = dc_option(DC_OPT_XCD_REMAP);
+    static unsigned long long attr_set = 0;
+    if (!dc_ensure_lds(&attr_set, reinterpret_cast<const void*>(&edge2_bwd_kernel), BWD_LDS, "dc_edge2_backward")) {
+        DC_CHECK_LAUNCH("dc_edge2_backward");
+    }
+    hipLaunchKernelGGL(edge2_bwd_kernel, dim3(chunks), dim3(WPB * 64), BWD_LDS, s, z, nbr, (long)n, k, W2, scale1, shift1, slope1, coefs5, dz2,
+                       arg, dU, csum, partial, dWpart, chunks, remap);
+    // 3. BatchNorm-1 sums, dW2
+    hipLaunchKernelGGL((colreduce_final_kernel<Bn1BwdFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH,
+                       Bn1BwdFin{(long)n * k, mean1, invstd1, training1, dgamma1, dbeta1, m12, m12 + CH});
+    hipLaunchKernelGGL(edge2_dw_reduce_kernel, dim3(CH * CH / 256), dim3(256), 0, s, dWpart, chunks, dW2);
+    // 4. the closing pass (overwrites dz = the d z2 buffer: the recompute pass has consumed it)
+    const long total = (long)n * (CH / 4);
+    hipLaunchKernelGGL(edge2_scatter_kernel, dim3(dc_cdiv(total, 256)), dim3(256), 0, s, (long)n, k, remap, tptr, tedge, dU, z, csum,
+                       s1pt, scale1, mean1, invstd1, m12, m12 + CH, training1, dz, (long)lddz);
+    DC_CHECK_LAUNCH("dc_edge2_backward");
+    return DC_OK;
+}

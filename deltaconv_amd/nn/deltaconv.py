@@ -132,6 +132,15 @@ class DeltaConv(torch.nn.Module):
                 and fused.sync_group() is None):
             y = fused.linear(x, blk[0].weight)      # own GEMM kernels (csrc/gemm.hip), any K
             return fused.edge_max_bn(y, graph, blk[1].bn, slope)
+        if self.aggr == 'max' and len(blocks) == 2 and all(isinstance(b, MLPBlock) for b in blocks):
+            s1, s2 = fused.slope_of(blocks[0][2]), fused.slope_of(blocks[1][2])
+            if fused.edge_mlp2_ok(x, blocks[0][0], blocks[0][1].bn, blocks[1][0], blocks[1][1].bn, s1, s2):
+                # depth 2 (the part-segmentation net): one MFMA pass over the edges, csrc/edge2.hip
+                out, slots = fused.edge_mlp2(x, graph, blocks[0][0], blocks[0][1].bn, s1, blocks[1][0], blocks[1][1].bn, s2)
+                from . import layer as _layer
+                if _layer.SLOT_TAP[0] is not None:          # test hook (layer.py)
+                    _layer.SLOT_TAP[0].append(slots.clone())
+                return out
         n, k = graph.n, graph.k
         nbr = graph.nbr.long()
         x_edge = (x[nbr] - x.unsqueeze(1)).reshape(n * k, x.shape[1])

@@ -294,6 +294,31 @@ int dc_edge_max_backward_tiled(const float* dout, int64_t lddo, const float* y, 
                                float* dzs, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* ---- depth-2 centralised edge MLP + max aggregation (first layer of the part-segmentation net) ------------------------
+ * out[i] = max_s act2(bn2(W2 act1(bn1(W1 (x_j - x_i))))), BatchNorm statistics over all E = n k edges:
+ * deltaconv/nn/deltaconv.py:50-52 with s_mlp_max = MLP([ci, 64, 64]) (experiments/train_shapenet.py:77-89, mlp_depth = 2),
+ * i.e. index_select, two addmm, two native_batch_norm, two leaky_relu and scatter_max on [E, 64] tensors + their autograd.
+ * Here (deltaconv_amd/csrc/edge2.hip): z = x W1^T on n rows (own GEMM), statistics of z_j - z_i by dc_edge_gather_stats, then
+ * ONE pass over the edges on v_mfma_f32_16x16x4_f32 (exact fp32) that keeps, per (point, channel), the selected
+ * pre-BatchNorm-2 value `ysel`, its first slot `arg`, and the BatchNorm-2 sums; out = act2(scale2 ysel + shift2) is a
+ * dc_bn_act call.  Backward: ONE recompute pass (three chained MFMA products: y2, du1 = (dy2 W2) act1', dW2 += dy2^T h1)
+ * + a CSC closing pass; bit-reproducible (ordered reductions, in-edges in ascending edge id).  64 channels in both blocks.
+ * stats_mode: 1 = batch statistics -> mean2 / invstd2 / scale2 / shift2 (+ running statistics), 2 = fp64 sums only
+ * (sums[128] = [sum y2 | sum y2^2], synchronised BatchNorm), 0 = none.  coef1 / coef2 = [mean | invstd | scale | shift]
+ * rows (4 x 64).  Workspace: dc_edge2_workspace_bytes(n, k, backward). */
+size_t dc_edge2_workspace_bytes(int32_t n, int32_t k, int32_t backward);
+int dc_edge2_forward(const float* z, const int32_t* nbr, int32_t n, int32_t k, const float* W2, const float* scale1,
+                     const float* shift1, float slope1, int32_t stats_mode, const float* gamma2, const float* beta2,
+                     float eps, float momentum, float* running_mean, float* running_var, float* ysel, uint8_t* arg,
+                     float* mean2, float* invstd2, float* scale2, float* shift2, double* sums, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int dc_edge2_backward(const float* dout, int64_t lddo, const float* z, const int32_t* nbr, const int32_t* tptr,
+                      const int32_t* tedge, int32_t n, int32_t k, const float* W2, const float* coef1, const float* coef2,
+                      const float* gamma2, float slope1, float slope2, int32_t training1, int32_t training2,
+                      const float* ysel, const uint8_t* arg, const float* s1pt, float* dz, int64_t lddz, float* dW2,
+                      float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ---- weight-gradient GEMM on the fp32 matrix cores ---------------------------------------------------
  * C[M,N] (+)= A^T B,  A [R,M], B [R,N], R >> M,N  (dW = dY^T X of every per-point Linear layer: ATen mm in the
  * autograd of deltaconv/nn/mlp.py:9,15).  v_mfma_f32_32x32x2_f32 through the LDS-staged kernel (any M, N, leading
