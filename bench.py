@@ -37,6 +37,8 @@ def parse(argv=None):
     ap.add_argument("--no-exact-chain", action="store_true",
                     help="skip the second timing of the same step with every dense product on the exact fp32 MFMA chain")
     ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
+    ap.add_argument("--no-cpu-full-batch", action="store_true",
+                    help="skip the second CPU-baseline entry on the full batch of the configuration (~25 s)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every kernel from Python each step instead of replaying the captured HIP graph")
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct synthetic batches cycled through")
@@ -94,7 +96,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
     def measure(passes=2, cases=None):
         cases = cases or cases_F
         # two passes over the family, the second one reported: the first replay series of a case in a process runs
-        # 1 - 1.5 us slower than every later one (r03 lab, tools/archive/tile_upw.py: 14.6 then 13.1 x 7 for the fused apply --
+        # 1 - 1.5 us slower than every later one (r03 lab, tools/archive_r01_r04.tar.gz:archive/tile_upw.py: 14.6 then 13.1 x 7 for the fused apply --
         # fresh allocations / cold translation caches), and the training step launches these kernels every iteration
         out = {}
         for rep in range(passes):
@@ -315,7 +317,15 @@ def cpu_baseline(args):
     one(small)
     t1 = statistics.median([one(small) for _ in range(3)])
     torch.set_num_threads(best)
-    return dict(value=args.cpu_clouds / med, unit="clouds/s", cores=best, kind="port",
+    # the SAME inputs as the GPU step: the full batch of the configuration, 1 warm-up + 2 timed steps
+    full = None
+    if not args.no_cpu_full_batch:
+        fb = synthetic_batch(args.batch, args.points, seed=100)
+        one(fb)
+        tf = [one(fb) for _ in range(2)]
+        full = dict(value=round(args.batch / statistics.median(tf), 3), unit="clouds/s", cores=best, clouds=args.batch,
+                    sample=f"the bench batch itself ({args.batch} clouds x {args.points} pts, seed 100), 1 warm-up + 2 timed steps")
+    return dict(value=args.cpu_clouds / med, unit="clouds/s", cores=best, kind="port", full_batch=full,
                 physical_cores=phys, hardware_threads=hw, one_thread_value=round(2 / t1, 3),
                 sample=f"oracle/ (torch-CPU restatement of the reference path), {args.cpu_clouds} clouds x "
                        f"{args.points} pts, k={args.k}, fwd+bwd train mode, 3 warm-up + 10 timed steps, median "

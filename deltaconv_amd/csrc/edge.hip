@@ -234,3 +234,158 @@ DC_EXPORT int dc_edge_max_backward_tiled(const float* dout, int64_t lddo, const 
     DC_CHECK_LAUNCH("dc_edge_max_backward_tiled");
     return DC_OK;
 }
+
+// ---- general form of the centralised edge MLP (any depth / width / aggregation): the edge tensor is materialised -------------
+// x_edge = x[col] - x[row] (deltaconv/nn/deltaconv.py:50), the MLP runs on its E = n k rows through the ordinary block kernels,
+// scatter(h, row, reduce=aggr) (deltaconv.py:52) is a reduction over the k CONSECUTIVE rows of a point (edges are centre-major).
+// The two reference models that use a centralised first layer never get here (depth 1: the analytic form above; depth 2 x 64
+// channels: edge2.hip); this is the path of every other shape, on hand-written kernels as well.
+namespace {
+template <int V>
+__global__ __launch_bounds__(256) void edge_diff_kernel(const float* __restrict__ x, long ldx, const int* __restrict__ nbr, long E,
+                                                        int k, int groups, float* __restrict__ out) {
+    const long C = (long)groups * V;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < E * groups; t += (long)gridDim.x * 256) {
+        const long e = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        const long i = e / k;
+        const FV<V> a = ldv<V>(x + (long)nbr[e] * ldx + c0), b = ldv<V>(x + i * ldx + c0);
+        FV<V> o;
+#pragma unroll
+        for (int q = 0; q < V; ++q) o.v[q] = a.v[q] - b.v[q];
+        *reinterpret_cast<FV<V>*>(out + e * C + c0) = o;
+    }
+}
+// dx[j] = sum over in-edges (ascending edge id) dE[e] - sum_s dE[(j, s)]
+template <int V>
+__global__ __launch_bounds__(256) void edge_diff_bwd_kernel(const float* __restrict__ dE, const int* __restrict__ tptr,
+                                                            const int* __restrict__ tedge, long n, int k, int groups,
+                                                            float* __restrict__ dx, long lddx) {
+    const long C = (long)groups * V;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * groups) return;
+    const long j = t / groups;
+    const int c0 = (int)(t % groups) * V;
+    FV<V> acc;
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc.v[q] = 0.f;
+    for (int p = tptr[j]; p < tptr[j + 1]; ++p) {
+        const FV<V> d = ldv<V>(dE + (long)tedge[p] * C + c0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc.v[q] += d.v[q];
+    }
+    for (int s = 0; s < k; ++s) {
+        const FV<V> d = ldv<V>(dE + (j * k + s) * C + c0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc.v[q] -= d.v[q];
+    }
+    *reinterpret_cast<FV<V>*>(dx + j * lddx + c0) = acc;
+}
+// mode 0 max, 1 min (first extremal slot), 2 sum, 3 mean over the k consecutive rows of a point
+template <int V>
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const float* __restrict__ h, long n, int k, int groups, int mode,
+                                                         float* __restrict__ out, unsigned char* __restrict__ arg) {
+    const long C = (long)groups * V;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n * groups; t += (long)gridDim.x * 256) {
+        const long i = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        FV<V> acc = ldv<V>(h + (i * k) * C + c0);
+        unsigned char sl[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) sl[q] = 0;
+        for (int s = 1; s < k; ++s) {
+            const FV<V> v = ldv<V>(h + (i * k + s) * C + c0);
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                if (mode >= 2) acc.v[q] += v.v[q];
+                else {
+                    const bool take = mode == 0 ? v.v[q] > acc.v[q] : v.v[q] < acc.v[q];
+                    acc.v[q] = take ? v.v[q] : acc.v[q];
+                    sl[q] = take ? (unsigned char)s : sl[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            if (mode == 3) acc.v[q] /= (float)k;
+            if (arg && mode < 2) arg[i * C + c0 + q] = sl[q];
+        }
+        *reinterpret_cast<FV<V>*>(out + i * C + c0) = acc;
+    }
+}
+template <int V>
+__global__ __launch_bounds__(256) void seg_reduce_bwd_kernel(const float* __restrict__ dout, long lddo,
+                                                             const unsigned char* __restrict__ arg, long E, int k, int groups,
+                                                             int mode, float* __restrict__ dh) {
+    const long C = (long)groups * V;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < E * groups; t += (long)gridDim.x * 256) {
+        const long e = t / groups;
+        const int c0 = (int)(t % groups) * V;
+        const long i = e / k;
+        const int s = (int)(e - i * k);
+        const FV<V> g = ldv<V>(dout + i * lddo + c0);
+        FV<V> o;
+#pragma unroll
+        for (int q = 0; q < V; ++q)
+            o.v[q] = mode == 2 ? g.v[q] : mode == 3 ? g.v[q] / (float)k : (arg[i * C + c0 + q] == (unsigned char)s ? g.v[q] : 0.f);
+        *reinterpret_cast<FV<V>*>(dh + e * C + c0) = o;
+    }
+}
+}  // namespace
+
+// out[e, :] = x[nbr[e], :] - x[e / k, :]   ([n k, C] contiguous; x row stride ldx): the edge tensor of deltaconv.py:50
+DC_EXPORT int dc_edge_diff(const float* x, int64_t ldx, const int32_t* nbr, int32_t n, int32_t k, int32_t C, float* out,
+                           void* stream) {
+    DC_REQUIRE(x && nbr && out, "dc_edge_diff: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && C >= 1 && ldx >= C, "dc_edge_diff: bad size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long E = (long)n * k;
+    if (C % 4 == 0 && ldx % 4 == 0 && al16(x) && al16(out))
+        hipLaunchKernelGGL(edge_diff_kernel<4>, dim3(stream_grid(E * (C / 4))), dim3(256), 0, s, x, (long)ldx, nbr, E, k, C / 4, out);
+    else
+        hipLaunchKernelGGL(edge_diff_kernel<1>, dim3(stream_grid(E * C)), dim3(256), 0, s, x, (long)ldx, nbr, E, k, C, out);
+    DC_CHECK_LAUNCH("dc_edge_diff");
+    return DC_OK;
+}
+// its transpose: dx[j] = sum_{in-edges of j, ascending edge id} dE[e] - sum_s dE[j k + s]   (CSC from dc_csc_build)
+DC_EXPORT int dc_edge_diff_backward(const float* dE, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, int32_t C,
+                                    float* dx, int64_t lddx, void* stream) {
+    DC_REQUIRE(dE && tptr && tedge && dx, "dc_edge_diff_backward: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && C >= 1 && lddx >= C, "dc_edge_diff_backward: bad size");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C % 4 == 0 && lddx % 4 == 0 && al16(dE) && al16(dx))
+        hipLaunchKernelGGL(edge_diff_bwd_kernel<4>, dim3(dc_cdiv((long)n * (C / 4), 256)), dim3(256), 0, s, dE, tptr, tedge, (long)n, k,
+                           C / 4, dx, (long)lddx);
+    else
+        hipLaunchKernelGGL(edge_diff_bwd_kernel<1>, dim3(dc_cdiv((long)n * C, 256)), dim3(256), 0, s, dE, tptr, tedge, (long)n, k, C, dx,
+                           (long)lddx);
+    DC_CHECK_LAUNCH("dc_edge_diff_backward");
+    return DC_OK;
+}
+// scatter(h, row, reduce=...) for centre-major edges (deltaconv.py:52): reduction over the k consecutive rows of every point.
+// mode 0 = max, 1 = min (arg = first extremal slot, uint8 [n, C], may be NULL), 2 = sum / add, 3 = mean.  h [n k, C], out [n, C].
+DC_EXPORT int dc_seg_reduce(const float* h, int32_t n, int32_t k, int32_t C, int32_t mode, float* out, uint8_t* arg, void* stream) {
+    DC_REQUIRE(h && out, "dc_seg_reduce: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && k <= 255 && C >= 1 && mode >= 0 && mode <= 3, "dc_seg_reduce: bad size / mode");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C % 4 == 0 && al16(h) && al16(out))
+        hipLaunchKernelGGL(seg_reduce_kernel<4>, dim3(stream_grid((long)n * (C / 4))), dim3(256), 0, s, h, (long)n, k, C / 4, mode, out, arg);
+    else
+        hipLaunchKernelGGL(seg_reduce_kernel<1>, dim3(stream_grid((long)n * C)), dim3(256), 0, s, h, (long)n, k, C, mode, out, arg);
+    DC_CHECK_LAUNCH("dc_seg_reduce");
+    return DC_OK;
+}
+DC_EXPORT int dc_seg_reduce_backward(const float* dout, int64_t lddo, const uint8_t* arg, int32_t n, int32_t k, int32_t C,
+                                     int32_t mode, float* dh, void* stream) {
+    DC_REQUIRE(dout && dh && (mode >= 2 || arg), "dc_seg_reduce_backward: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && k <= 255 && C >= 1 && lddo >= C && mode >= 0 && mode <= 3, "dc_seg_reduce_backward: bad size / mode");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const long E = (long)n * k;
+    if (C % 4 == 0 && lddo % 4 == 0 && al16(dout) && al16(dh))
+        hipLaunchKernelGGL(seg_reduce_bwd_kernel<4>, dim3(stream_grid(E * (C / 4))), dim3(256), 0, s, dout, (long)lddo, arg, E, k, C / 4,
+                           mode, dh);
+    else
+        hipLaunchKernelGGL(seg_reduce_bwd_kernel<1>, dim3(stream_grid(E * C)), dim3(256), 0, s, dout, (long)lddo, arg, E, k, C, mode, dh);
+    DC_CHECK_LAUNCH("dc_seg_reduce_backward");
+    return DC_OK;
+}

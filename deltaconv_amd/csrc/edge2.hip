@@ -299,12 +299,25 @@ __global__ __launch_bounds__(WPB * 64) void edge2_bwd_kernel(const float* __rest
     block_sums(reinterpret_cast<float(*)[2][CH]>(&tiles[0][0][0]), wave, q, j, cs, cy, live, partial, chunks, blk);
 }
 
-// dW2[idx] = sum over the workgroups' partials, ascending (fixed order)
+// dW2[idx] = sum over the workgroups' partials in a fixed order: block = 16 outputs x 16 slices of the chunk range (each thread
+// an ascending serial sum of its slice, loads independent of the adds), then the 16 slice sums ascending.  (First version: one
+// thread per output walking all 512 partials = 138 us of dependent latency for 8 MB; profiles/r05b.)
 __global__ __launch_bounds__(256) void edge2_dw_reduce_kernel(const float* __restrict__ part, int chunks, float* __restrict__ dW) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double sm[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + o;
+    const int per = (chunks + 15) / 16, b0 = sl * per, b1 = min(b0 + per, chunks);
     double s = 0.0;
-    for (int b = 0; b < chunks; ++b) s += (double)part[(long)b * (CH * CH) + idx];
-    dW[idx] = (float)s;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) s += (double)part[(long)b * (CH * CH) + idx];
+    sm[sl][o] = s;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += sm[q][threadIdx.x];
+        dW[blockIdx.x * 16 + threadIdx.x] = (float)t;
+    }
 }
 
 // finaliser of the BatchNorm-1 backward sums:  s0 = sum_e du1,  s1 = sum_e du1 y1
@@ -477,7 +490,7 @@ DC_EXPORT int dc_edge2_backward(const float* dout, int64_t lddo, const float* z,
     // 3. BatchNorm-1 sums, dW2
     hipLaunchKernelGGL((colreduce_final_kernel<Bn1BwdFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH,
                        Bn1BwdFin{(long)n * k, mean1, invstd1, training1, dgamma1, dbeta1, m12, m12 + CH});
-    hipLaunchKernelGGL(edge2_dw_reduce_kernel, dim3(CH * CH / 256), dim3(256), 0, s, dWpart, chunks, dW2);
+    hipLaunchKernelGGL(edge2_dw_reduce_kernel, dim3(CH * CH / 16), dim3(256), 0, s, dWpart, chunks, dW2);
     // 4. the closing pass (overwrites dz = the d z2 buffer: the recompute pass has consumed it)
     const long total = (long)n * (CH / 4);
     hipLaunchKernelGGL(edge2_scatter_kernel, dim3(dc_cdiv(total, 256)), dim3(256), 0, s, (long)n, k, remap, tptr, tedge, dU, z, csum,

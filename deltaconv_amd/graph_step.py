@@ -2,7 +2,7 @@
 HIP graph and replayed with a single host call.
 
 Why: at 32 clouds per GPU a step is ~230 kernel launches of ~17 us each -- the Python / autograd /
-ctypes enqueue time (4.3 ms) has caught up with the GPU time (see tools/archive/cpu_overhead.py).  Every entry
+ctypes enqueue time (4.3 ms) has caught up with the GPU time (see tools/archive_r01_r04.tar.gz:archive/cpu_overhead.py).  Every entry
 point of the C ABI is capture-safe by construction (stream-ordered kernels only: no allocation, no
 sync, no memset/memcpy nodes; workspaces come from torch's allocator, which serves captures from a
 private pool), so the whole step replays from one `hipGraphLaunch`.  Shapes are static (equal-size

@@ -5,7 +5,6 @@ What differs underneath: the kNN max-aggregation never materialises the [E,C] ga
 ``div v``, ``curl v`` and ``|v|`` come out of one gather pass, and the Hodge-Laplacian reuses them
 instead of recomputing two applies (operators.py:40,43 vs deltaconv.py:57)."""
 import torch
-import torch.nn.functional as F
 
 from .mlp import MLP, VectorMLP, MLPBlock, VectorBlock, run_mlp
 from . import fused
@@ -141,19 +140,15 @@ class DeltaConv(torch.nn.Module):
                 if _layer.SLOT_TAP[0] is not None:          # test hook (layer.py)
                     _layer.SLOT_TAP[0].append(slots.clone())
                 return out
-        n, k = graph.n, graph.k
-        nbr = graph.nbr.long()
-        x_edge = (x[nbr] - x.unsqueeze(1)).reshape(n * k, x.shape[1])
-        h = self.s_mlp_max(x_edge).view(n, k, -1)                   # edges are centre-major, k contiguous
+        # every other shape (depth >= 3, other widths, other aggregations): the edge tensor is materialised by dc_edge_diff, the
+        # MLP blocks run on its E rows, dc_seg_reduce aggregates the k consecutive rows of every point (csrc/edge.hip)
+        h = self.s_mlp_max(fused.edge_diff(x, graph))
+        out, slots = fused.seg_reduce(h, graph.n, graph.k, self.aggr)
         if self.aggr == 'max':
-            vals, idx = h.max(dim=1)
             from . import layer as _layer
             if _layer.SLOT_TAP[0] is not None:          # test hook (layer.py)
-                _layer.SLOT_TAP[0].append(idx.to(torch.uint8))
-            return vals
-        if self.aggr == 'min':
-            return h.min(dim=1).values
-        return h.mean(dim=1) if self.aggr == 'mean' else h.sum(dim=1)
+                _layer.SLOT_TAP[0].append(slots.clone())
+        return out
 
     def __repr__(self):
         return f'{self.__class__.__name__}({self.in_channels}, {self.out_channels})'

@@ -340,6 +340,72 @@ def edge_max_bn(y, graph, bn, slope):
     return _EdgeMaxBN.apply(y, graph, bn.weight, bn.bias, rm, rv, use_batch, mom, float(bn.eps), float(slope))
 
 
+class _EdgeDiff(torch.autograd.Function):
+    """x_edge[e] = x[nbr[e]] - x[e // k]  (deltaconv/nn/deltaconv.py:50) as an [n k, C] tensor: the general (materialised)
+    form of the centralised edge MLP; its transpose sums the in-edges of a point in ascending edge id (no atomics)."""
+
+    @staticmethod
+    def forward(ctx, x, graph):
+        x = _c(x)
+        n, k, c = graph.n, graph.k, x.shape[1]
+        out = torch.empty(n * k, c, dtype=torch.float32, device=x.device)
+        lib.call("dc_edge_diff", x, c, graph.nbr, n, k, c, out)
+        ctx.graph, ctx.c = graph, c
+        return out
+
+    @staticmethod
+    def backward(ctx, d_edge):
+        g, c = ctx.graph, ctx.c
+        d_edge = _c(d_edge)
+        tptr, tedge = g.csc()
+        dx = torch.empty(g.n, c, dtype=torch.float32, device=d_edge.device)
+        lib.call("dc_edge_diff_backward", d_edge, tptr, tedge, g.n, g.k, c, dx, c)
+        return dx, None
+
+
+def edge_diff(x, graph):
+    require_gpu()
+    return _EdgeDiff.apply(x, graph)
+
+
+_SEG_MODES = {"max": 0, "min": 1, "sum": 2, "add": 2, "mean": 3}
+
+
+class _SegReduce(torch.autograd.Function):
+    """scatter(h, row, reduce=aggr) for centre-major edges (deltaconv.py:52): reduction over the k consecutive rows of every
+    point; max / min keep the first extremal slot (uint8), the backward writes the [n k, C] gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, h, n, k, mode):
+        h = _c(h)
+        c = h.shape[1]
+        out = torch.empty(n, c, dtype=torch.float32, device=h.device)
+        arg = torch.empty(n, c, dtype=torch.uint8, device=h.device) if mode < 2 else None
+        lib.call("dc_seg_reduce", h, n, k, c, mode, out, arg)
+        ctx.cfg = (n, k, c, mode)
+        ctx.arg = arg
+        ctx.save_for_backward(*(() if arg is None else (arg,)))
+        if arg is None:
+            arg = torch.empty(0, dtype=torch.uint8, device=h.device)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, dout, _darg):
+        n, k, c, mode = ctx.cfg
+        dout = _c(dout)
+        arg = ctx.saved_tensors[0] if mode < 2 else None
+        dh = torch.empty(n * k, c, dtype=torch.float32, device=dout.device)
+        lib.call("dc_seg_reduce_backward", dout, c, arg, n, k, c, mode, dh)
+        return dh, None, None, None
+
+
+def seg_reduce(h, n, k, aggr):
+    """-> (reduced [n, C], first extremal slot uint8 [n, C] for 'max' / 'min', else an empty tensor)."""
+    require_gpu()
+    return _SegReduce.apply(h, n, k, _SEG_MODES[aggr])
+
+
 USE_EDGE2 = True    # A/B switch: False = the materialised [E, C] path for the depth-2 centralised edge MLP
 EDGE2_CH = 64       # csrc/edge2.hip is specialised to 64 channels in both blocks (the part-segmentation net's first layer)
 

@@ -294,6 +294,18 @@ int dc_edge_max_backward_tiled(const float* dout, int64_t lddo, const float* y, 
                                float* dzs, float* dy, int64_t lddy, float* dgamma, float* dbeta, void* workspace,
                                size_t workspace_bytes, void* stream);
 
+/* ---- general form of the centralised edge MLP: materialised edge tensor --------------------------------------------------
+ * x_edge = x[col] - x[row] and scatter(h, row, reduce=aggr) of deltaconv/nn/deltaconv.py:50-52 for the shapes the two fused
+ * forms do not cover (depth >= 3, other widths, aggr != 'max'): edges are centre-major with k contiguous slots
+ * (grad_div_mls.py:24-25), so the scatter is a reduction over k consecutive rows.  mode: 0 max, 1 min, 2 sum, 3 mean;
+ * max / min ties keep the first slot. */
+int dc_edge_diff(const float* x, int64_t ldx, const int32_t* nbr, int32_t n, int32_t k, int32_t C, float* out, void* stream);
+int dc_edge_diff_backward(const float* dE, const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, int32_t C,
+                          float* dx, int64_t lddx, void* stream);
+int dc_seg_reduce(const float* h, int32_t n, int32_t k, int32_t C, int32_t mode, float* out, uint8_t* arg, void* stream);
+int dc_seg_reduce_backward(const float* dout, int64_t lddo, const uint8_t* arg, int32_t n, int32_t k, int32_t C, int32_t mode,
+                           float* dh, void* stream);
+
 /* ---- depth-2 centralised edge MLP + max aggregation (first layer of the part-segmentation net) ------------------------
  * out[i] = max_s act2(bn2(W2 act1(bn1(W1 (x_j - x_i))))), BatchNorm statistics over all E = n k edges:
  * deltaconv/nn/deltaconv.py:50-52 with s_mlp_max = MLP([ci, 64, 64]) (experiments/train_shapenet.py:77-89, mlp_depth = 2),

@@ -507,7 +507,7 @@ def test_c1_train_step_b2():
         worst_ref = max(worst_ref, float((p2.grad.double() - p3.grad).abs().max()) / gmax)
     print(f"worst grad error / largest gradient: hip-vs-f64 {worst_hip:.2e}  oracle32-vs-f64 {worst_ref:.2e}")
     # max-aggregation / max-pooling are piecewise: ONE arg-max that flips under fp32 rounding moves a few gradient
-    # entries by ~1e-2 of the largest gradient, in either implementation (measured with tools/archive/debug_b2.py: vendor-GEMM
+    # entries by ~1e-2 of the largest gradient, in either implementation (measured with tools/archive_r01_r04.tar.gz:archive/debug_b2.py: vendor-GEMM
     # path 1.1e-2 at B = 4, hand-written-GEMM path 1.8e-2 at B = 2, 8e-5 where nothing flips) -- hence the floor
     assert worst_hip < max(3 * worst_ref + 1e-3, 3e-2)
 
