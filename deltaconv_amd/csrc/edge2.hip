@@ -72,6 +72,63 @@ __device__ __forceinline__ Rows lds_row(const float* s, int q) {
     return r;
 }
 
+// Source of y1 = W1 (x_j - x_i) for the lane's 16 channels.  CI = 0: rows of z = x W1^T (any ci), y1 = z_j - z_i.  CI = 1..3:
+// the ci input channels themselves (positions, ci = 3, in both reference nets): y1 = W1 (x_j - x_i) evaluated per edge -- the
+// reference's own order of operations (the difference of two nearby points is exact in fp32, z_j - z_i loses |z| / |y1| ~ 20x
+// of that), 12 gathered bytes per neighbour instead of 256, and 3 fmaf per channel beside 64 MFMAs.
+template <int CI>
+struct EdgeSrc {
+    Rows zi;                          // CI == 0
+    float xi[CI > 0 ? CI : 1];        // CI > 0
+    f32x4 w[CI > 0 ? CI : 1][4];      // W1[16 b + 4 q + r][d] as [d][b][r]
+    const float* base; long ld;
+    __device__ __forceinline__ void init(const float* src, long ld_, long row, const float* __restrict__ W1, int q) {
+        base = src; ld = ld_;
+        if constexpr (CI == 0) zi = load_row(src, row, q);
+        else {
+#pragma unroll
+            for (int d = 0; d < CI; ++d) {
+                xi[d] = src[row * ld + d];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[d][b][r] = W1[(16 * b + 4 * q + r) * CI + d];
+            }
+        }
+    }
+    struct Nb { Rows z; float x[CI > 0 ? CI : 1]; };
+    __device__ __forceinline__ Nb fetch(long row, int q) const {
+        Nb nb;
+        if constexpr (CI == 0) nb.z = load_row(base, row, q);
+        else {
+#pragma unroll
+            for (int d = 0; d < CI; ++d) nb.x[d] = base[row * ld + d];
+        }
+        return nb;
+    }
+    __device__ __forceinline__ Rows y1(const Nb& nb) const {
+        Rows y;
+        if constexpr (CI == 0) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) y.v[b] = nb.z.v[b] - zi.v[b];
+        } else {
+            float dlt[CI];
+#pragma unroll
+            for (int d = 0; d < CI; ++d) dlt[d] = nb.x[d] - xi[d];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = w[0][b][r] * dlt[0];
+#pragma unroll
+                    for (int d = 1; d < CI; ++d) a = fmaf(w[d][b][r], dlt[d], a);
+                    y.v[b][r] = a;
+                }
+        }
+        return y;
+    }
+};
+
 // product 1: y2 (register [mb][r']) from h (register [cb][r])
 __device__ __forceinline__ void product1(const f32x4* fragA1, int lane, const Rows& h, Rows& y2) {
 #pragma unroll
@@ -109,7 +166,9 @@ __device__ __forceinline__ void block_sums(float (*red)[2][CH], int wave, int q,
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WPB * 64) void edge2_fwd_kernel(const float* __restrict__ z, const int* __restrict__ nbr, long n, int k,
+template <int CI>
+__global__ __launch_bounds__(WPB * 64, 2) void edge2_fwd_kernel(const float* __restrict__ src, long ldsrc, const float* __restrict__ W1,
+                                                             const int* __restrict__ nbr, long n, int k,
                                                              const float* __restrict__ W2, const float* __restrict__ scale1,
                                                              const float* __restrict__ shift1, float slope1,
                                                              const float* __restrict__ gamma2, float* __restrict__ ysel,
@@ -130,25 +189,27 @@ __global__ __launch_bounds__(WPB * 64) void edge2_fwd_kernel(const float* __rest
     const long p = blk * PPB + wave * PPW + j;
     const bool live = p < n;
     const long pc = live ? p : n - 1;
-    const Rows zi = load_row(z, pc, q), sc = lds_row(s_sc, q), sh = lds_row(s_sh, q), sg = lds_row(s_sg, q);
+    const Rows sc = lds_row(s_sc, q), sh = lds_row(s_sh, q), sg = lds_row(s_sg, q);
+    EdgeSrc<CI> es;
+    es.init(src, ldsrc, pc, W1, q);
     const int* ids = nbr + pc * k;
-    Rows zn = load_row(z, ids[0], q);
+    typename EdgeSrc<CI>::Nb zn = es.fetch(ids[0], q);
     int id_next = ids[k > 1 ? 1 : 0];
     Rows s0, s1, best;
     unsigned bestarg[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int b = 0; b < 4; ++b) s0.v[b] = s1.v[b] = best.v[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < k; ++s) {
-        const Rows zc = zn;
+        const Rows y1 = es.y1(zn);
         if (s + 1 < k) {
-            zn = load_row(z, id_next, q);
+            zn = es.fetch(id_next, q);
             id_next = ids[s + 2 < k ? s + 2 : k - 1];
         }
         Rows h, y2;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h.v[b][r] = dcnn::act(fmaf(sc.v[b][r], zc.v[b][r] - zi.v[b][r], sh.v[b][r]), slope1);
+            for (int r = 0; r < 4; ++r) h.v[b][r] = dcnn::act(fmaf(sc.v[b][r], y1.v[b][r], sh.v[b][r]), slope1);
         product1(fragA1, lane, h, y2);
         const unsigned sbytes = (unsigned)s * 0x01010101u;
 #pragma unroll
@@ -180,7 +241,9 @@ __global__ __launch_bounds__(WPB * 64) void edge2_fwd_kernel(const float* __rest
 
 // ---- backward, the recompute pass -------------------------------------------------------------------------------------
 // coefs2 = the five rows [scale2 | shift2 | a | c | b] of BwdCoefFin (colreduce.h):  dy2 = a hot + c y2 + b
-__global__ __launch_bounds__(WPB * 64) void edge2_bwd_kernel(const float* __restrict__ z, const int* __restrict__ nbr, long n, int k,
+template <int CI>
+__global__ __launch_bounds__(WPB * 64, 2) void edge2_bwd_kernel(const float* __restrict__ src, long ldsrc, const float* __restrict__ W1,
+                                                             const int* __restrict__ nbr, long n, int k,
                                                              const float* __restrict__ W2, const float* __restrict__ scale1,
                                                              const float* __restrict__ shift1, float slope1,
                                                              const float* __restrict__ coefs2, const float* __restrict__ dz2,
@@ -211,21 +274,23 @@ __global__ __launch_bounds__(WPB * 64) void edge2_bwd_kernel(const float* __rest
     const bool live = p < n;
     const long pc = live ? p : n - 1;
     const int row = wave * PPW + j;
-    const Rows zi = load_row(z, pc, q), dzv = load_row(dz2, pc, q);
+    const Rows dzv = load_row(dz2, pc, q);
+    EdgeSrc<CI> es;
+    es.init(src, ldsrc, pc, W1, q);
     unsigned argv[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) argv[b] = *reinterpret_cast<const unsigned*>(arg + pc * CH + 16 * b + 4 * q);
     const int* ids = nbr + pc * k;
-    Rows zn = load_row(z, ids[0], q);
+    typename EdgeSrc<CI>::Nb zn = es.fetch(ids[0], q);
     int id_next = ids[k > 1 ? 1 : 0];
     Rows cs, cy;
     f32x4 dw[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) cs.v[b] = cy.v[b] = dw[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < k; ++s) {
-        const Rows zc = zn;
+        const Rows y1 = es.y1(zn);
         if (s + 1 < k) {
-            zn = load_row(z, id_next, q);
+            zn = es.fetch(id_next, q);
             id_next = ids[s + 2 < k ? s + 2 : k - 1];
         }
         Rows h, y2;
@@ -234,7 +299,7 @@ __global__ __launch_bounds__(WPB * 64) void edge2_bwd_kernel(const float* __rest
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h.v[b][r] = dcnn::act(fmaf(sc.v[b][r], zc.v[b][r] - zi.v[b][r], sh.v[b][r]), slope1);
+                for (int r = 0; r < 4; ++r) h.v[b][r] = dcnn::act(fmaf(sc.v[b][r], y1.v[b][r], sh.v[b][r]), slope1);
         }
         product1(fragA1, lane, h, y2);
         {   // dy2 in place of y2
@@ -274,7 +339,7 @@ __global__ __launch_bounds__(WPB * 64) void edge2_bwd_kernel(const float* __rest
                 const float d = du.v[b][r] * (h.v[b][r] > 0.f ? 1.f : slope1);      // act1'(pre1): h1 > 0  <=>  pre1 > 0
                 du.v[b][r] = d;
                 cs.v[b][r] += d;
-                cy.v[b][r] = fmaf(d, zc.v[b][r] - zi.v[b][r], cy.v[b][r]);
+                cy.v[b][r] = fmaf(d, y1.v[b][r], cy.v[b][r]);
             }
             if (live) *reinterpret_cast<f32x4*>(dU + (p * k + s) * CH + 16 * b + 4 * q) = du.v[b];
         }
@@ -403,13 +468,15 @@ DC_EXPORT size_t dc_edge2_workspace_bytes(int32_t n, int32_t k, int32_t backward
     return b;
 }
 
-// Forward: z [n, 64] contiguous (= x W1^T), scale1 / shift1 = BatchNorm-1 as an affine map (batch statistics of z_j - z_i from
+// Forward: z [n, 64] contiguous (= x W1^T); x [n, ci] (row stride ldx) and W1 [64, ci]: when given and ci <= 3 the kernels
+// evaluate y1 = W1 (x_j - x_i) per edge (the reference's order of operations) instead of z_j - z_i; scale1 / shift1 = BatchNorm-1 as an affine map (batch statistics of z_j - z_i from
 // dc_edge_gather_stats, or the running ones), W2 [64, 64].  Outputs ysel [n, 64] = the selected pre-BatchNorm-2 value per
 // (point, channel), arg uint8 [n, 64] its first slot.  stats_mode 1: BatchNorm-2 batch statistics over all n k edges ->
 // mean2 / invstd2 / scale2 / shift2 (+ running statistics); 2: only the fp64 sums [sum y2 | sum y2^2] -> sums[128]
 // (synchronised BatchNorm: all-reduce, then dc_bn_coeffs_from_sums); 0: none (inference: coefficients from the running
 // statistics).  out = act2(scale2 ysel + shift2) is one dc_bn_act call of the caller.
-DC_EXPORT int dc_edge2_forward(const float* z, const int32_t* nbr, int32_t n, int32_t k, const float* W2, const float* scale1,
+DC_EXPORT int dc_edge2_forward(const float* z, const float* x, int64_t ldx, int32_t ci, const float* W1, const int32_t* nbr,
+                               int32_t n, int32_t k, const float* W2, const float* scale1,
                                const float* shift1, float slope1, int32_t stats_mode, const float* gamma2, const float* beta2,
                                float eps, float momentum, float* running_mean, float* running_var, float* ysel, uint8_t* arg,
                                float* mean2, float* invstd2, float* scale2, float* shift2, double* sums, void* workspace,
@@ -426,8 +493,16 @@ DC_EXPORT int dc_edge2_forward(const float* z, const int32_t* nbr, int32_t n, in
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int chunks = edge2_chunks(n);
     double* partial = stats_mode ? static_cast<double*>(workspace) : nullptr;
-    hipLaunchKernelGGL(edge2_fwd_kernel, dim3(chunks), dim3(WPB * 64), 0, s, z, nbr, (long)n, k, W2, scale1, shift1, slope1, gamma2,
-                       ysel, arg, partial, chunks, dc_option(DC_OPT_XCD_REMAP));
+    const int remap = dc_option(DC_OPT_XCD_REMAP);
+    const bool direct = x && W1 && ci >= 1 && ci <= 3 && ldx >= ci;
+#define DC_EDGE2_FWD(CI, SRC, LD)                                                                                              \
+    hipLaunchKernelGGL(edge2_fwd_kernel<CI>, dim3(chunks), dim3(WPB * 64), 0, s, SRC, (long)(LD), W1, nbr, (long)n, k, W2, scale1, \
+                       shift1, slope1, gamma2, ysel, arg, partial, chunks, remap)
+    if (!direct) DC_EDGE2_FWD(0, z, CH);
+    else if (ci == 1) DC_EDGE2_FWD(1, x, ldx);
+    else if (ci == 2) DC_EDGE2_FWD(2, x, ldx);
+    else DC_EDGE2_FWD(3, x, ldx);
+#undef DC_EDGE2_FWD
     if (stats_mode == 1) {
         const BnFin fin{(long)n * k, gamma2, beta2, eps, momentum, running_mean, running_var, mean2, invstd2, scale2, shift2};
         hipLaunchKernelGGL((colreduce_final_kernel<BnFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH, fin);
@@ -443,7 +518,8 @@ DC_EXPORT int dc_edge2_forward(const float* z, const int32_t* nbr, int32_t n, in
 // coef1 / coef2 = [mean | invstd | scale | shift] rows (4 x 64) of the two BatchNorms as used in the forward pass;
 // training1 / training2: batch statistics (the mean / variance terms of the BatchNorm backward) or running ones;
 // tptr / tedge = the CSC of the graph (dc_csc_build); s1pt = sum_s (z_j - z_i) per point (dc_edge_gather_stats).
-DC_EXPORT int dc_edge2_backward(const float* dout, int64_t lddo, const float* z, const int32_t* nbr, const int32_t* tptr,
+DC_EXPORT int dc_edge2_backward(const float* dout, int64_t lddo, const float* z, const float* x, int64_t ldx, int32_t ci,
+                                const float* W1, const int32_t* nbr, const int32_t* tptr,
                                 const int32_t* tedge, int32_t n, int32_t k, const float* W2, const float* coef1,
                                 const float* coef2, const float* gamma2, float slope1, float slope2, int32_t training1,
                                 int32_t training2, const float* ysel, const uint8_t* arg, const float* s1pt, float* dz,
@@ -481,12 +557,21 @@ DC_EXPORT int dc_edge2_backward(const float* dout, int64_t lddo, const float* z,
     }
     // 2. the recompute pass
     const int remap = dc_option(DC_OPT_XCD_REMAP);
-    static unsigned long long attr_set = 0;
-    if (!dc_ensure_lds(&attr_set, reinterpret_cast<const void*>(&edge2_bwd_kernel), BWD_LDS, "dc_edge2_backward")) {
-        DC_CHECK_LAUNCH("dc_edge2_backward");
-    }
-    hipLaunchKernelGGL(edge2_bwd_kernel, dim3(chunks), dim3(WPB * 64), BWD_LDS, s, z, nbr, (long)n, k, W2, scale1, shift1, slope1, coefs5, dz2,
-                       arg, dU, csum, partial, dWpart, chunks, remap);
+    const bool direct = x && W1 && ci >= 1 && ci <= 3 && ldx >= ci;
+#define DC_EDGE2_BWD(CI, SRC, LD)                                                                                              \
+    do {                                                                                                                        \
+        static unsigned long long attr_set = 0;                                                                                 \
+        if (!dc_ensure_lds(&attr_set, reinterpret_cast<const void*>(&edge2_bwd_kernel<CI>), BWD_LDS, "dc_edge2_backward")) {     \
+            DC_CHECK_LAUNCH("dc_edge2_backward");                                                                               \
+        }                                                                                                                       \
+        hipLaunchKernelGGL(edge2_bwd_kernel<CI>, dim3(chunks), dim3(WPB * 64), BWD_LDS, s, SRC, (long)(LD), W1, nbr, (long)n, k, W2, \
+                           scale1, shift1, slope1, coefs5, dz2, arg, dU, csum, partial, dWpart, chunks, remap);                 \
+    } while (0)
+    if (!direct) DC_EDGE2_BWD(0, z, CH);
+    else if (ci == 1) DC_EDGE2_BWD(1, x, ldx);
+    else if (ci == 2) DC_EDGE2_BWD(2, x, ldx);
+    else DC_EDGE2_BWD(3, x, ldx);
+#undef DC_EDGE2_BWD
     // 3. BatchNorm-1 sums, dW2
     hipLaunchKernelGGL((colreduce_final_kernel<Bn1BwdFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH,
                        Bn1BwdFin{(long)n * k, mean1, invstd1, training1, dgamma1, dbeta1, m12, m12 + CH});

@@ -435,7 +435,7 @@ class _EdgeMLP2(torch.autograd.Function):
         arg = torch.empty(n, c, dtype=torch.uint8, device=dev)
         nb2 = lib.raw("dc_edge2_workspace_bytes")(n, k, 0)
         ws2 = torch.empty((nb2 + 7) // 8, dtype=torch.float64, device=dev)
-        lib.call("dc_edge2_forward", z, graph.nbr, n, k, W2, coef1[2], coef1[3], slope1, int(use2), g2, b2, eps2, mom2,
+        lib.call("dc_edge2_forward", z, x, x.stride(0), x.shape[1], W1, graph.nbr, n, k, W2, coef1[2], coef1[3], slope1, int(use2), g2, b2, eps2, mom2,
                  rm2 if use2 else None, rv2 if use2 else None, ysel, arg, coef2[0], coef2[1], coef2[2], coef2[3], None, ws2, nb2)
         out = torch.empty(n, c, **f32)
         lib.call("dc_bn_act", ysel, n, c, c, coef2[2], coef2[3], slope2, None, 0, out, c)
@@ -458,7 +458,7 @@ class _EdgeMLP2(torch.autograd.Function):
         dg1, db1, dg2, db2 = (torch.empty(c, **f32) for _ in range(4))
         nb = lib.raw("dc_edge2_workspace_bytes")(n, k, 1)
         ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
-        lib.call("dc_edge2_backward", dout, c, z, g.nbr, tptr, tedge, n, k, W2, coef1, coef2, g2, slope1, slope2, int(use1),
+        lib.call("dc_edge2_backward", dout, c, z, x, x.stride(0), x.shape[1], W1, g.nbr, tptr, tedge, n, k, W2, coef1, coef2, g2, slope1, slope2, int(use1),
                  int(use2), ysel, arg, s1pt, dz, c, dW2, dg1, db1, dg2, db2, ws, nb)
         dW1 = gemm_tn(dz, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[2] else None
         dx = mm_nn(dz, W1) if ctx.needs_input_grad[0] else None

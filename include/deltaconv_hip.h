@@ -317,14 +317,17 @@ int dc_seg_reduce_backward(const float* dout, int64_t lddo, const uint8_t* arg, 
  * + a CSC closing pass; bit-reproducible (ordered reductions, in-edges in ascending edge id).  64 channels in both blocks.
  * stats_mode: 1 = batch statistics -> mean2 / invstd2 / scale2 / shift2 (+ running statistics), 2 = fp64 sums only
  * (sums[128] = [sum y2 | sum y2^2], synchronised BatchNorm), 0 = none.  coef1 / coef2 = [mean | invstd | scale | shift]
- * rows (4 x 64).  Workspace: dc_edge2_workspace_bytes(n, k, backward). */
+ * rows (4 x 64).  x [n, ci] / W1 [64, ci] (may be NULL): for ci <= 3 the edge pre-activation is evaluated as W1 (x_j - x_i)
+ * per edge, the reference's own order of operations, instead of z_j - z_i.  Workspace: dc_edge2_workspace_bytes(n, k, backward). */
 size_t dc_edge2_workspace_bytes(int32_t n, int32_t k, int32_t backward);
-int dc_edge2_forward(const float* z, const int32_t* nbr, int32_t n, int32_t k, const float* W2, const float* scale1,
+int dc_edge2_forward(const float* z, const float* x, int64_t ldx, int32_t ci, const float* W1, const int32_t* nbr,
+                     int32_t n, int32_t k, const float* W2, const float* scale1,
                      const float* shift1, float slope1, int32_t stats_mode, const float* gamma2, const float* beta2,
                      float eps, float momentum, float* running_mean, float* running_var, float* ysel, uint8_t* arg,
                      float* mean2, float* invstd2, float* scale2, float* shift2, double* sums, void* workspace,
                      size_t workspace_bytes, void* stream);
-int dc_edge2_backward(const float* dout, int64_t lddo, const float* z, const int32_t* nbr, const int32_t* tptr,
+int dc_edge2_backward(const float* dout, int64_t lddo, const float* z, const float* x, int64_t ldx, int32_t ci,
+                      const float* W1, const int32_t* nbr, const int32_t* tptr,
                       const int32_t* tedge, int32_t n, int32_t k, const float* W2, const float* coef1, const float* coef2,
                       const float* gamma2, float slope1, float slope2, int32_t training1, int32_t training2,
                       const float* ysel, const uint8_t* arg, const float* s1pt, float* dz, int64_t lddz, float* dW2,
