@@ -143,12 +143,18 @@ struct BwdCoefFin {
 struct NoFin {
     __device__ void operator()(int, double, double) const {}
 };
-// the two column sums themselves (fp64): the data-parallel SyncBN path all-reduces them across ranks
+// the two column sums themselves (fp64): the data-parallel SyncBN path all-reduces them across ranks.  Layout of `sums`:
+// double [2][2 C + 1] = two identical records (sum_0[C] | sum_1[C] | rows): the host all-reduces the FIRST record in place
+// and keeps the second as this rank's own sums (dgamma / dbeta are local quantities) -- no fill, no clone launch.
 struct SumsFin {
-    double* sums; int C;
+    double* sums; int C; double rows;
     __device__ void operator()(int c, double s0, double s1) const {
+        double* dup = sums + 2 * C + 1;
         sums[c] = s0;
         sums[C + c] = s1;
+        dup[c] = s0;
+        dup[C + c] = s1;
+        if (c == 0) { sums[2 * C] = rows; dup[2 * C] = rows; }
     }
 };
 

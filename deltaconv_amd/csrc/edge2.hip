@@ -507,7 +507,7 @@ DC_EXPORT int dc_edge2_forward(const float* z, const float* x, int64_t ldx, int3
         const BnFin fin{(long)n * k, gamma2, beta2, eps, momentum, running_mean, running_var, mean2, invstd2, scale2, shift2};
         hipLaunchKernelGGL((colreduce_final_kernel<BnFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH, fin);
     } else if (stats_mode == 2) {
-        hipLaunchKernelGGL((colreduce_final_kernel<SumsFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH, SumsFin{sums, CH});
+        hipLaunchKernelGGL((colreduce_final_kernel<SumsFin>), dim3(CH), dim3(64), 0, s, partial, chunks, CH, SumsFin{sums, CH, (double)n * k});
     }
     DC_CHECK_LAUNCH("dc_edge2_forward");
     return DC_OK;

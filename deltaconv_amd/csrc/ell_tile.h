@@ -309,7 +309,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
                 body.init(c);
                 Vec<4> s0 = vzero<4>(), s1 = vzero<4>();
                 if (U <= UL) {
-#pragma unroll 4
+#pragma unroll BODY::KU
                     for (int s = 0; s < k; ++s) {
                         const int l = lp[s];
                         const Vec<4> p0 = *reinterpret_cast<const Vec<4>*>(rows + (l * R) * 64 + l16 * 4);
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
 // grad @ x (ell_math.h: grad_fwd)
 struct GradB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr int KU = 4;                       // k-loop unroll of the persistent kernel
     static constexpr bool ROWPASS = false;
     static constexpr int NST = 2;                      // vector-memory store instructions of finish()
     const float* in; long ldj, hs; float* out; long ldo;
@@ -370,6 +371,7 @@ struct GradB {
 // div @ v (div_fwd)
 struct DivB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr int KU = 4;                       // k-loop unroll of the persistent kernel
     static constexpr bool ROWPASS = false;
     static constexpr int NST = 1;
     const float* in; long ldj, hs; float* out; long ldo;
@@ -381,6 +383,7 @@ struct DivB {
 // [div v | curl v | norm v] (divcurlnorm_fwd)
 struct DivCurlNormB {
     static constexpr bool COEF = true, SELF = true;
+    static constexpr int KU = 4;                       // k-loop unroll of the persistent kernel
     static constexpr bool ROWPASS = false;
     static constexpr int NST = 3;
     const float* in; long ldj, hs; float* out; long ldo; int C;
@@ -404,6 +407,7 @@ struct DivCurlNormB {
 // hodge Laplacian from [div v | curl v] (hodge_fwd): pieces = the two column blocks of one row
 struct HodgeB {
     static constexpr bool COEF = true, SELF = false;
+    static constexpr int KU = 2;     // 4 puts the persistent kernel at 128 registers + 1 scratch spill (round-4 verdict); same op order
     static constexpr bool ROWPASS = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; float* out; long ldo;
@@ -424,6 +428,7 @@ struct HodgeB {
 template <bool AFFINE>
 struct KnnMaxB {
     static constexpr bool COEF = false, SELF = false;
+    static constexpr int KU = 4;
     // ROWPASS: BatchNorm + activation of the producing block are applied ONCE per unique row, in place in LDS, before the walk
     // (the same fmaf and select per element as per gathered value before: same bits; ~165 rows instead of 64 x k gathers per tile --
     // the walk was VALU-bound: 9 of its 12 instructions per gathered value were this transform)

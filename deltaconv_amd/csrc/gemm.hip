@@ -1207,6 +1207,49 @@ DC_EXPORT int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const floa
     return DC_OK;
 }
 
+// The same two products with the statistics cut at the reduction (synchronised BatchNorm, data parallel): the fp64 column sums
+// sums[2 C] = (sum_0, sum_1) of THIS rank's rows instead of finalised coefficients -- the host all-reduces them and
+// dc_bn_coeffs_from_sums continues (deltaconv_amd/dp.py).  Same tile sums, same ordered final stage.
+DC_EXPORT int dc_linear_bn_sums_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K,
+                                        float* Y, int64_t ldy, double* sums, int32_t tile, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(X && W && Y && sums, "dc_linear_bn_sums_forward: null pointer");
+    DC_REQUIRE(M >= 1 && N >= 1 && K >= 1 && ldx >= K && ldw >= K && ldy >= N, "dc_linear_bn_sums_forward: bad size");
+    if (!workspace || workspace_bytes < dc_linear_stats_workspace_bytes(M, N, K, tile)) {
+        dc_set_error("dc_linear_bn_sums_forward: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(workspace);
+    if (int rc = run_gemm("dc_linear_bn_sums_forward", B_NK, EPI_COLSTATS, X, ldx, W, ldw, M, N, K, Y, ldy, 0, tile, part, N, s))
+        return rc;
+    hipLaunchKernelGGL((dccol::colreduce_final_kernel<dccol::SumsFin>), dim3(N), dim3(64), 0, s, part, chunks_for(M, N, K, tile), N,
+                       dccol::SumsFin{sums, N, (double)M});
+    DC_CHECK_LAUNCH("dc_linear_bn_sums_forward");
+    return DC_OK;
+}
+DC_EXPORT int dc_linear_vn_sums_forward(const float* V, int64_t ldv, const float* Wst, int64_t ldw, int64_t n, int32_t co, int32_t K,
+                                        float* PQ, int64_t ldpq, int32_t interleaved, double* sums, int32_t tile, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(V && Wst && PQ && sums, "dc_linear_vn_sums_forward: null pointer");
+    const long M = 2 * n;
+    const int N = interleaved ? 2 * co : co;
+    DC_REQUIRE(n >= 1 && co >= 1 && K >= 1 && ldv >= K && ldw >= K && ldpq >= N, "dc_linear_vn_sums_forward: bad size");
+    if (!workspace || workspace_bytes < dc_linear_stats_workspace_bytes(M, N, K, tile)) {
+        dc_set_error("dc_linear_vn_sums_forward: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* part = static_cast<double*>(workspace);
+    if (int rc = run_gemm("dc_linear_vn_sums_forward", B_NK, interleaved ? EPI_VNSTATS : EPI_VNSTATS0, V, ldv, Wst, ldw, M, N, K, PQ,
+                          ldpq, 0, tile, part, co, s))
+        return rc;
+    hipLaunchKernelGGL((dccol::colreduce_final_kernel<dccol::SumsFin>), dim3(co), dim3(64), 0, s, part, chunks_for(M, N, K, tile), co,
+                       dccol::SumsFin{sums, co, (double)n});
+    DC_CHECK_LAUNCH("dc_linear_vn_sums_forward");
+    return DC_OK;
+}
+
 // ---- pre-split weight planes (round 4) ------------------------------------------------------------------------------------
 // A weight matrix is the B operand of hundreds of workgroups per product and of several products per step; cutting it into
 // its three bf16 planes once per step (instead of in every wave's K loop) removes half of the split instructions and the whole

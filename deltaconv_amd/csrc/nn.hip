@@ -562,7 +562,7 @@ DC_EXPORT int dc_bn_sums(const float* h, int64_t R, int32_t C, int64_t ldh, doub
     DC_WS_CHECK("dc_bn_sums", R, C)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, R, C);
-    const SumsFin fin{sums, C};
+    const SumsFin fin{sums, C, (double)R};
     if (C % 4 == 0 && ldh % 4 == 0 && al16(h))
         run_colreduce<4>(StatsF<4>{h, (long)ldh}, R, C, w, s, fin);
     else
@@ -578,7 +578,7 @@ DC_EXPORT int dc_vn_sums(const float* in, int64_t n, int32_t co, int64_t ld, int
     DC_WS_CHECK("dc_vn_sums", n, co)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, n, co);
-    const SumsFin fin{sums, co};
+    const SumsFin fin{sums, co, (double)n};
     if (co % 4 == 0 && ld % 4 == 0 && al16(in))
         run_colreduce<4>(VnStatsF<4>{in, (long)ld, co, combine}, n, co, w, s, fin);
     else
@@ -612,12 +612,64 @@ DC_EXPORT int dc_bn_act_backward_sums(const float* dy, int64_t lddy, const float
     DC_WS_CHECK("dc_bn_act_backward_sums", R, C)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, R, C);
-    const SumsFin fin{sums, C};
+    const SumsFin fin{sums, C, (double)R};
     if (C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && al16(dy) && al16(h))
         run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
     else
         run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
     DC_CHECK_LAUNCH("dc_bn_act_backward_sums");
+    return DC_OK;
+}
+
+// backward, between the two steps: the global means and this rank's parameter gradients from the two records of `sums`
+// (first record all-reduced, second local): m1 = sum_0 / rows, m2 = sum_1 / rows, dbeta = local sum_0, dgamma = local sum_1.
+namespace {
+__global__ void sync_means_kernel(const double* __restrict__ sums, int C, float* m1, float* m2, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double* loc = sums + 2 * C + 1;
+    const double cnt = sums[2 * C];
+    m1[c] = (float)(sums[c] / cnt);
+    m2[c] = (float)(sums[C + c] / cnt);
+    if (dbeta) dbeta[c] = (float)loc[c];
+    if (dgamma) dgamma[c] = (float)loc[C + c];
+}
+}  // namespace
+DC_EXPORT int dc_sync_means(const double* sums, int32_t C, float* m1, float* m2, float* dgamma, float* dbeta, void* stream) {
+    DC_REQUIRE(sums && m1 && m2, "dc_sync_means: null pointer");
+    DC_REQUIRE(C >= 1, "dc_sync_means: bad size");
+    hipLaunchKernelGGL(sync_means_kernel, dim3(dc_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream), sums, C, m1, m2,
+                       dgamma, dbeta);
+    DC_CHECK_LAUNCH("dc_sync_means");
+    return DC_OK;
+}
+
+// backward, step 2 for the FUSED form (dc_linear_bn_backward_input / _weight rebuild dh in their operand loaders): the five
+// per-column coefficient rows of the GEMM prologue from the GLOBAL sums (count <= 0: the row count is on the device at
+// global_sums[2C]), dgamma / dbeta from this rank's own sums (they are averaged with every other gradient afterwards).
+namespace {
+__global__ void bn_bwd_coefs_from_sums_kernel(const double* __restrict__ gs, long count, const double* __restrict__ ls, int C,
+                                              BwdCoefFin fin) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    fin.R = count > 0 ? count : (long)(gs[2 * C] + 0.5);
+    float* dg = fin.dgamma; float* db = fin.dbeta;
+    fin.dgamma = nullptr; fin.dbeta = nullptr;
+    fin(c, gs[c], gs[C + c]);
+    if (db) db[c] = (float)ls[c];
+    if (dg) dg[c] = (float)ls[C + c];
+}
+}  // namespace
+DC_EXPORT int dc_bn_backward_coefs_from_sums(const double* global_sums, int64_t count, const double* local_sums, int32_t C,
+                                             const float* gamma, const float* scale, const float* shift, const float* mean,
+                                             const float* invstd, int32_t training, float* dgamma, float* dbeta, float* coefs,
+                                             void* stream) {
+    DC_REQUIRE(global_sums && local_sums && scale && shift && mean && invstd && coefs, "dc_bn_backward_coefs_from_sums: null pointer");
+    DC_REQUIRE(C >= 1, "dc_bn_backward_coefs_from_sums: bad size");
+    const BwdCoefFin fin{(long)count, gamma, scale, shift, mean, invstd, training, dgamma, dbeta, coefs, C};
+    hipLaunchKernelGGL(bn_bwd_coefs_from_sums_kernel, dim3(dc_cdiv(C, 128)), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       global_sums, (long)count, local_sums, C, fin);
+    DC_CHECK_LAUNCH("dc_bn_backward_coefs_from_sums");
     return DC_OK;
 }
 
@@ -648,7 +700,7 @@ DC_EXPORT int dc_vn_backward_sums(const float* dout, int64_t lddo, const float* 
     DC_WS_CHECK("dc_vn_backward_sums", n, co)
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, n, co);
-    const SumsFin fin{sums, co};
+    const SumsFin fin{sums, co, (double)n};
     if (co % 4 == 0 && ld % 4 == 0 && lddo % 4 == 0 && al16(in) && al16(dout))
         run_colreduce<4>(VnBwdF<4>{in, dout, scale, shift, mean, invstd, (long)ld, (long)lddo, co, combine}, n, co, w, s, fin);
     else

@@ -89,8 +89,8 @@ class DeltaNetBase(torch.nn.Module):
         # run as fused nodes; otherwise plain tensors
         widths = [c.out_channels for c in self.convs]
         from ..nn import fused
-        fusable = fused.sync_group() is None and all(c.fuse_layer and c.aggr == 'max' and c._fusable() is not None and w % 4 == 0
-                                                     for c, w in zip(self.convs, widths))
+        fusable = all(c.fuse_layer and c.aggr == 'max' and c._fusable() is not None and w % 4 == 0
+                      for c, w in zip(self.convs, widths))
         blocks = None
         if fusable and x.is_cuda:
             xall = torch.empty(x.shape[0], sum(widths), dtype=torch.float32, device=x.device)

@@ -62,10 +62,10 @@ class DeltaConv(torch.nn.Module):
         one fused node x' is ALSO written into that column block; the call then returns THREE values
         (x' as that column block, v', x' as the view inside the next layer's operand buffer)."""
         graph = as_graph(edge_index, grad.graph)
-        # synchronised BatchNorm (dp.py) runs through the composed blocks: their statistics kernels have the split form
-        # (the fused node is the max-aggregation layer of every reference model; other aggregations run composed)
-        slopes = (self._fusable() if (self.fuse_layer and self.aggr == 'max' and fused.sync_group() is None and x.is_cuda)
-                  else None)
+        # (the fused node is the max-aggregation layer of every reference model; other aggregations run composed.  Under
+        # synchronised BatchNorm (dp.py) the node keeps its GEMM epilogues: they emit this rank's sums, fused.linear_stats
+        # all-reduces them; only a centralised edge MLP -- statistics over the edges -- is computed outside, below)
+        slopes = self._fusable() if (self.fuse_layer and self.aggr == 'max' and x.is_cuda) else None
         if slopes is None:
             return self.forward_composed(x, v, grad, div, graph)
         slopes_m, slopes_s = slopes
@@ -78,8 +78,9 @@ class DeltaConv(torch.nn.Module):
                      else None)
         x_max = None
         blocks_m = list(self.s_mlp_max)
-        if self.centralized and len(blocks_m) > 1:
-            # edge MLP of depth > 1: BatchNorm over the [E, C] edge tensor between two products -- computed outside
+        if self.centralized and (len(blocks_m) > 1 or fused.sync_group() is not None):
+            # edge MLP of depth > 1 (csrc/edge2.hip or the general form), or synchronised statistics over the edges -- computed
+            # outside, enters the node as x_max
             x_max = self._centralized_max(x, graph)
             blocks_m = []
         blocks_s = list(self.s_mlp)

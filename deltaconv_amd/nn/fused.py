@@ -62,14 +62,15 @@ def sync_group():
 
 
 def _sync_stats(kernel_args, c, rows, dev, group):
-    """Local fp64 sums via a dc_*_sums entry point -> [sum_0 | sum_1 | rows] all-reduced over `group`.
-    Returns (global stats, local stats)."""
+    """Local fp64 sums via a dc_*_sums entry point -> all-reduced over `group`.  The kernels write TWO identical records
+    [sum_0 | sum_1 | rows] (csrc/colreduce.h: SumsFin): the first is all-reduced in place, the second stays this rank's own --
+    no fill, no clone launch.  Returns (global record, local record), views of one buffer.  (`rows` is written by the kernel.)"""
     from .. import dp
-    local = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-    local[2 * c:].fill_(float(rows))          # (a fill kernel: `local[i] = x` is a host-to-device copy, not capturable)
+    buf = torch.empty(2, 2 * c + 1, dtype=torch.float64, device=dev)
     name, args = kernel_args
-    lib.call(name, *args(local))
-    return dp.all_reduce_stats(local.clone(), group), local
+    lib.call(name, *args(buf))
+    dp.all_reduce_stats(buf[0], group)
+    return buf[0], buf[1]
 
 
 _EVAL_EPOCH = [0]
@@ -143,7 +144,6 @@ class _BNAct(torch.autograd.Function):
         if ctx.group is not None:                                     # statistics of the global batch
             ws, nb = _ws(r, c, dev)
             stats, _ = _sync_stats(("dc_bn_sums", lambda out: (h, r, c, c, out, ws, nb)), c, r, dev, ctx.group)
-            ctx.stats_cnt = stats[2 * c:2 * c + 1]
             lib.call("dc_bn_coeffs_from_sums", stats, 0, c, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1],
                      coef[2], coef[3])
         elif use_batch_stats:
@@ -170,16 +170,12 @@ class _BNAct(torch.autograd.Function):
         dbeta = torch.empty(c, dtype=torch.float32, device=h.device) if has_b else None
         ws, nb = _ws(r, c, h.device)
         if ctx.group is not None:
-            stats, local = _sync_stats(("dc_bn_act_backward_sums", lambda out: (dy, c, h, c, r, c, coef[2], coef[3], coef[0],
-                                                                             coef[1], slope, out, ws, nb)), c, 0, h.device,
-                                       ctx.group)
-            if has_b:
-                dbeta.copy_(local[:c])
-            if has_g:
-                dgamma.copy_(local[c:2 * c])
-            m = (stats[:2 * c] / ctx.stats_cnt).float()
+            stats, _ = _sync_stats(("dc_bn_act_backward_sums", lambda out: (dy, c, h, c, r, c, coef[2], coef[3], coef[0],
+                                                                         coef[1], slope, out, ws, nb)), c, r, h.device, ctx.group)
+            m = torch.empty(2, c, dtype=torch.float32, device=h.device)
+            lib.call("dc_sync_means", stats, c, m[0], m[1], dgamma, dbeta)      # global means + this rank's dgamma / dbeta
             lib.call("dc_bn_act_backward_apply", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
-                     int(training), m[:c], m[c:], dh, c)
+                     int(training), m[0], m[1], dh, c)
         else:
             lib.call("dc_bn_act_backward", dy, c, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
                      int(training), dh, c, dgamma, dbeta, ws, nb)
@@ -217,7 +213,6 @@ class _VectorNonLin(torch.autograd.Function):
             ws, nb = _ws(n, co, dev)
             stats, _ = _sync_stats(("dc_vn_sums", lambda out: (inp, n, co, ld, int(combine), out, ws, nb)), co, n, dev,
                                    ctx.group)
-            ctx.stats_cnt = stats[2 * co:2 * co + 1]
             lib.call("dc_bn_coeffs_from_sums", stats, 0, co, gamma, beta, eps, momentum, rm, rv, coef[0], coef[1],
                      coef[2], coef[3])
         elif mode == 2:
@@ -248,16 +243,12 @@ class _VectorNonLin(torch.autograd.Function):
         dbeta = torch.empty(co, dtype=torch.float32, device=dev) if has_b else None
         ws, nb = _ws(n, co, dev)
         if ctx.group is not None:
-            stats, local = _sync_stats(("dc_vn_backward_sums", lambda out: (dout, co, inp, ld, combine, n, co, coef[2], coef[3],
-                                                                         coef[0], coef[1], out, ws, nb)), co, 0, dev,
-                                       ctx.group)
-            if has_b:
-                dbeta.copy_(local[:co])
-            if has_g:
-                dgamma.copy_(local[co:2 * co])
-            m = (stats[:2 * co] / ctx.stats_cnt).float()
+            stats, _ = _sync_stats(("dc_vn_backward_sums", lambda out: (dout, co, inp, ld, combine, n, co, coef[2], coef[3],
+                                                                     coef[0], coef[1], out, ws, nb)), co, n, dev, ctx.group)
+            m = torch.empty(2, co, dtype=torch.float32, device=dev)
+            lib.call("dc_sync_means", stats, co, m[0], m[1], dgamma, dbeta)
             lib.call("dc_vn_backward_apply", dout, co, inp, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1], gamma,
-                     1, m[:co], m[co:], din, ld)
+                     1, m[0], m[1], din, ld)
         else:
             lib.call("dc_vn_backward", dout, co, inp, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1],
                      gamma if mode else None, int(mode == 2), din, ld, dgamma, dbeta, ws, nb)
@@ -766,7 +757,24 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
     rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
     coef = torch.empty(4, c, dtype=torch.float32, device=dev)
     h = torch.empty(m, n, dtype=torch.float32, device=dev)
-    if use_batch and _own_gemm(x) and sync_group() is None:
+    group = sync_group() if use_batch else None
+    if group is not None and _own_gemm(x):
+        # statistics of the GLOBAL batch (deltaconv_amd/dp.py): the same GEMM epilogue, cut at the reduction -- this rank's fp64
+        # column sums + its row count are all-reduced, dc_bn_coeffs_from_sums finishes (round 5: the fused layer nodes keep
+        # their epilogues under synchronised BatchNorm instead of falling back to the composed blocks)
+        from .. import dp
+        nb = lib.raw("dc_linear_stats_workspace_bytes")(m, n, k, 0)
+        ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
+        sums = torch.empty(2, 2 * c + 1, dtype=torch.float64, device=dev)      # two records: [0] all-reduced, [1] local
+        _hint_planes(w, False)
+        if vn:
+            lib.call("dc_linear_vn_sums_forward", x, x.stride(0), w, w.stride(0), rows, c, k, h, n, int(vn == 2), sums, 0, ws, nb)
+        else:
+            lib.call("dc_linear_bn_sums_forward", x, x.stride(0), w, w.stride(0), m, n, k, h, n, sums, 0, ws, nb)
+        dp.all_reduce_stats(sums[0], group)
+        lib.call("dc_bn_coeffs_from_sums", sums[0], 0, c, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3])
+        return h, coef, True
+    if use_batch and _own_gemm(x) and group is None:
         nb = lib.raw("dc_linear_stats_workspace_bytes")(m, n, k, 0)
         ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
         _hint_planes(w, False)
@@ -779,7 +787,7 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
         return h, coef, True
     mm_nt(x, w, out=h)
     if use_batch:
-        assert sync_group() is None, "synchronised BatchNorm runs through bn_act / vector_nonlin"
+        assert group is None, "synchronised BatchNorm runs through bn_act / vector_nonlin when the own GEMM kernels are off"
         ws, nb = _ws(rows, c, dev)
         if vn:
             lib.call("dc_vn_stats", h, rows, c, n, 2 if vn == 2 else 0, gamma, beta, float(bn.eps), mom, rm, rv, coef[0],
@@ -809,10 +817,17 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
     db = torch.empty(c, dtype=torch.float32, device=dev)
     ws, nb = _ws(r, c, dev)
     inp = _rowmajor(inp)
-    if FUSE_BN_BWD and _own_gemm(h) and USE_MFMA_TN and c * k <= OWN_TN_MAX_OUTPUTS:
+    group = sync_group() if use_batch else None
+    if (FUSE_BN_BWD or group is not None) and _own_gemm(h) and USE_MFMA_TN and c * k <= OWN_TN_MAX_OUTPUTS:
         coefs = torch.empty(5 * c, dtype=torch.float32, device=dev)
-        lib.call("dc_bn_act_backward_reduce", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
-                 int(use_batch), dg, db, coefs, ws, nb)
+        if group is not None:     # sums of this rank -> all-reduce -> the prologue coefficients from the global sums
+            stats, local = _sync_stats(("dc_bn_act_backward_sums", lambda out: (dy, lddy, h, c, r, c, coef[2], coef[3], coef[0],
+                                                                             coef[1], slope, out, ws, nb)), c, r, dev, group)
+            lib.call("dc_bn_backward_coefs_from_sums", stats, 0, local, c, gamma, coef[2], coef[3], coef[0], coef[1], 1, dg, db,
+                     coefs)
+        else:
+            lib.call("dc_bn_act_backward_reduce", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
+                     int(use_batch), dg, db, coefs, ws, nb)
         dW = torch.empty(c, k, dtype=torch.float32, device=dev)
         nb2 = lib.raw("dc_gemm_tn_workspace_bytes")(r, c, k)
         ws2 = torch.empty((nb2 + 3) // 4, dtype=torch.float32, device=dev)
@@ -826,6 +841,7 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
             lib.call("dc_linear_bn_backward_input", dy, lddy, h, c, coefs, slope, W, W.stride(0), r, c, k, dinp,
                      dinp.stride(0), int(accumulate), 0)
         return dW, dg, db, dinp
+    assert group is None, "synchronised BatchNorm backward of a fused block needs the own GEMM kernels"
     dh = torch.empty_like(h)
     lib.call("dc_bn_act_backward", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope, int(use_batch),
              dh, c, dg, db, ws, nb)
@@ -1005,7 +1021,7 @@ def linear_bn_act(x, lin, bn, slope, residual=None):
     """[Linear(no bias) -> BatchNorm1d -> leaky(slope)](x) (+ residual); lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d."""
     if lin.bias is None and residual is None and _rowblock_ok(x, lin.weight):
         return _RowBlock.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope))
-    if (lin.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and sync_group() is None):
+    if lin.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32:     # (synchronised statistics included)
         return _LinearBNAct.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope), residual)
     return bn_act(linear(x, lin.weight, lin.bias), bn, slope, residual)
 

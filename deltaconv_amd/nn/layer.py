@@ -118,6 +118,15 @@ def _vn_backward(dout, lddo, h, combine, coef, use, gamma):
     dh = torch.empty_like(h)
     dg, db = torch.empty(co, dtype=_F32, device=dev), torch.empty(co, dtype=_F32, device=dev)
     ws, nb = fused._ws(n, co, dev)
+    group = fused.sync_group() if use else None
+    if group is not None:        # synchronised statistics: this rank's sums -> all-reduce -> apply with the global means
+        stats, local = fused._sync_stats(("dc_vn_backward_sums", lambda out: (dout, lddo, h, ld, combine, n, co, coef[2], coef[3],
+                                                                              coef[0], coef[1], out, ws, nb)), co, n, dev, group)
+        m = torch.empty(2, co, dtype=_F32, device=dev)
+        lib.call("dc_sync_means", stats, co, m[0], m[1], dg, db)             # global means + this rank's dgamma / dbeta
+        lib.call("dc_vn_backward_apply", dout, lddo, h, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1], gamma, 1,
+                 m[0], m[1], dh, ld)
+        return dh, dg, db
     lib.call("dc_vn_backward", dout, lddo, h, ld, combine, n, co, coef[2], coef[3], coef[0], coef[1], gamma, int(use),
              dh, ld, dg, db, ws, nb)
     return dh, dg, db

@@ -346,7 +346,10 @@ int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t
 /* ---- split statistics for synchronised BatchNorm (data parallel) ----------------------------------------
  * Same arithmetic as dc_bn_stats / dc_vn_stats / dc_bn_act_backward / dc_vn_backward (nn/nonlin.py:24-35, 63-79),
  * cut at the reduction so that the host can all-reduce the fp64 column sums across ranks in between
- * (deltaconv_amd/dp.py).  sums: double [2*C] = (sum_0[C], sum_1[C]).
+ * (deltaconv_amd/dp.py).  sums: double [2][2*C + 1] = two identical records
+ * (sum_0[C] | sum_1[C] | rows of this rank): the host all-reduces the FIRST record in place, the second stays this rank's own
+ * (dgamma / dbeta are local sums): no fill, no clone.  dc_sync_means: m1 = sum_0 / rows, m2 = sum_1 / rows from the reduced
+ * record, dbeta / dgamma (may be NULL) from the local one.
  *   forward : dc_bn_sums | dc_vn_sums -> all-reduce -> dc_bn_coeffs_from_sums(count = rows of ALL ranks; count <= 0:
  *             the count is on the device at sums[2*C], all-reduced together with the sums -- no host sync)
  *   backward: dc_*_backward_sums -> all-reduce -> m1 = sum_0 / count, m2 = sum_1 / count -> dc_*_backward_apply;
@@ -361,6 +364,7 @@ int dc_bn_coeffs_from_sums(const double* sums, int64_t count, int32_t C, const f
 int dc_bn_act_backward_sums(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
                             const float* scale, const float* shift, const float* mean, const float* invstd,
                             float slope, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int dc_sync_means(const double* sums, int32_t C, float* m1, float* m2, float* dgamma, float* dbeta, void* stream);
 int dc_bn_act_backward_apply(const float* dy, int64_t lddy, const float* h, int64_t ldh, int64_t R, int32_t C,
                              const float* scale, const float* shift, const float* mean, const float* invstd,
                              const float* gamma, float slope, int32_t training, const float* m1, const float* m2,
@@ -416,6 +420,16 @@ int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const float* Wst, in
                                float* scale, float* shift, int32_t tile, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* the two statistics products with the reduction cut open (synchronised BatchNorm): sums[2 C] = the fp64 column sums of this
+ * rank's rows (two records, as above), to be all-reduced and finished by dc_bn_coeffs_from_sums -- the fused layer nodes keep their GEMM epilogues
+ * when BatchNorm statistics span the ranks of a data-parallel group. */
+int dc_linear_bn_sums_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K,
+                              float* Y, int64_t ldy, double* sums, int32_t tile, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int dc_linear_vn_sums_forward(const float* V, int64_t ldv, const float* Wst, int64_t ldw, int64_t n, int32_t co, int32_t K,
+                              float* PQ, int64_t ldpq, int32_t interleaved, double* sums, int32_t tile, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
 /* ---- BatchNorm/activation backward folded into the GEMMs that consume it --------------------------------
  * Backward of one MLP block y = leaky(batch_norm(x W^T)) (nn/mlp.py:7-11, nn/nonlin.py:24-35): instead of
  * dc_bn_act_backward (reduce + a pass that writes dh) followed by two products that read dh,
@@ -428,6 +442,13 @@ int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const float* h, int
                               const float* scale, const float* shift, const float* mean, const float* invstd,
                               const float* gamma, float slope, int32_t training, float* dgamma, float* dbeta,
                               float* coefs, void* workspace, size_t workspace_bytes, void* stream);
+/* the coefficient rows of that prologue from ALL-REDUCED sums (dc_bn_act_backward_sums on every rank -> all-reduce):
+ * coefs[5 C] from global_sums and the global row count (count <= 0: on the device at global_sums[2 C]); dgamma / dbeta
+ * from local_sums (this rank's share; gradients are averaged afterwards). */
+int dc_bn_backward_coefs_from_sums(const double* global_sums, int64_t count, const double* local_sums, int32_t C,
+                                   const float* gamma, const float* scale, const float* shift, const float* mean,
+                                   const float* invstd, int32_t training, float* dgamma, float* dbeta, float* coefs,
+                                   void* stream);
 int dc_linear_bn_backward_input(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
                                 float slope, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K, float* dX,
                                 int64_t lddx, int32_t accumulate, int32_t tile, void* stream);
