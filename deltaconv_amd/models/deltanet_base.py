@@ -1,4 +1,6 @@
 """DeltaNet backbone (reference: deltaconv/models/deltanet_base.py:9-87)."""
+import os
+
 import torch
 
 from ..nn import DeltaConv
@@ -24,6 +26,38 @@ def _ptr_info(data):
     except Exception:
         pass
     return info
+
+
+# Lab switch, OFF: structures only the BACKWARD pass reads -- the CSC of the graph, the transposed tile plan, the operators'
+# coefficients in tile order: five latency-bound launches, ~50 us at the ModelNet40 shape -- built on a side stream while the
+# forward pass runs (one fork after the operators exist, one join at the end of the backbone: a parallel branch of the captured
+# HIP graph).  Measured round 5, same box, graph-replayed C2 step: 3.07-3.08 ms lazily at the start of the backward pass (off),
+# 3.13-3.15 ms with the branch (DC_SIDE_STRUCTS=1): like the weight-gradient branch of round 4, a fork / join of the replayed
+# graph costs more than the overlapped 50 us (profiles/r05_labs.txt).
+SIDE_STRUCTS = [os.environ.get("DC_SIDE_STRUCTS", "0") == "1"]
+_SIDE = {}
+
+
+def _prefetch_backward_structures(graph, grad, div):
+    if not graph.nbr.is_cuda or graph._csc is not None:
+        return None
+    dev = graph.nbr.device
+    main = torch.cuda.current_stream(dev)
+    plan = graph.tile_plan()                 # the forward plan belongs to the main stream (its first user is a forward apply)
+    side = _SIDE.get(dev.index)
+    if side is None:
+        side = _SIDE[dev.index] = torch.cuda.Stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        made = list(graph.csc())
+        if plan is not None:
+            pt = graph.tile_plan_T()
+            if pt is not None:
+                made.append(pt.blob)
+                made.extend((grad.coefTt(), div.coefTt()))
+    for t in made:                           # allocated under the side stream, read by the main stream's backward kernels
+        t.record_stream(main)
+    return side
 
 
 class DeltaNetBase(torch.nn.Module):
@@ -81,6 +115,14 @@ class DeltaNetBase(torch.nn.Module):
         from ..nn import fused as _fused
         _fused.presplit_begin()      # bf16 planes of every weight the products have asked for: one launch per forward pass
         graph, grad, div = self.build_operators(data)
+        side = _prefetch_backward_structures(graph, grad, div) if (SIDE_STRUCTS[0] and torch.is_grad_enabled()) else None
+        try:
+            return self._forward_layers(data, graph, grad, div)
+        finally:
+            if side is not None:     # join: everything the backward pass needs is complete before the loss is formed
+                torch.cuda.current_stream().wait_stream(side)
+
+    def _forward_layers(self, data, graph, grad, div):
         x = data.x if hasattr(data, 'x') and data.x is not None else data.pos   # deltanet_base.py:76
         v = grad @ x                                                             # deltanet_base.py:78
         out = []
