@@ -5,7 +5,7 @@ from torch.nn import Sequential as Seq, Dropout, LeakyReLU
 from .deltanet_base import DeltaNetBase, _ptr_info
 from .pool import embed_and_pool, broadcast_to_points
 from ..nn import MLP, fused
-from ..nn.mlp import Linear
+from ..nn.mlp import Linear, run_head
 from ..nn.layer import cat_outputs
 
 
@@ -50,6 +50,6 @@ class DeltaNetSegmentation(torch.nn.Module):
             h = fused.linear(conv_cat, w[:, p:]).view(nc, mx, -1)
             h = (h + fused.linear(pooled, w[:, :p]).unsqueeze(1)).view(n, -1)
             y = fused.bn_act(h, blk[1].bn, fused.slope_of(blk[2]))
-            return self.segmentation_head[1:](y)
+            return run_head(list(self.segmentation_head)[1:], y)
         x_max = broadcast_to_points(pooled, batch, info, n)
-        return self.segmentation_head(torch.cat([x_max, conv_cat], dim=1))
+        return run_head(self.segmentation_head, torch.cat([x_max, conv_cat], dim=1))

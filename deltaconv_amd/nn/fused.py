@@ -879,6 +879,67 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+USE_BIAS_ACT = True     # A/B switch: False = ATen add / leaky_relu / column sum around the product (round 4)
+_CONST = {}
+
+
+def _const(c, dev, value):
+    """[c] fp32 constant vector on `dev` (ones / zeros: the identity BatchNorm map of the bias + activation form below)."""
+    key = (dev.index, c, value)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full((c,), value, dtype=torch.float32, device=dev)
+    return t
+
+
+class _LinearBiasAct(torch.autograd.Function):
+    """y = leaky_slope(x W^T + b) on many rows (slope 1 = plain Linear with bias): the segmentation head's
+    `Linear(256, 128) -> LeakyReLU(0.2) -> Linear(128, num_classes)` (deltaconv/models/deltanet_segmentation.py:45-51).
+    Bias + activation are ONE pass of the BatchNorm/activation kernel with the identity map (scale 1, shift b); the backward
+    pass takes d b and d h from its inference-mode backward (one ordered reduction + one pass) -- ATen ran add, leaky_relu,
+    leaky_relu_backward and a [R, C] -> [C] sum here (round 5)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        h = mm_nt(x, w)
+        r, c = h.shape
+        y = torch.empty_like(h)
+        lib.call("dc_bn_act", h, r, c, c, _const(c, h.device, 1.0), b, slope, None, 0, y, c)
+        ctx.save_for_backward(x, w, h if slope != 1.0 else None, b)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, h, b = ctx.saved_tensors
+        slope = ctx.slope
+        dy = _c(dy)
+        r, c = dy.shape
+        dev = dy.device
+        one, zero = _const(c, dev, 1.0), _const(c, dev, 0.0)
+        db = torch.empty(c, dtype=torch.float32, device=dev)
+        ws, nb = _ws(r, c, dev)
+        dh = torch.empty(r, c, dtype=torch.float32, device=dev)
+        # (slope 1: act' = 1 whatever h is -- dy itself stands in for the pre-activation that was not kept)
+        lib.call("dc_bn_act_backward", dy, c, h if h is not None else dy, c, r, c, one, b, zero, one, None, slope, 0, dh, c,
+                 None, db, ws, nb)
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
+            dw, dx = linear_grads(dh, x, w)
+        else:
+            dx = mm_nn(dh, w) if ctx.needs_input_grad[0] else None
+            dw = gemm_tn(dh, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[1] else None
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def linear_bias_act(x, w, b, slope=1.0):
+    """leaky_slope(x W^T + b) -- own kernels for 2-D fp32 GPU inputs with a bias, else torch."""
+    if (USE_BIAS_ACT and b is not None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32
+            and b.dtype == torch.float32 and slope >= 0 and not _rowblock_ok(x, w)):
+        return _LinearBiasAct.apply(_c(x), w, b, float(slope))
+    y = linear(x, w, b)
+    return y if slope == 1.0 else torch.nn.functional.leaky_relu(y, slope)
+
+
 # ---- blocks on a handful of rows (classification head: one row per cloud): csrc/rowblock.hip ------------------------
 ROWBLOCK_MAX_ROWS = 64
 USE_ROWBLOCK = True        # A/B switch: False = the composed path (library GEMM + statistics + finaliser + activation)
@@ -987,6 +1048,8 @@ def linear(x, w, b=None):
     if _rowblock_ok(x, w):
         return _RowLinear.apply(x, w, b)
     if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
+        if USE_BIAS_ACT and b is not None and b.dtype == torch.float32:
+            return _LinearBiasAct.apply(_c(x), w, b, 1.0)        # bias in the activation kernel's pass, d b from its reduction
         return _Linear.apply(x, w, b)
     return F.linear(x, w, b)
 

@@ -79,6 +79,24 @@ def run_mlp(mlp, x, residual=None):
     return out if residual is None else out + residual
 
 
+def run_head(modules, x):
+    """A head Sequential (or a slice of one) module by module, with `Linear(bias) -> LeakyReLU | ReLU` pairs run as one
+    fused call (deltaconv/models/deltanet_segmentation.py:45-51: Linear(256, 128), LeakyReLU(0.2), Linear(128, classes))."""
+    mods = list(modules)
+    i = 0
+    while i < len(mods):
+        mod = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        slope = fused.slope_of(nxt) if isinstance(nxt, (LeakyReLU, torch.nn.ReLU)) else None
+        if isinstance(mod, torch.nn.Linear) and mod.bias is not None and slope is not None and not getattr(nxt, "inplace", False):
+            x = fused.linear_bias_act(x, mod.weight, mod.bias, slope)
+            i += 2
+        else:
+            x = mod(x)
+            i += 1
+    return x
+
+
 class ScalarVectorMLP(torch.nn.Module):
     """mlp.py:19-39"""
 

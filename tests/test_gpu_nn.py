@@ -486,3 +486,32 @@ def test_rowblock_equals_composed_path_in_the_model():
         assert float((g1[n] - g0[n]).abs().max()) < 2e-5 * max(float(g0[n].abs().max()), 1e-3 * gmax), n
     for n in b0:
         assert rel_err(b1[n].float(), b0[n].float()) < 1e-5, n
+
+
+@pytest.mark.parametrize("rows,k,c,slope", [(4096, 256, 128, 0.2), (3000, 128, 50, 1.0), (513, 64, 7, 0.0)])
+def test_linear_bias_act_vs_torch(rows, k, c, slope):
+    """The segmentation head's Linear(bias) -> LeakyReLU pair and its plain Linear(bias) on many rows
+    (deltaconv/models/deltanet_segmentation.py:45-51): bias + activation in the BatchNorm/activation kernel's pass, d b from its
+    ordered reduction -- against torch in fp64, forward and every gradient."""
+    from deltaconv_amd.nn import fused
+    gen = torch.Generator().manual_seed(rows + c)
+    x = torch.randn(rows, k, generator=gen, dtype=torch.float64)
+    w = torch.randn(c, k, generator=gen, dtype=torch.float64) / k ** 0.5
+    b = torch.randn(c, generator=gen, dtype=torch.float64)
+    dy = torch.randn(rows, c, generator=gen, dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.linear(*leaves), slope) if slope != 1.0 else torch.nn.functional.linear(*leaves)
+    ref.backward(dy)
+    dl = [t.float().to(DEV).requires_grad_(True) for t in (x, w, b)]
+    out = fused.linear_bias_act(*dl, slope)
+    out.backward(dy.float().to(DEV))
+    assert rel_err(out, ref) < 1e-5
+    for got, want, name in zip(dl, leaves, "xwb"):
+        assert rel_err(got.grad, want.grad) < 1e-4, name
+    # and the module form: Linear with a bias runs the same kernels
+    import deltaconv_amd as dc
+    lin = dc.nn.mlp.Linear(k, c).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(w); lin.bias.copy_(b)
+    y = lin(x.float().to(DEV))
+    assert rel_err(y, torch.nn.functional.linear(x, w, b)) < 1e-5
