@@ -165,6 +165,77 @@ __device__ __forceinline__ void block_sums(float (*red)[2][CH], int wave, int q,
     }
 }
 
+// ---- BatchNorm-1 statistics of y1 = W1 (x_j - x_i) from the MOMENTS of the edge differences (ci <= 3) --------------------------
+// y1 is linear in d = x_j - x_i:  sum_e y1[c] = W1[c] . (sum_e d),  sum_e y1[c]^2 = W1[c]^T (sum_e d d^T) W1[c]  -- ci + ci (ci + 1) / 2
+// numbers (9 for positions) replace the gather pass over 64-channel rows of z = x W1^T (31 us at C4) and the product that makes z.
+// Per point the pass also keeps sd = sum_s d (ci floats): the closed forms of the backward pass need sum_s y1 = W1 sd.
+// Ordered fp64 reductions (block: fixed serial order over the 256 threads; final: serial over the blocks): bit-reproducible.
+constexpr int MOM_TPB = 256;
+template <int CI>
+__global__ __launch_bounds__(MOM_TPB) void edge2_moments_kernel(const float* __restrict__ x, long ldx, const int* __restrict__ nbr, long n,
+                                                                int k, float* __restrict__ sd, double* __restrict__ partial, int chunks) {
+    constexpr int NQ = CI + CI * (CI + 1) / 2;
+    __shared__ double sm[NQ][MOM_TPB];
+    const long p = (long)blockIdx.x * MOM_TPB + threadIdx.x;
+    double q[NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) q[a] = 0.0;
+    if (p < n) {
+        float xi[CI], acc[CI];
+#pragma unroll
+        for (int d = 0; d < CI; ++d) { xi[d] = x[p * ldx + d]; acc[d] = 0.f; }
+        const int* ids = nbr + p * k;
+        for (int s = 0; s < k; ++s) {
+            const long jn = ids[s];
+            float dl[CI];
+#pragma unroll
+            for (int d = 0; d < CI; ++d) { dl[d] = x[jn * ldx + d] - xi[d]; acc[d] += dl[d]; q[d] += (double)dl[d]; }
+            int o = CI;
+#pragma unroll
+            for (int a = 0; a < CI; ++a)
+#pragma unroll
+                for (int b = a; b < CI; ++b) q[o++] += (double)dl[a] * (double)dl[b];
+        }
+#pragma unroll
+        for (int d = 0; d < CI; ++d) sd[p * CI + d] = acc[d];
+    }
+#pragma unroll
+    for (int a = 0; a < NQ; ++a) sm[a][threadIdx.x] = q[a];
+    __syncthreads();
+    if (threadIdx.x < NQ) {
+        double t = 0.0;
+        for (int i = 0; i < MOM_TPB; ++i) t += sm[threadIdx.x][i];
+        partial[(long)threadIdx.x * chunks + blockIdx.x] = t;
+    }
+}
+// one workgroup of 64 threads: moments = ordered sums of the partials, then channel c: mean, invstd, scale, shift (+ running statistics)
+template <int CI>
+__global__ __launch_bounds__(CH) void edge2_bn1_kernel(const double* __restrict__ partial, int chunks, long E, const float* __restrict__ W1,
+                                                       BnFin fin) {
+    constexpr int NQ = CI + CI * (CI + 1) / 2;
+    __shared__ double mom[NQ];
+    if (threadIdx.x < NQ) {
+        double t = 0.0;
+        for (int b = 0; b < chunks; ++b) t += partial[(long)threadIdx.x * chunks + b];
+        mom[threadIdx.x] = t;
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    double w[CI];
+#pragma unroll
+    for (int d = 0; d < CI; ++d) w[d] = (double)W1[c * CI + d];
+    double s0 = 0.0, s1 = 0.0;
+    int o = CI;
+#pragma unroll
+    for (int a = 0; a < CI; ++a) {
+        s0 += w[a] * mom[a];
+#pragma unroll
+        for (int b = a; b < CI; ++b) s1 += (a == b ? 1.0 : 2.0) * w[a] * w[b] * mom[o++];
+    }
+    fin.R = E;
+    fin(c, s0, s1);          // s0 = sum_e y1, s1 = sum_e y1^2: the finaliser of every BatchNorm of the library (colreduce.h)
+}
+
 // ---- forward ---------------------------------------------------------------------------------------------------------
 template <int CI>
 __global__ __launch_bounds__(WPB * 64, 2) void edge2_fwd_kernel(const float* __restrict__ src, long ldsrc, const float* __restrict__ W1,
@@ -415,38 +486,75 @@ struct Bn2BwdF {
     }
 };
 
-// closing pass: thread = (target point, 4 channels); in-edges in ascending edge id (CSC order)
+// closing pass: thread = (target point, 4 channels); in-edges in ascending edge id (CSC order).  CI = 0: the mean / variance terms
+// from rows of z = x W1^T (T = sum_in z_src, s1 = sum_s (z_j - z_i)); CI = 1..3: from the ci input channels themselves --
+// indeg z_p - T_p = W1 (indeg x_p - sum_in x_src) and s1_p = W1 sd_p are linear in positions: 12 gathered bytes per in-edge
+// instead of a 256-byte row, and no z at all.
+template <int CI>
 __global__ __launch_bounds__(256) void edge2_scatter_kernel(long n, int k, int remap, const int* __restrict__ tptr,
                                                             const int* __restrict__ tedge, const float* __restrict__ dU,
-                                                            const float* __restrict__ z, const float* __restrict__ csum,
-                                                            const float* __restrict__ s1pt, const float* __restrict__ scale1,
-                                                            const float* __restrict__ mean1, const float* __restrict__ invstd1,
-                                                            const float* __restrict__ m1, const float* __restrict__ m2,
-                                                            int training, float* __restrict__ dz, long lddz) {
+                                                            const float* __restrict__ src, long ldsrc, const float* __restrict__ W1,
+                                                            const float* __restrict__ csum, const float* __restrict__ s1in,
+                                                            const float* __restrict__ scale1, const float* __restrict__ mean1,
+                                                            const float* __restrict__ invstd1, const float* __restrict__ m1,
+                                                            const float* __restrict__ m2, int training, float* __restrict__ dz,
+                                                            long lddz) {
     const long t = dc_xcd_block(remap) * 256 + threadIdx.x;
     if (t >= n * (CH / 4)) return;
     const long jp = t / (CH / 4);
     const int c0 = (int)(t % (CH / 4)) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, T = {0.f, 0.f, 0.f, 0.f};
+    float tx[CI > 0 ? CI : 1];
+#pragma unroll
+    for (int d = 0; d < (CI > 0 ? CI : 1); ++d) tx[d] = 0.f;
     const int p0 = tptr[jp], p1 = tptr[jp + 1];
     for (int e0 = p0; e0 < p1; ++e0) {
         const long e = tedge[e0];
         const long i = e / k;
-        const f32x4 d = ld4(dU + e * CH + c0), zi = ld4(z + i * CH + c0);
+        const f32x4 d = ld4(dU + e * CH + c0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[r] += d[r]; T[r] += zi[r]; }
+        for (int r = 0; r < 4; ++r) acc[r] += d[r];
+        if (training) {
+            if constexpr (CI == 0) {
+                const f32x4 zi = ld4(src + i * CH + c0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[r] += zi[r];
+            } else {
+#pragma unroll
+                for (int d2 = 0; d2 < CI; ++d2) tx[d2] += src[i * ldsrc + d2];
+            }
+        }
     }
     const float indeg = (float)(p1 - p0);
-    const f32x4 zj = ld4(z + jp * CH + c0), cs = ld4(csum + jp * CH + c0), s1 = ld4(s1pt + jp * CH + c0);
+    const f32x4 cs = ld4(csum + jp * CH + c0);
+    f32x4 diff = {0.f, 0.f, 0.f, 0.f};                 // (indeg z_p - T_p) - s1_p  per channel
+    if (training) {
+        if constexpr (CI == 0) {
+            const f32x4 zj = ld4(src + jp * CH + c0), s1 = ld4(s1in + jp * CH + c0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) diff[r] = (indeg * zj[r] - T[r]) - s1[r];
+        } else {
+            float v[CI];
+#pragma unroll
+            for (int d2 = 0; d2 < CI; ++d2) v[d2] = (indeg * src[jp * ldsrc + d2] - tx[d2]) - s1in[jp * CI + d2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = W1[(c0 + r) * CI] * v[0];
+#pragma unroll
+                for (int d2 = 1; d2 < CI; ++d2) a = fmaf(W1[(c0 + r) * CI + d2], v[d2], a);
+                diff[r] = a;
+            }
+        }
+    }
     f32x4 out;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = c0 + r;
         float g = acc[r] - cs[r];
         if (training) {
-            const float col_hat = (indeg * zj[r] - T[r] - indeg * mean1[c]) * invstd1[c];
-            const float row_hat = (s1[r] - (float)k * mean1[c]) * invstd1[c];
-            g -= m1[c] * (indeg - (float)k) + m2[c] * (col_hat - row_hat);
+            // col_hat - row_hat = invstd [ (indeg z_p - T_p - indeg mu) - (s1_p - k mu) ]
+            const float hat = (diff[r] - (indeg - (float)k) * mean1[c]) * invstd1[c];
+            g -= m1[c] * (indeg - (float)k) + m2[c] * hat;
         }
         out[r] = scale1[c] * g;
     }
@@ -468,6 +576,36 @@ DC_EXPORT size_t dc_edge2_workspace_bytes(int32_t n, int32_t k, int32_t backward
     return b;
 }
 
+// BatchNorm-1 of the edge MLP from the moments of the edge differences (ci <= 3): sd [n, ci] = sum_s (x_j - x_i) per point (the
+// backward pass's closed forms need it) and mean1 / invstd1 / scale1 / shift1 [64] (+ running statistics) of y1 = W1 (x_j - x_i) over
+// all n k edges -- what dc_edge_gather_stats computes from rows of z = x W1^T, without z.  Workspace: dc_edge2_workspace_bytes.
+DC_EXPORT int dc_edge2_bn1_stats(const float* x, int64_t ldx, int32_t ci, const float* W1, const int32_t* nbr, int32_t n, int32_t k,
+                                 const float* gamma1, const float* beta1, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* sd, float* mean1, float* invstd1, float* scale1, float* shift1,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(x && W1 && nbr && sd && mean1 && invstd1 && scale1 && shift1, "dc_edge2_bn1_stats: null pointer");
+    DC_REQUIRE(n >= 1 && k >= 1 && ci >= 1 && ci <= 3 && ldx >= ci, "dc_edge2_bn1_stats: bad size (ci <= 3)");
+    const int chunks = dc_cdiv(n, MOM_TPB);
+    if (!workspace || workspace_bytes < (size_t)chunks * 9 * sizeof(double)) {
+        dc_set_error("dc_edge2_bn1_stats: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* partial = static_cast<double*>(workspace);
+    const BnFin fin{(long)n * k, gamma1, beta1, eps, momentum, running_mean, running_var, mean1, invstd1, scale1, shift1};
+#define DC_EDGE2_MOM(CI)                                                                                                      \
+    do {                                                                                                                        \
+        hipLaunchKernelGGL(edge2_moments_kernel<CI>, dim3(chunks), dim3(MOM_TPB), 0, s, x, (long)ldx, nbr, (long)n, k, sd, partial, chunks); \
+        hipLaunchKernelGGL(edge2_bn1_kernel<CI>, dim3(1), dim3(CH), 0, s, partial, chunks, (long)n * k, W1, fin);               \
+    } while (0)
+    if (ci == 1) DC_EDGE2_MOM(1);
+    else if (ci == 2) DC_EDGE2_MOM(2);
+    else DC_EDGE2_MOM(3);
+#undef DC_EDGE2_MOM
+    DC_CHECK_LAUNCH("dc_edge2_bn1_stats");
+    return DC_OK;
+}
+
 // Forward: z [n, 64] contiguous (= x W1^T); x [n, ci] (row stride ldx) and W1 [64, ci]: when given and ci <= 3 the kernels
 // evaluate y1 = W1 (x_j - x_i) per edge (the reference's order of operations) instead of z_j - z_i; scale1 / shift1 = BatchNorm-1 as an affine map (batch statistics of z_j - z_i from
 // dc_edge_gather_stats, or the running ones), W2 [64, 64].  Outputs ysel [n, 64] = the selected pre-BatchNorm-2 value per
@@ -481,9 +619,10 @@ DC_EXPORT int dc_edge2_forward(const float* z, const float* x, int64_t ldx, int3
                                float eps, float momentum, float* running_mean, float* running_var, float* ysel, uint8_t* arg,
                                float* mean2, float* invstd2, float* scale2, float* shift2, double* sums, void* workspace,
                                size_t workspace_bytes, void* stream) {
-    DC_REQUIRE(z && nbr && W2 && scale1 && shift1 && ysel && arg, "dc_edge2_forward: null pointer");
+    DC_REQUIRE(nbr && W2 && scale1 && shift1 && ysel && arg, "dc_edge2_forward: null pointer");
+    DC_REQUIRE(z || (x && W1 && ci >= 1 && ci <= 3 && ldx >= ci), "dc_edge2_forward: z may only be NULL with x, W1 and ci <= 3");
     DC_REQUIRE(n >= 1 && k >= 1 && k <= 255, "dc_edge2_forward: bad size");
-    DC_REQUIRE(al16(z) && al16(W2) && al16(ysel) && (reinterpret_cast<uintptr_t>(arg) & 3) == 0, "dc_edge2_forward: misaligned");
+    DC_REQUIRE((!z || al16(z)) && al16(W2) && al16(ysel) && (reinterpret_cast<uintptr_t>(arg) & 3) == 0, "dc_edge2_forward: misaligned");
     DC_REQUIRE(stats_mode != 1 || (mean2 && invstd2 && scale2 && shift2), "dc_edge2_forward: null pointer");
     DC_REQUIRE(stats_mode != 2 || sums, "dc_edge2_forward: null pointer");
     if (stats_mode && (!workspace || workspace_bytes < dc_edge2_workspace_bytes(n, k, 0))) {
@@ -525,10 +664,11 @@ DC_EXPORT int dc_edge2_backward(const float* dout, int64_t lddo, const float* z,
                                 int32_t training2, const float* ysel, const uint8_t* arg, const float* s1pt, float* dz,
                                 int64_t lddz, float* dW2, float* dgamma1, float* dbeta1, float* dgamma2, float* dbeta2,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-    DC_REQUIRE(dout && z && nbr && tptr && tedge && W2 && coef1 && coef2 && ysel && arg && s1pt && dz && dW2,
-               "dc_edge2_backward: null pointer");
+    DC_REQUIRE(dout && nbr && tptr && tedge && W2 && coef1 && coef2 && ysel && arg && dz && dW2, "dc_edge2_backward: null pointer");
+    DC_REQUIRE(z || (x && W1 && ci >= 1 && ci <= 3 && ldx >= ci), "dc_edge2_backward: z may only be NULL with x, W1 and ci <= 3");
+    DC_REQUIRE(s1pt || !training1, "dc_edge2_backward: the batch-statistics backward needs s1pt");
     DC_REQUIRE(n >= 1 && k >= 1 && k <= 255 && lddo >= CH && lddz >= CH && lddo % 4 == 0 && lddz % 4 == 0, "dc_edge2_backward: bad size");
-    DC_REQUIRE(al16(dout) && al16(z) && al16(W2) && al16(ysel) && al16(s1pt) && al16(dz) && (reinterpret_cast<uintptr_t>(arg) & 3) == 0,
+    DC_REQUIRE(al16(dout) && (!z || al16(z)) && al16(W2) && al16(ysel) && al16(dz) && (reinterpret_cast<uintptr_t>(arg) & 3) == 0,
                "dc_edge2_backward: misaligned");
     if (!workspace || workspace_bytes < dc_edge2_workspace_bytes(n, k, 1)) {
         dc_set_error("dc_edge2_backward: workspace too small");
@@ -578,8 +718,17 @@ DC_EXPORT int dc_edge2_backward(const float* dout, int64_t lddo, const float* z,
     hipLaunchKernelGGL(edge2_dw_reduce_kernel, dim3(CH * CH / 16), dim3(256), 0, s, dWpart, chunks, dW2);
     // 4. the closing pass (overwrites dz = the d z2 buffer: the recompute pass has consumed it)
     const long total = (long)n * (CH / 4);
-    hipLaunchKernelGGL(edge2_scatter_kernel, dim3(dc_cdiv(total, 256)), dim3(256), 0, s, (long)n, k, remap, tptr, tedge, dU, z, csum,
-                       s1pt, scale1, mean1, invstd1, m12, m12 + CH, training1, dz, (long)lddz);
+#define DC_EDGE2_SCATTER(CI, SRC, LD)                                                                                          \
+    hipLaunchKernelGGL(edge2_scatter_kernel<CI>, dim3(dc_cdiv(total, 256)), dim3(256), 0, s, (long)n, k, remap, tptr, tedge, dU, SRC, \
+                       (long)(LD), W1, csum, s1pt, scale1, mean1, invstd1, m12, m12 + CH, training1, dz, (long)lddz)
+    if (z) {                 // rows of z given: the closed forms from them (s1pt = sum_s (z_j - z_i), [n, 64])
+        DC_REQUIRE(!training1 || al16(s1pt), "dc_edge2_backward: misaligned");
+        DC_EDGE2_SCATTER(0, z, CH);
+    } else if (ci == 1)      // no z: from the input channels (s1pt = sd = sum_s (x_j - x_i), [n, ci]: dc_edge2_bn1_stats)
+        DC_EDGE2_SCATTER(1, x, ldx);
+    else if (ci == 2) DC_EDGE2_SCATTER(2, x, ldx);
+    else DC_EDGE2_SCATTER(3, x, ldx);
+#undef DC_EDGE2_SCATTER
     DC_CHECK_LAUNCH("dc_edge2_backward");
     return DC_OK;
 }

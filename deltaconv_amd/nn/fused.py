@@ -398,46 +398,59 @@ def seg_reduce(h, n, k, aggr):
 
 
 USE_EDGE2 = True    # A/B switch: False = the materialised [E, C] path for the depth-2 centralised edge MLP
+EDGE2_DIRECT = True # A/B switch: False = BatchNorm-1 statistics and closed forms through rows of z = x W1^T even for ci <= 3
 EDGE2_CH = 64       # csrc/edge2.hip is specialised to 64 channels in both blocks (the part-segmentation net's first layer)
 
 
 class _EdgeMLP2(torch.autograd.Function):
     """x_max[i] = max_s act2(bn2(W2 act1(bn1(W1 (x_j - x_i))))) -- the depth-2 centralised edge MLP of the first layer
     (deltaconv/nn/deltaconv.py:50-52 with mlp_depth = 2) on csrc/edge2.hip: no [E, C] tensor in the forward pass, one
-    recompute pass + a CSC closing pass backward.  Bit-reproducible."""
+    recompute pass + a CSC closing pass backward.  Bit-reproducible.  ci <= 3 (positions): everything from the input channels
+    themselves -- no z = x W1^T at all, BatchNorm-1 from the moments of the edge differences; otherwise through rows of z."""
 
     @staticmethod
     def forward(ctx, x, graph, W1, g1, b1, W2, g2, b2, mode1, mode2, slope1, slope2):
         # mode = (use_batch_stats, momentum, running_mean, running_var, eps)
         n, k, dev, c = graph.n, graph.k, x.device, EDGE2_CH
+        ci = x.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
-        z = mm_nt(x, W1)                                           # [n, 64]: W1 (x_j - x_i) = z_j - z_i
         use1, mom1, rm1, rv1, eps1 = mode1
         use2, mom2, rm2, rv2, eps2 = mode2
-        stat = torch.empty(3, n, c, **f32)                        # amax, amin (unused here), s1pt
-        args = torch.empty(2, n, c, dtype=torch.uint8, device=dev)
+        direct = ci <= 3 and EDGE2_DIRECT
+        nb2 = lib.raw("dc_edge2_workspace_bytes")(n, k, 0)
+        ws2 = torch.empty((nb2 + 7) // 8, dtype=torch.float64, device=dev)
         coef1 = torch.empty(4, c, **f32) if use1 else eval_coeffs(g1, b1, rm1, rv1, eps1, c)
-        ws, nb = _ws(n, c, dev)
-        lib.call("dc_edge_gather_stats", z, c, graph.nbr, n, k, c, int(use1), g1, b1, eps1, mom1, rm1 if use1 else None,
-                 rv1 if use1 else None, stat[0], stat[1], args[0], args[1], stat[2], coef1[0], coef1[1], coef1[2], coef1[3],
-                 ws, nb)
+        z = s1 = None
+        if direct:
+            if use1:                                               # BatchNorm-1 from the moments of x_j - x_i
+                s1 = torch.empty(n, ci, **f32)
+                lib.call("dc_edge2_bn1_stats", x, x.stride(0), ci, W1, graph.nbr, n, k, g1, b1, eps1, mom1, rm1, rv1, s1, coef1[0],
+                         coef1[1], coef1[2], coef1[3], ws2, nb2)
+        else:
+            z = mm_nt(x, W1)                                       # [n, 64]: W1 (x_j - x_i) = z_j - z_i
+            stat = torch.empty(3, n, c, **f32)                     # amax, amin (unused here), s1pt
+            args = torch.empty(2, n, c, dtype=torch.uint8, device=dev)
+            ws, nb = _ws(n, c, dev)
+            lib.call("dc_edge_gather_stats", z, c, graph.nbr, n, k, c, int(use1), g1, b1, eps1, mom1, rm1 if use1 else None,
+                     rv1 if use1 else None, stat[0], stat[1], args[0], args[1], stat[2], coef1[0], coef1[1], coef1[2], coef1[3],
+                     ws, nb)
+            s1 = stat[2]
         coef2 = torch.empty(4, c, **f32) if use2 else eval_coeffs(g2, b2, rm2, rv2, eps2, c)
         ysel = torch.empty(n, c, **f32)
         arg = torch.empty(n, c, dtype=torch.uint8, device=dev)
-        nb2 = lib.raw("dc_edge2_workspace_bytes")(n, k, 0)
-        ws2 = torch.empty((nb2 + 7) // 8, dtype=torch.float64, device=dev)
-        lib.call("dc_edge2_forward", z, x, x.stride(0), x.shape[1], W1, graph.nbr, n, k, W2, coef1[2], coef1[3], slope1, int(use2), g2, b2, eps2, mom2,
-                 rm2 if use2 else None, rv2 if use2 else None, ysel, arg, coef2[0], coef2[1], coef2[2], coef2[3], None, ws2, nb2)
+        lib.call("dc_edge2_forward", z, x, x.stride(0), ci, W1, graph.nbr, n, k, W2, coef1[2], coef1[3], slope1, int(use2), g2, b2,
+                 eps2, mom2, rm2 if use2 else None, rv2 if use2 else None, ysel, arg, coef2[0], coef2[1], coef2[2], coef2[3], None,
+                 ws2, nb2)
         out = torch.empty(n, c, **f32)
         lib.call("dc_bn_act", ysel, n, c, c, coef2[2], coef2[3], slope2, None, 0, out, c)
-        ctx.save_for_backward(x, z, stat[2], coef1, coef2, ysel, arg, W1, W2, g2)
+        ctx.save_for_backward(x, z, s1, coef1, coef2, ysel, arg, W1, W2, g2)
         ctx.graph, ctx.cfg = graph, (use1, use2, slope1, slope2, g1 is not None, b1 is not None, g2 is not None, b2 is not None)
         ctx.mark_non_differentiable(arg)
         return out, arg
 
     @staticmethod
     def backward(ctx, dout, _darg):
-        x, z, s1pt, coef1, coef2, ysel, arg, W1, W2, g2 = ctx.saved_tensors
+        x, z, s1, coef1, coef2, ysel, arg, W1, W2, g2 = ctx.saved_tensors
         use1, use2, slope1, slope2, hg1, hb1, hg2, hb2 = ctx.cfg
         g = ctx.graph
         n, k, dev, c = g.n, g.k, x.device, EDGE2_CH
@@ -449,8 +462,8 @@ class _EdgeMLP2(torch.autograd.Function):
         dg1, db1, dg2, db2 = (torch.empty(c, **f32) for _ in range(4))
         nb = lib.raw("dc_edge2_workspace_bytes")(n, k, 1)
         ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
-        lib.call("dc_edge2_backward", dout, c, z, x, x.stride(0), x.shape[1], W1, g.nbr, tptr, tedge, n, k, W2, coef1, coef2, g2, slope1, slope2, int(use1),
-                 int(use2), ysel, arg, s1pt, dz, c, dW2, dg1, db1, dg2, db2, ws, nb)
+        lib.call("dc_edge2_backward", dout, c, z, x, x.stride(0), x.shape[1], W1, g.nbr, tptr, tedge, n, k, W2, coef1, coef2, g2,
+                 slope1, slope2, int(use1), int(use2), ysel, arg, s1, dz, c, dW2, dg1, db1, dg2, db2, ws, nb)
         dW1 = gemm_tn(dz, x if x.stride(1) == 1 else x.contiguous()) if ctx.needs_input_grad[2] else None
         dx = mm_nn(dz, W1) if ctx.needs_input_grad[0] else None
         return (dx, None, dW1, dg1 if hg1 else None, db1 if hb1 else None, dW2, dg2 if hg2 else None, db2 if hb2 else None,

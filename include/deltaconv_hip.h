@@ -320,6 +320,14 @@ int dc_seg_reduce_backward(const float* dout, int64_t lddo, const uint8_t* arg, 
  * rows (4 x 64).  x [n, ci] / W1 [64, ci] (may be NULL): for ci <= 3 the edge pre-activation is evaluated as W1 (x_j - x_i)
  * per edge, the reference's own order of operations, instead of z_j - z_i.  Workspace: dc_edge2_workspace_bytes(n, k, backward). */
 size_t dc_edge2_workspace_bytes(int32_t n, int32_t k, int32_t backward);
+/* BatchNorm-1 of that block for ci <= 3 WITHOUT z: y1 = W1 (x_j - x_i) is linear in the edge difference, so its batch statistics
+ * follow from the ci + ci (ci + 1) / 2 first and second moments of the differences (ordered fp64 sums); sd [n, ci] = sum_s
+ * (x_j - x_i) per point feeds the closed forms of the backward pass.  With it dc_edge2_forward / dc_edge2_backward take z = NULL
+ * and `s1pt` = sd. */
+int dc_edge2_bn1_stats(const float* x, int64_t ldx, int32_t ci, const float* W1, const int32_t* nbr, int32_t n, int32_t k,
+                       const float* gamma1, const float* beta1, float eps, float momentum, float* running_mean,
+                       float* running_var, float* sd, float* mean1, float* invstd1, float* scale1, float* shift1,
+                       void* workspace, size_t workspace_bytes, void* stream);
 int dc_edge2_forward(const float* z, const float* x, int64_t ldx, int32_t ci, const float* W1, const int32_t* nbr,
                      int32_t n, int32_t k, const float* W2, const float* scale1,
                      const float* shift1, float slope1, int32_t stats_mode, const float* gamma2, const float* beta2,

@@ -41,7 +41,7 @@ def _setup(sizes, k, ci, seed):
     graph = dc.geometry.Graph.knn(b.pos, k, b.batch)
     gen = torch.Generator().manual_seed(seed)
     rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
-    x = b.pos.double().cpu() if ci == 3 else torch.cat([b.pos.double().cpu(), rnd(graph.n, ci - 3)], 1)
+    x = b.pos.double().cpu()[:, :ci].contiguous() if ci <= 3 else torch.cat([b.pos.double().cpu(), rnd(graph.n, ci - 3)], 1)
     c = 64
     W1, W2 = rnd(c, ci) * 0.7, rnd(c, c) * 0.25
     g1, b1 = rnd(c), rnd(c) * 0.3                      # both signs of gamma: max AND min selections
@@ -69,11 +69,19 @@ def _run(graph, x, mlp):
     return xd, out, slots
 
 
-@pytest.mark.parametrize("sizes,k,ci", [([400, 256, 300], 20, 3), ([2048, 2048], 20, 3), ([130], 7, 6), ([512, 77], 30, 3)])
-def test_edge2_train_vs_fp64_composed(sizes, k, ci):
+@pytest.mark.parametrize("moments", [True, False])
+@pytest.mark.parametrize("sizes,k,ci", [([400, 256, 300], 20, 3), ([2048, 2048], 20, 3), ([130], 7, 6), ([512, 77], 30, 3), ([333], 12, 2)])
+def test_edge2_train_vs_fp64_composed(sizes, k, ci, moments):
+    """moments: BatchNorm-1 statistics and the closed forms of the backward pass from the input channels themselves (ci <= 3: no
+    z = x W1^T at all) or through rows of z (the form of any ci)."""
+    from deltaconv_amd.nn import fused
     graph, x, params = _setup(sizes, k, ci, seed=11)
     mlp = _modules(params, True)
-    xd, out, slots = _run(graph, x, mlp)
+    fused.EDGE2_DIRECT = moments
+    try:
+        xd, out, slots = _run(graph, x, mlp)
+    finally:
+        fused.EDGE2_DIRECT = True
     nbr = graph.nbr.cpu().long()
     leaves = [t.clone().requires_grad_(True) for t in (x, *params)]
     ref, h2, (y1, y2) = composed64(leaves[0], nbr, *leaves[1:], 0.2, 0.2, slots=slots.cpu())
@@ -83,7 +91,11 @@ def test_edge2_train_vs_fp64_composed(sizes, k, ci):
     gen = torch.Generator().manual_seed(3)
     dout = torch.randn(ref.shape, generator=gen, dtype=torch.float64)
     ref.backward(dout)
-    out.backward(dout.float().to(DEV))
+    fused.EDGE2_DIRECT = moments
+    try:
+        out.backward(dout.float().to(DEV))
+    finally:
+        fused.EDGE2_DIRECT = True
     names = ("x", "W1", "g1", "b1", "W2", "g2", "b2")
     got = (xd.grad, mlp[0][0].weight.grad, mlp[0][1].bn.weight.grad, mlp[0][1].bn.bias.grad, mlp[1][0].weight.grad,
            mlp[1][1].bn.weight.grad, mlp[1][1].bn.bias.grad)
