@@ -53,27 +53,39 @@ class Batch:
         return Batch(self.pos[lo:hi], self.batch[lo:hi] - rank * per, cut(self.norm), cut(self.x), y, cat, per)
 
 
-def _surface(n, gen):
+def _surface(n, gen, m=3, l=2, a=0.25):
+    """n points on the closed surface r = 1 + a sin(m theta) cos(l phi) with its analytic normals; (m, l, a) = the shape family."""
     d = torch.randn(n, 3, generator=gen, dtype=torch.float64)
     d = d / d.norm(dim=1, keepdim=True)
     theta = torch.acos(d[:, 2].clamp(-1, 1))
     phi = torch.atan2(d[:, 1], d[:, 0])
-    r = 1 + 0.25 * torch.sin(3 * theta) * torch.cos(2 * phi)
+    r = 1 + a * torch.sin(m * theta) * torch.cos(l * phi)
     p = d * r[:, None]
     # normal of the implicit surface F(p) = |p| - r(theta(p), phi(p)) via autograd
     q = p.clone().requires_grad_(True)
     rad = q.norm(dim=1)
     th = torch.acos((q[:, 2] / rad).clamp(-1 + 1e-12, 1 - 1e-12))
     ph = torch.atan2(q[:, 1], q[:, 0])
-    F = rad - (1 + 0.25 * torch.sin(3 * th) * torch.cos(2 * ph))
+    F = rad - (1 + a * torch.sin(m * th) * torch.cos(l * ph))
     (g,) = torch.autograd.grad(F.sum(), q)
     nrm = g / g.norm(dim=1, keepdim=True).clamp(1e-12)
     return p, nrm
 
 
-def synthetic_cloud(n, seed, normals=True, dup_frac=0.0, outlier_frac=0.0, jitter=0.0):
+def shape_family(cls):
+    """(m, l, a) of class `cls` of the learnable synthetic task (examples/train_modelnet_like.py): lobes in theta x lobes in phi."""
+    return 1 + cls % 5, 1 + (cls // 5) % 3, 0.25 + 0.05 * ((cls // 15) % 2)
+
+
+def synthetic_cloud(n, seed, normals=True, dup_frac=0.0, outlier_frac=0.0, jitter=0.0, family=None):
     gen = torch.Generator().manual_seed(int(seed))
-    p, nrm = _surface(n, gen)
+    if family is None:
+        p, nrm = _surface(n, gen)
+    else:       # a member of a shape family, randomly rotated (the label must not be readable off the axes)
+        p, nrm = _surface(n, gen, *family)
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=gen, dtype=torch.float64))
+        q = q * torch.sign(torch.linalg.det(q))
+        p, nrm = p @ q.t(), nrm @ q.t()
     if outlier_frac > 0:
         m = int(n * outlier_frac)
         p[:m] = torch.rand(m, 3, generator=gen, dtype=torch.float64) * 2.5 - 1.25
@@ -91,17 +103,21 @@ def synthetic_cloud(n, seed, normals=True, dup_frac=0.0, outlier_frac=0.0, jitte
 
 
 def synthetic_batch(num_clouds, n, seed=0, normals=True, num_classes=40, per_point_labels=False,
-                    categories=0, sizes=None, **kw):
-    """B clouds x N points (or ragged ``sizes``), labels ``randint``; seed = 1000*seed + cloud."""
+                    categories=0, sizes=None, learnable=False, **kw):
+    """B clouds x N points (or ragged ``sizes``), labels ``randint``; seed = 1000*seed + cloud.
+    learnable: the label of a cloud IS its shape family (``shape_family``), the cloud a randomly rotated member of it -- a task
+    a classifier can learn (the default, one surface with random labels, only measures throughput)."""
     sizes = [n] * num_clouds if sizes is None else list(sizes)
+    gen = torch.Generator().manual_seed(1000 * seed + 999)
+    ycls = torch.randint(0, num_classes, (len(sizes),), generator=gen) if learnable else None
     ps, ns, bs = [], [], []
     for c, m in enumerate(sizes):
-        p, nr = synthetic_cloud(m, 1000 * seed + c, normals, **kw)
+        fam = shape_family(int(ycls[c])) if learnable else None
+        p, nr = synthetic_cloud(m, 1000 * seed + c, normals, family=fam, **kw)
         ps.append(p); ns.append(nr); bs.append(torch.full((m,), c, dtype=torch.long))
-    gen = torch.Generator().manual_seed(1000 * seed + 999)
     pos = torch.cat(ps)
     ny = pos.shape[0] if per_point_labels else len(sizes)
-    y = torch.randint(0, num_classes, (ny,), generator=gen)
+    y = ycls if (learnable and not per_point_labels) else torch.randint(0, num_classes, (ny,), generator=gen)
     cat = None
     if categories:
         cat = torch.zeros(len(sizes), categories)

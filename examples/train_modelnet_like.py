@@ -27,11 +27,12 @@ from deltaconv_amd.dp import FlatGradDataParallel
 from deltaconv_amd.data import synthetic_batch
 
 
-def make_split(num_batches, batch_size, points, seed, device):
-    """Synthetic stand-in for the ModelNet40 loaders: the label is a function of the shape family."""
+def make_split(num_batches, batch_size, points, seed, device, num_classes=30):
+    """Synthetic stand-in for the ModelNet40 loaders: the label IS the shape family of the cloud (30 families of closed surfaces
+    r = 1 + a sin(m theta) cos(l phi), randomly rotated: deltaconv_amd.data.shape_family) -- a learnable task."""
     out = []
     for b in range(num_batches):
-        data = synthetic_batch(batch_size, points, seed=seed + b, num_classes=40)
+        data = synthetic_batch(batch_size, points, seed=seed + b, num_classes=num_classes, learnable=True)
         out.append(data.to(device))
     return out
 
@@ -90,7 +91,7 @@ def main():
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, args.epochs, eta_min=0.001)
     if args.data is None:
         train = make_split(args.train_batches, args.batch_size, args.num_points, 1000 * (rank + 1), dev)
-        test = make_split(2, args.batch_size, args.num_points, 777000, dev)
+        test = make_split(4, args.batch_size, args.num_points, 777000, dev)
     else:
         import deltaconv_amd.transforms as T
         from deltaconv_amd.datasets import Compose, DataLoader, ModelNet
