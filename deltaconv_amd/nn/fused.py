@@ -507,6 +507,11 @@ def edge_mlp2(x, graph, lin1, bn1, slope1, lin2, bn2, slope2):
 # (never during a graph capture: registration copies a table to the device); planes are used only when they were cut after
 # the last modification of the weight (version counter + step epoch), else the product splits in its K loop as before.
 USE_WEIGHT_PLANES = os.environ.get("DC_WEIGHT_PLANES", "1") != "0"
+# DC_WEIGHT_PLANES_CHECK=1 (advisor, round 4): cut the planes again in front of EVERY eager product -- the cache watches the tensor
+# version counter and the step epoch, which a write through `p.data` (manual EMA / clipping idioms) moves neither of; with this
+# switch stale planes are impossible (one extra tiny launch per product: a debugging mode, not a fast path).  The supported ways to
+# change a weight behind autograd's back stay `invalidate_planes()` after the write, or tracked in-place ops (`p.copy_`, optimizers).
+PLANES_ALWAYS_RECUT = os.environ.get("DC_WEIGHT_PLANES_CHECK", "0") == "1"
 _PL = {"entries": {}, "order": [], "table": None, "chunks": None, "n_chunks": 0, "epoch": 0, "dirty": False}
 
 
@@ -635,7 +640,7 @@ def _hint_planes(w, transposed):
         e["want_" + need] = True
         _PL["dirty"] = True                               # joins the one-launch table at the next presplit_begin()
         _split_one(e, base)
-    elif e["epoch"] != _PL["epoch"] or e["version"] != base._version:
+    elif e["epoch"] != _PL["epoch"] or e["version"] != base._version or (PLANES_ALWAYS_RECUT and not capturing):
         if capturing:
             return
         _split_one(e, base)

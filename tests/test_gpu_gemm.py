@@ -411,3 +411,87 @@ def test_presplit_planes_with_batchnorm_prologue(R, C, K):
         assert torch.equal(a, b)
     else:
         assert rel_err(b[:2048], ref) < 1.5 * rel_err(a[:2048], ref) + 1e-7
+
+
+def test_planes_after_a_write_through_data_and_the_check_switch():
+    """Advisor (round 4): a write through `p.data` moves neither the version counter nor the step epoch, so the plane cache cannot
+    see it.  Documented ways out: `invalidate_planes()` after the write, or DC_WEIGHT_PLANES_CHECK=1 (`PLANES_ALWAYS_RECUT`), which
+    cuts the planes in front of every eager product.  Both give the product of the NEW weight; the unguarded call is the negative
+    control (it multiplies with the planes of the old one: that is the hazard the switch exists for)."""
+    from deltaconv_amd.nn import fused
+    fused._planes_reset()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4096, 256, generator=g).to(DEV)
+    w = torch.nn.Parameter((torch.randn(128, 256, generator=g) / 16).to(DEV))
+    try:
+        with torch.no_grad():
+            y_old = fused.mm_nt(x, w).clone()            # registers the weight, cuts its planes
+            w.data.mul_(2.0)                             # behind autograd's back: no version bump
+            y_stale = fused.mm_nt(x, w).clone()
+            fused.invalidate_planes()
+            y_inval = fused.mm_nt(x, w).clone()
+            w.data.mul_(0.5)
+            fused.PLANES_ALWAYS_RECUT = True
+            y_check = fused.mm_nt(x, w).clone()
+    finally:
+        fused.PLANES_ALWAYS_RECUT = False
+        fused._planes_reset()
+    assert torch.equal(y_stale, y_old)                   # negative control: the cache did not notice the write
+    assert torch.equal(y_inval, 2.0 * y_old)             # (a power of two scales every plane exactly)
+    assert torch.equal(y_check, y_old)
+
+
+def test_graph_keeps_the_plane_tables_it_captured_alive():
+    """Advisor (round 4, medium): a captured step holds RAW addresses of the pre-split table, the chunk table and the plane buffers.
+    Registering another model's weights eagerly after the capture replaces the tables; without a holder the old tensors would go
+    back to the allocator and the next replay would read recycled memory.  GraphedTrainStep pins what it captured: capture,
+    register a second model (new tables), churn the allocator, replay -- the replays must equal the eager steps bit for bit."""
+    import deltaconv_amd as dc
+    from deltaconv_amd.data import synthetic_batch
+    from deltaconv_amd.graph_step import GraphedTrainStep
+    from deltaconv_amd.nn import fused
+    from deltaconv_amd.utils import calc_loss
+    fused._planes_reset()
+    torch.manual_seed(3)
+    b = synthetic_batch(2, 512, seed=11).to(DEV)
+
+    def fresh():
+        torch.manual_seed(5)
+        m = dc.models.DeltaNetClassification(3, 40, num_neighbors=20).to(DEV).train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.eval()
+        return m, torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+    try:
+        m1, o1 = fresh()
+        step = GraphedTrainStep(m1, calc_loss, b, optimizer=o1, warmup=2)
+        held = [t.data_ptr() for t in step._planes_keepalive]
+        assert held, "the captured step uses pre-split planes"
+        # a second model registers its weights: new tables, the first model's table objects are dropped by the cache
+        m2, _ = fresh()
+        calc_loss(m2(b), b.y).backward()
+        fused.presplit_begin()
+        junk = [torch.full((1 << 18,), float("nan"), device=DEV) for _ in range(64)]      # whatever was freed is overwritten
+        del junk
+        losses = [float(step()) for _ in range(3)]
+        # reference: the same three steps eagerly from the same state (2 warm-up updates + capture leaves weights untouched)
+        fused._planes_reset()
+        m3, o3 = fresh()
+        for _ in range(2):
+            for p in m3.parameters():
+                p.grad = None
+            calc_loss(m3(b), b.y).backward()
+            o3.step()
+        ref = []
+        for _ in range(3):
+            for p in m3.parameters():
+                p.grad = None
+            l = calc_loss(m3(b), b.y)
+            l.backward()
+            o3.step()
+            ref.append(float(l))
+    finally:
+        fused._planes_reset()
+    assert all(l == l for l in losses), losses                                 # no NaN from recycled memory
+    assert losses == ref, (losses, ref)
+    assert [t.data_ptr() for t in step._planes_keepalive] == held
