@@ -1,7 +1,8 @@
 """Fused blocks of the scalar / vector MLP stream: hand-written fp32-MFMA products (deltaconv_amd/csrc/gemm.hip, with
 the BatchNorm statistics in their epilogue and the BatchNorm backward in their operand loaders) + hand-written HIP
-BatchNorm / activation / vector non-linearity kernels (deltaconv_amd/csrc/nn.hip), each with its own backward.  Only
-per-cloud products (the 32-row classification head) go to the vendor library.
+BatchNorm / activation / vector non-linearity kernels (deltaconv_amd/csrc/nn.hip), each with its own backward; the centralised
+edge MLPs of the first layer (csrc/edge.hip, edge2.hip); blocks on a handful of rows (the classification head) on
+csrc/rowblock.hip.  No vendor-library GEMM is reachable for fp32 GPU inputs.
 
 Reference semantics: deltaconv/nn/mlp.py:7-17 and nn/nonlin.py:11-86 (Linear(no bias) ->
 BatchNorm1d over rows -> LeakyReLU(0.2);  Linear(no bias) -> VectorNonLin(BatchNorm1d))."""

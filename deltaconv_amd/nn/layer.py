@@ -20,8 +20,11 @@ owns its buffers:
 
 MLPs of any depth (reference default 1; the part-segmentation net uses 2, models/deltanet_segmentation.py:10): every
 block but the last of a stream is [GEMM + statistics epilogue -> BatchNorm/activation kernel], the last block carries
-the fusions above.  Only the edge MLP of a centralized first layer with depth > 1 stays outside (its BatchNorm runs
-over the [E, C] edge tensor between two products): its result enters the node as ``x_max``.
+the fusions above.  The edge MLP of a centralized first layer with depth > 1 (BatchNorm over the edges between two products) is
+computed in front of the node -- depth 2 x 64 channels on csrc/edge2.hip (chained fp32-MFMA products over the edges), other shapes
+through dc_edge_diff / dc_seg_reduce -- and enters it as ``x_max``; so does a depth-1 one under synchronised BatchNorm.
+Under synchronised BatchNorm (deltaconv_amd/dp.py) the node is unchanged: fused.linear_stats / bn_block_backward / _vn_backward
+all-reduce the fp64 sums their kernels hand out between a product and its finaliser.
 
 Dense GEMMs: hand-written fp32-MFMA kernels (csrc/gemm.hip forward + input gradient, the forward ones with the
 BatchNorm statistics of the block in their epilogue; csrc/gemm_tn.hip weight gradient).
