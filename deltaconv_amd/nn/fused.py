@@ -553,7 +553,15 @@ def presplit_begin():
             del ents[k]
         if dead or _PL["dirty"] or _PL["table"] is None:
             rows, starts, total = [], [0], 0
-            for e in ents.values():
+            cur_dev = torch.device("cuda", torch.cuda.current_device())
+            order = []
+            for key_, e in ents.items():
+                if e["dev"] != cur_dev:
+                    # (advisor, round 4) one table per launch, launched on the current device: weights that live on ANOTHER device
+                    # stay out of it -- their planes are cut on the spot at each use (_hint_planes -> _split_one), never through
+                    # cross-device pointers
+                    continue
+                order.append(key_)
                 n, k = e["n"], e["k"]
                 for need in ("fwd", "bwd"):
                     if e["want_" + need] and e[need] is None:
@@ -565,11 +573,10 @@ def presplit_begin():
             if not rows:
                 _PL.update(table=None, chunks=None, n_chunks=0, dirty=False)
                 return
-            dev = next(iter(ents.values()))["dev"]
-            _PL["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
-            _PL["chunks"] = torch.tensor(starts, dtype=torch.int32).to(dev)
+            _PL["table"] = torch.tensor(rows, dtype=torch.int64).to(cur_dev)
+            _PL["chunks"] = torch.tensor(starts, dtype=torch.int32).to(cur_dev)
             _PL["n_chunks"], _PL["dirty"] = total, False
-            _PL["order"] = list(ents.keys())
+            _PL["order"] = order
     if _PL["table"] is None:
         return
     if not capturing:        # nothing changed since the last cut (inference, repeated forward passes): the planes stand
