@@ -45,6 +45,8 @@ def parse(argv=None):
     ap.add_argument("--sync-bn", action="store_true",
                     help="BatchNorm statistics over the global batch (all-reduced fp64 sums); the data-parallel step is then ONE "
                          "graph with its collectives captured")
+    ap.add_argument("--spawn", action="store_true",
+                    help="go through the self-launcher even with --gpus 1 (exercises the path `--gpus N > 1` takes; tests/test_gpu_dist.py)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
     return ap.parse_args(argv)
@@ -350,12 +352,12 @@ def self_launch_command(args, argv, port=None):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
         # plain `python bench.py --gpus N`: spawn the N ranks ourselves; rank 0 of the child prints the one JSON line
         import subprocess
         env = dict(os.environ)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
-        sys.exit(subprocess.call(self_launch_command(args, argv), env=env))
+        sys.exit(subprocess.call(self_launch_command(args, [a for a in argv if a != "--spawn"]), env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
