@@ -621,7 +621,8 @@ DC_EXPORT int dc_edge2_bn1_stats(const float* x, int64_t ldx, int32_t ci, const 
 // evaluate y1 = W1 (x_j - x_i) per edge (the reference's order of operations) instead of z_j - z_i; scale1 / shift1 = BatchNorm-1 as an affine map (batch statistics of z_j - z_i from
 // dc_edge_gather_stats, or the running ones), W2 [64, 64].  Outputs ysel [n, 64] = the selected pre-BatchNorm-2 value per
 // (point, channel), arg uint8 [n, 64] its first slot.  stats_mode 1: BatchNorm-2 batch statistics over all n k edges ->
-// mean2 / invstd2 / scale2 / shift2 (+ running statistics); 2: only the fp64 sums [sum y2 | sum y2^2] -> sums[128]
+// mean2 / invstd2 / scale2 / shift2 (+ running statistics); 2: only the fp64 sums -> sums = double [2][2*64 + 1], two identical records
+// [sum y2 | sum y2^2 | n k] as every *_sums entry point writes them (258 doubles: the caller sizes the buffer for BOTH)
 // (synchronised BatchNorm: all-reduce, then dc_bn_coeffs_from_sums); 0: none (inference: coefficients from the running
 // statistics).  out = act2(scale2 ysel + shift2) is one dc_bn_act call of the caller.
 DC_EXPORT int dc_edge2_forward(const float* z, const float* x, int64_t ldx, int32_t ci, const float* W1, const int32_t* nbr,

@@ -87,6 +87,96 @@ __global__ __launch_bounds__(256) void mls_div_kernel(const float* __restrict__ 
     D[2 * e] = d[0]; D[2 * e + 1] = d[1];
 }
 
+// ---- the stages on their own: coords_projected, gaussian_weights, weighted_least_squares, fit_vector_mapping ----
+// The reference exports and tests them one by one (grad_div_mls.py:72,100,119,155; test_grad_div_mls.py:58-275);
+// the product path runs them fused (mls_fit / mls_div above) through the SAME dcmath:: functions.
+
+// coords_projected (:72-97): frame of edge e = frame[e / k] (the reference expands the frames k times by position),
+// positions by row / col.
+__global__ __launch_bounds__(256) void mls_coords_kernel(const float* __restrict__ pos, const float* __restrict__ normal,
+                                                         const float* __restrict__ xb, const float* __restrict__ yb,
+                                                         const int* __restrict__ row, const int* __restrict__ col,
+                                                         long num_edges, int k, float* __restrict__ coords) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= num_edges) return;
+    const long f = e / k;
+    dcmath::Frame fr{dcmath::ld3(pos + 3 * (long)row[e]), dcmath::ld3(normal + 3 * f), dcmath::ld3(xb + 3 * f),
+                     dcmath::ld3(yb + 3 * f)};
+    const dcmath::EdgeGeom g = dcmath::edge_geom(fr, dcmath::ld3(pos + 3 * (long)col[e]));
+    coords[2 * e] = (float)g.u;
+    coords[2 * e + 1] = (float)g.v;
+}
+
+// gaussian_weights, the cloud average (:112): mean over the cloud's points of the mean over a point's k distances
+__global__ __launch_bounds__(AVG_THREADS) void mls_avg_of_dist_kernel(const float* __restrict__ dist,
+                                                                      const int* __restrict__ cloud_ptr, int k,
+                                                                      double* __restrict__ avg) {
+    __shared__ double part[AVG_THREADS / 64];
+    const int cloud = blockIdx.x;
+    const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
+    double acc = 0;
+    for (int q = threadIdx.x; q < n; q += AVG_THREADS) {
+        const float* d = dist + (long)(begin + q) * k;
+        double s = 0;
+        for (int e = 0; e < k; ++e) s += (double)d[e];
+        acc += s / k;
+    }
+    acc = dc_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < AVG_THREADS / 64; ++w) t += part[w];
+        avg[cloud] = (n > 0) ? t / n : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(128) void mls_weights_kernel(const float* __restrict__ dist,
+                                                          const int* __restrict__ cloud_ptr, int k, double kernel_width,
+                                                          const double* __restrict__ avg, float* __restrict__ weights) {
+    const int cloud = blockIdx.y;
+    const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const long i = begin + q;
+    dcmath::gaussian_weights_point(dist + i * k, k, avg[cloud], kernel_width, weights + i * k);
+}
+
+// weighted_least_squares (:119-144): one point per thread
+__global__ __launch_bounds__(128) void mls_wls_kernel(const float* __restrict__ coords, const float* __restrict__ weights,
+                                                      int num_points, int k, double lambda, float* __restrict__ wls) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_points) return;
+    dcmath::wls_point(coords + i * k * 2, weights + i * k, k, lambda, wls + i * k * 6);
+}
+
+// fit_vector_mapping (:155-194): edges come in groups of k with one centre (row) per group; every thread forms its
+// group's six surface coefficients c = sum_s wls[s, :] * height_s (scatter_add over row, :165) in slot order
+__global__ __launch_bounds__(256) void mls_vmap_kernel(const float* __restrict__ pos, const float* __restrict__ normal,
+                                                       const float* __restrict__ xb, const float* __restrict__ yb,
+                                                       const int* __restrict__ row, const int* __restrict__ col,
+                                                       long num_edges, int k, const float* __restrict__ wls,
+                                                       const float* __restrict__ coords, float* __restrict__ out) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= num_edges) return;
+    const long g0 = e / k * k;
+    const long i = row[e];
+    const dcmath::Frame fi = dcmath::load_frame(pos, normal, xb, yb, i);
+    double c[6] = {0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < k; ++s) {
+        const dcmath::V3 d = dcmath::sub(dcmath::ld3(pos + 3 * (long)col[g0 + s]), fi.p);
+        const double h = dcmath::dot(fi.n, d);                        // patch_f (:163)
+#pragma unroll
+        for (int a = 0; a < 6; ++a) c[a] += (double)wls[(g0 + s) * 6 + a] * h;
+    }
+    const long j = col[e];
+    double m[4];
+    dcmath::vector_map(fi, c, (double)coords[2 * e], (double)coords[2 * e + 1], dcmath::ld3(xb + 3 * j),
+                       dcmath::ld3(yb + 3 * j), m);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) out[4 * e + a] = (float)m[a];
+}
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
@@ -161,4 +251,93 @@ DC_EXPORT int dc_mls_assemble_shape(const float* pos, const float* normal, const
     return mls_assemble("dc_mls_assemble_shape", pos, normal, x_basis, y_basis, nbr, cloud_ptr, num_clouds, num_points,
                         max_cloud_size, k, kernel_width, regularizer, true, shape_regularizer, normalized, G, D,
                         workspace, workspace_bytes, stream);
+}
+
+// ---- stage entry points (the reference's public helpers, grad_div_mls.py:72,100,119,155) ------------------------
+namespace {
+int launch_status(const char* name) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dc_set_error("%s: %s", name, hipGetErrorString(e));
+        return DC_ERR_LAUNCH;
+    }
+    return DC_OK;
+}
+}  // namespace
+
+DC_EXPORT int dc_mls_coords(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                            const int32_t* row, const int32_t* col, int64_t num_edges, int32_t k, float* coords,
+                            void* stream) {
+    if (num_edges < 0 || k < 1) {
+        dc_set_error("dc_mls_coords: bad size");
+        return DC_ERR_ARG;
+    }
+    if (num_edges == 0) return DC_OK;
+    if (!(pos && normal && x_basis && y_basis && row && col && coords)) {
+        dc_set_error("dc_mls_coords: null pointer");
+        return DC_ERR_ARG;
+    }
+    hipLaunchKernelGGL(mls_coords_kernel, dim3(dc_cdiv((long long)num_edges, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pos, normal, x_basis, y_basis, row, col, (long)num_edges, k,
+                       coords);
+    return launch_status("dc_mls_coords");
+}
+
+DC_EXPORT int dc_mls_gaussian_weights(const float* dist, const int32_t* cloud_ptr, int32_t num_clouds,
+                                      int32_t max_cloud_size, int32_t k, float kernel_width, float* weights,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (num_clouds < 0 || max_cloud_size < 0 || k < 1) {
+        dc_set_error("dc_mls_gaussian_weights: bad size");
+        return DC_ERR_ARG;
+    }
+    if (num_clouds == 0 || max_cloud_size == 0) return DC_OK;
+    if (!(dist && cloud_ptr && weights)) {
+        dc_set_error("dc_mls_gaussian_weights: null pointer");
+        return DC_ERR_ARG;
+    }
+    if (!workspace || workspace_bytes < (size_t)num_clouds * 8) {
+        dc_set_error("dc_mls_gaussian_weights: workspace too small (%zu < %zu)", workspace_bytes,
+                     (size_t)num_clouds * 8);
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* avg = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(mls_avg_of_dist_kernel, dim3(num_clouds), dim3(AVG_THREADS), 0, s, dist, cloud_ptr, k, avg);
+    hipLaunchKernelGGL(mls_weights_kernel, dim3(dc_cdiv(max_cloud_size, 128), num_clouds), dim3(128), 0, s, dist,
+                       cloud_ptr, k, (double)kernel_width, avg, weights);
+    return launch_status("dc_mls_gaussian_weights");
+}
+
+DC_EXPORT int dc_mls_wls(const float* coords, const float* weights, int32_t num_points, int32_t k, float regularizer,
+                         float* wls, void* stream) {
+    if (num_points < 0 || k < 1) {
+        dc_set_error("dc_mls_wls: bad size");
+        return DC_ERR_ARG;
+    }
+    if (num_points == 0) return DC_OK;
+    if (!(coords && weights && wls)) {
+        dc_set_error("dc_mls_wls: null pointer");
+        return DC_ERR_ARG;
+    }
+    hipLaunchKernelGGL(mls_wls_kernel, dim3(dc_cdiv(num_points, 128)), dim3(128), 0, static_cast<hipStream_t>(stream),
+                       coords, weights, num_points, k, (double)regularizer, wls);
+    return launch_status("dc_mls_wls");
+}
+
+DC_EXPORT int dc_mls_vector_mapping(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                                    const int32_t* row, const int32_t* col, int64_t num_edges, int32_t k,
+                                    const float* wls, const float* coords, float* mapping, void* stream) {
+    if (num_edges < 0 || k < 1 || num_edges % k != 0) {
+        dc_set_error("dc_mls_vector_mapping: bad size (edges come in groups of k)");
+        return DC_ERR_ARG;
+    }
+    if (num_edges == 0) return DC_OK;
+    if (!(pos && normal && x_basis && y_basis && row && col && wls && coords && mapping)) {
+        dc_set_error("dc_mls_vector_mapping: null pointer");
+        return DC_ERR_ARG;
+    }
+    hipLaunchKernelGGL(mls_vmap_kernel, dim3(dc_cdiv((long long)num_edges, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pos, normal, x_basis, y_basis, row, col, (long)num_edges, k,
+                       wls, coords, mapping);
+    return launch_status("dc_mls_vector_mapping");
 }

@@ -157,6 +157,109 @@ DC_HD double point_dist_sum(const float* pos, const int* nbr_i, long i, int k) {
     return s;
 }
 
+// polynomial basis row of one neighbour: triu of [1,u,v] (x) [1,u,v] (:133-137)
+DC_HD void poly_basis(double u, double v, double b[6]) {
+    b[0] = 1.0; b[1] = u; b[2] = v; b[3] = u * u; b[4] = u * v; b[5] = v * v;
+}
+
+// Cholesky M = L L^T of the symmetric positive definite 6x6 held in the UPPER triangle (diagonal included);
+// L lands in the strict lower triangle and on the diagonal (the upper triangle keeps M's off-diagonal entries).
+DC_HD void chol6_factor(double M[6][6]) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double s = M[j][j];
+#pragma unroll
+        for (int p = 0; p < j; ++p) s -= M[j][p] * M[j][p];
+        const double ljj = sqrt(fmax(s, 1e-300));
+        const double inv_l = 1.0 / ljj;
+#pragma unroll
+        for (int r = j + 1; r < 6; ++r) {
+            double t = M[j][r];
+#pragma unroll
+            for (int p = 0; p < j; ++p) t -= M[r][p] * M[j][p];
+            M[r][j] = t * inv_l;
+        }
+        M[j][j] = ljj;  // diagonal now holds L (M's diagonal is not needed any more)
+    }
+}
+
+// x <- (L L^T)^-1 x with the factor of chol6_factor: forward substitution L y = x, back substitution L^T x = y
+DC_HD void chol6_solve(const double M[6][6], double z[6]) {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        double t = z[r];
+#pragma unroll
+        for (int p = 0; p < r; ++p) t -= M[r][p] * z[p];
+        z[r] = t * (1.0 / M[r][r]);
+    }
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+        double t = z[r];
+#pragma unroll
+        for (int p = r + 1; p < 6; ++p) t -= M[p][r] * z[p];
+        z[r] = t * (1.0 / M[r][r]);
+    }
+}
+
+// gaussian_weights for the k edges of one point (:113-114): w = exp(-d^2 / (h avg)^2), normalised by the row sum
+// clamped at EPS.  `avg` = the cloud's mean edge length (:112).
+DC_HD void gaussian_weights_point(const float* dist_i, int k, double avg_dist, double kernel_width, float* w_out) {
+    const double inv_h2 = 1.0 / ((kernel_width * avg_dist) * (kernel_width * avg_dist));
+    double wsum = 0;
+    for (int e = 0; e < k; ++e) wsum += exp(-((double)dist_i[e] * (double)dist_i[e]) * inv_h2);
+    const double inv_w = 1.0 / fmax(wsum, (double)BASIS_EPS);
+    for (int e = 0; e < k; ++e) w_out[e] = (float)(exp(-((double)dist_i[e] * (double)dist_i[e]) * inv_h2) * inv_w);
+}
+
+// weighted_least_squares for one point (:119-144): wls[e,:] = w_e (B^T W B + lambda I)^-1 b_e -- the k columns of
+// (M^-1 B^T W), transposed.  Same normal equations, same factorisation as mls_fit_point (which keeps only rows 1, 2
+// of M^-1 and the product with the heights).
+DC_HD void wls_point(const float* coords_i, const float* w_i, int k, double lambda, float* wls_out) {
+    double M[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) M[a][b] = 0;
+    for (int e = 0; e < k; ++e) {
+        double b[6];
+        poly_basis((double)coords_i[2 * e], (double)coords_i[2 * e + 1], b);
+        const double w = (double)w_i[e];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double wb = w * b[a];
+#pragma unroll
+            for (int c = a; c < 6; ++c) M[a][c] += wb * b[c];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) M[a][a] += lambda;
+    chol6_factor(M);
+    for (int e = 0; e < k; ++e) {
+        double z[6];
+        poly_basis((double)coords_i[2 * e], (double)coords_i[2 * e + 1], z);
+        chol6_solve(M, z);
+        const double w = (double)w_i[e];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) wls_out[6 * e + a] = (float)(w * z[a]);
+    }
+}
+
+// fit_vector_mapping for one edge (:168-194, eq. 15 of the supplement): m = g^-1 T, the map from the frame at p_j to
+// the frame of p_i pushed forward along the fitted height field (coef = its six coefficients at p_i) to (u, v).
+DC_HD void vector_map(const Frame& fi, const double* coef, double u, double v, const V3& xj, const V3& yj,
+                      double m[4]) {
+    const double hu = coef[1] + 2 * coef[3] * u + coef[4] * v;      // (:168)
+    const double hv = coef[2] + coef[4] * u + 2 * coef[5] * v;      // (:169)
+    const V3 gam_u = axpy(hu, fi.n, fi.x);                          // (:173)
+    const V3 gam_v = axpy(hv, fi.n, fi.y);                          // (:175)
+    const double det = 1 + hu * hu + hv * hv;                       // (:179)
+    const double E = 1 + hu * hu, F = hu * hv, G = 1 + hv * hv;     // (:180)
+    const double t00 = dot(gam_u, xj), t01 = dot(gam_u, yj), t10 = dot(gam_v, xj), t11 = dot(gam_v, yj);
+    const double inv_det = 1.0 / det;
+    m[0] = (G * t00 - F * t10) * inv_det; m[1] = (G * t01 - F * t11) * inv_det;  // (:181-194)
+    m[2] = (-F * t00 + E * t10) * inv_det; m[3] = (-F * t01 + E * t11) * inv_det;
+}
+
 // Weighted least squares fit at one point (:100-152,163-165,253-259).
 //   g_out[k][2]  un-normalised gradient rows  (wls[e,1], wls[e,2])
 //   coef[6]      quadratic height-field coefficients c = sum_e wls[e,:] * height_e
@@ -207,84 +310,19 @@ DC_HD float mls_fit_point(const float* pos, const float* normal, const float* xb
             for (int b = a; b < 6; ++b) S[a][b] = M[a][b];
             S[a][a] += lambda_shape;
         }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {                       // Cholesky, as below
-            double d = S[j][j];
-#pragma unroll
-            for (int p = 0; p < j; ++p) d -= S[j][p] * S[j][p];
-            const double ljj = sqrt(fmax(d, 1e-300));
-            const double inv_l = 1.0 / ljj;
-#pragma unroll
-            for (int r = j + 1; r < 6; ++r) {
-                double t = S[j][r];
-#pragma unroll
-                for (int p = 0; p < j; ++p) t -= S[r][p] * S[j][p];
-                S[r][j] = t * inv_l;
-            }
-            S[j][j] = ljj;
-        }
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            double t = c[r];
-#pragma unroll
-            for (int p = 0; p < r; ++p) t -= S[r][p] * c[p];
-            c[r] = t / S[r][r];
-        }
-#pragma unroll
-        for (int r = 5; r >= 0; --r) {
-            double t = c[r];
-#pragma unroll
-            for (int p = r + 1; p < 6; ++p) t -= S[p][r] * c[p];
-            c[r] = t / S[r][r];
-        }
+        chol6_factor(S);
+        chol6_solve(S, c);
 #pragma unroll
         for (int a = 0; a < 6; ++a) coef[a] = c[a];
     }
 #pragma unroll
     for (int a = 0; a < 6; ++a) M[a][a] += lambda;  // B^T W B + lambda I (:141-143)
-    // Cholesky M = L L^T (L stored in the lower triangle of M; upper triangle holds M)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        double s = M[j][j];
-#pragma unroll
-        for (int p = 0; p < j; ++p) s -= M[j][p] * M[j][p];
-        const double ljj = sqrt(fmax(s, 1e-300));
-        const double inv_l = 1.0 / ljj;
-#pragma unroll
-        for (int r = j + 1; r < 6; ++r) {
-            double t = M[j][r];
-#pragma unroll
-            for (int p = 0; p < j; ++p) t -= M[r][p] * M[j][p];
-            M[r][j] = t * inv_l;
-        }
-        M[j][j] = ljj;  // diagonal now holds L (M's diagonal is not needed any more)
-    }
+    chol6_factor(M);
     // three right-hand sides: e1, e2 (rows 1,2 of M^-1 -> gradient) and rhs (surface coefficients)
     double z1[6] = {0, 1, 0, 0, 0, 0}, z2[6] = {0, 0, 1, 0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {  // forward substitution  L y = b
-        double t1 = z1[r], t2 = z2[r], t3 = rhs[r];
-#pragma unroll
-        for (int p = 0; p < r; ++p) {
-            t1 -= M[r][p] * z1[p];
-            t2 -= M[r][p] * z2[p];
-            t3 -= M[r][p] * rhs[p];
-        }
-        const double inv_l = 1.0 / M[r][r];
-        z1[r] = t1 * inv_l; z2[r] = t2 * inv_l; rhs[r] = t3 * inv_l;
-    }
-#pragma unroll
-    for (int r = 5; r >= 0; --r) {  // back substitution  L^T x = y
-        double t1 = z1[r], t2 = z2[r], t3 = rhs[r];
-#pragma unroll
-        for (int p = r + 1; p < 6; ++p) {
-            t1 -= M[p][r] * z1[p];
-            t2 -= M[p][r] * z2[p];
-            t3 -= M[p][r] * rhs[p];
-        }
-        const double inv_l = 1.0 / M[r][r];
-        z1[r] = t1 * inv_l; z2[r] = t2 * inv_l; rhs[r] = t3 * inv_l;
-    }
+    chol6_solve(M, z1);
+    chol6_solve(M, z2);
+    chol6_solve(M, rhs);
     if (!SHAPE) {
 #pragma unroll
         for (int a = 0; a < 6; ++a) coef[a] = rhs[a];
@@ -320,16 +358,9 @@ DC_HD void mls_div_edge(const Frame& fi, const double* coef, const V3& pj, const
         gv = (double)(g[1] / inf_norm);
     }
     const EdgeGeom e = edge_geom(fi, pj);
-    const double hu = coef[1] + 2 * coef[3] * e.u + coef[4] * e.v;  // (:168)
-    const double hv = coef[2] + coef[4] * e.u + 2 * coef[5] * e.v;  // (:169)
-    const V3 gam_u = axpy(hu, fi.n, fi.x);                          // (:173)
-    const V3 gam_v = axpy(hv, fi.n, fi.y);                          // (:175)
-    const double det = 1 + hu * hu + hv * hv;                       // (:179)
-    const double E = 1 + hu * hu, F = hu * hv, G = 1 + hv * hv;     // (:180)
-    const double t00 = dot(gam_u, xj), t01 = dot(gam_u, yj), t10 = dot(gam_v, xj), t11 = dot(gam_v, yj);
-    const double inv_det = 1.0 / det;
-    const double m00 = (G * t00 - F * t10) * inv_det, m01 = (G * t01 - F * t11) * inv_det;  // (:181-194)
-    const double m10 = (-F * t00 + E * t10) * inv_det, m11 = (-F * t01 + E * t11) * inv_det;
+    double m[4];
+    vector_map(fi, coef, e.u, e.v, xj, yj, m);
+    const double m00 = m[0], m01 = m[1], m10 = m[2], m11 = m[3];
     g[0] = (float)gu;
     g[1] = (float)gv;
     d_out[0] = (float)(gu * m00 + gv * m10);  // [g_u g_v] . map (:271-272)

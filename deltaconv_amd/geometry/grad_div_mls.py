@@ -104,6 +104,106 @@ def estimate_basis(pos, edge_index, k=None, orientation=None):
     return normal, xb, yb
 
 
+# ---- the stages of build_grad_div on their own: the reference exports and tests them one by one
+# (/root/reference/deltaconv/geometry/__init__.py:3, test/geometry/test_grad_div_mls.py:58-275).  Each is one
+# entry point of the C ABI running the device functions the fused kernels of dc_mls_assemble call
+# (csrc/point_math.h); the product path itself never materialises these tensors.
+def _rows_cols(edge_index):
+    """(row, col) of an [2, E] tensor, a (row, col) pair or a Graph as contiguous int32 device vectors."""
+    if isinstance(edge_index, Graph):
+        edge_index = edge_index.edge_index
+    row, col = edge_index
+    return row.to(torch.int32).contiguous(), col.to(torch.int32).contiguous()
+
+
+def _k_of(row, k):
+    # k = (row == 0).sum() (grad_div_mls.py:24,85,224); generalised to "edges of the first centre" so that the
+    # reference's own test graphs, whose centres are not point 0 .. N-1 (test_grad_div_mls.py:247-250), resolve
+    return int((row == row[0]).sum()) if k is None else int(k)
+
+
+def coords_projected(pos, normal, x_basis, y_basis, edge_index, k=None):
+    """grad_div_mls.py:72-97 -> coords [E, 2]: neighbours projected onto the tangent plane of their centre."""
+    require_gpu()
+    row, col = _rows_cols(edge_index)
+    if row.numel() == 0:
+        return pos.new_zeros(0, 2, dtype=torch.float32)
+    k = _k_of(row, k)
+    if row.numel() != normal.shape[0] * k:
+        raise ValueError(f"coords_projected: {row.numel()} edges for {normal.shape[0]} frames of k = {k} neighbours "
+                         "(the reference expands the frames k times by position, grad_div_mls.py:88-90)")
+    coords = torch.empty(row.numel(), 2, dtype=torch.float32, device=row.device)
+    lib.call("dc_mls_coords", pos.contiguous().float(), normal.contiguous().float(), x_basis.contiguous().float(),
+             y_basis.contiguous().float(), row, col, row.numel(), k, coords)
+    return coords
+
+
+def gaussian_weights(dist, k, batch=None, kernel_width=1):
+    """grad_div_mls.py:100-116 -> weights [N * k]: Gaussian of the edge length relative to kernel_width x the
+    cloud's mean edge length, normalised per neighbourhood.  `batch` must be sorted (clouds contiguous)."""
+    require_gpu()
+    k = int(k)
+    dist = dist.contiguous().float().reshape(-1)
+    n = dist.numel() // k
+    if dist.numel() != n * k:
+        raise ValueError(f"gaussian_weights: {dist.numel()} distances are not a multiple of k = {k}")
+    weights = torch.empty_like(dist)
+    if n == 0:
+        return weights
+    if batch is None:
+        ptr, num_clouds, max_cloud = torch.tensor([0, n], dtype=torch.int32, device=dist.device), 1, n
+    else:
+        if batch.numel() != n:
+            raise ValueError(f"gaussian_weights: batch holds {batch.numel()} points, dist {n}")
+        if bool((batch[1:] < batch[:-1]).any()):
+            raise ValueError("gaussian_weights: batch must be sorted (clouds contiguous)")
+        info = _ptr_from_batch(batch.to(dist.device), n, dist.device)
+        ptr, num_clouds, max_cloud = info[0], info[1], info[2]
+    ws = torch.empty(num_clouds, dtype=torch.float64, device=dist.device)
+    lib.call("dc_mls_gaussian_weights", dist, ptr, num_clouds, max_cloud, k, float(kernel_width), weights, ws,
+             ws.numel() * 8)
+    return weights
+
+
+def weighted_least_squares(coords, weights, k, regularizer, shape_regularizer=None):
+    """grad_div_mls.py:119-152 -> wls [N * k, 6] = ((B^T W B + regularizer I)^-1 B^T W)^T per point; with
+    shape_regularizer the pair (wls, wls_shape)."""
+    require_gpu()
+    k = int(k)
+    coords = coords.contiguous().float().reshape(-1, 2)
+    weights = weights.contiguous().float().reshape(-1)
+    n = weights.numel() // k
+    if weights.numel() != n * k or coords.shape[0] != n * k:
+        raise ValueError(f"weighted_least_squares: {coords.shape[0]} coords / {weights.numel()} weights for k = {k}")
+
+    def solve(lam):
+        wls = torch.empty(n * k, 6, dtype=torch.float32, device=coords.device)
+        lib.call("dc_mls_wls", coords, weights, n, k, float(lam), wls)
+        return wls
+
+    if shape_regularizer is not None:
+        return solve(regularizer), solve(shape_regularizer)
+    return solve(regularizer)
+
+
+def fit_vector_mapping(pos, normal, x_basis, y_basis, edge_index, wls, coords):
+    """grad_div_mls.py:155-194 -> [E, 2, 2]: the map between the frame at p_j and the frame of p_i pushed forward to
+    p_j (eq. 15 of the supplement).  Edges must be grouped by centre in runs of k (every graph the reference builds)."""
+    require_gpu()
+    row, col = _rows_cols(edge_index)
+    e = row.numel()
+    out = torch.empty(e, 2, 2, dtype=torch.float32, device=row.device)
+    if e == 0:
+        return out
+    k = _k_of(row, None)
+    if e % k != 0 or bool((row.view(-1, k) != row.view(-1, k)[:, :1]).any()):
+        raise ValueError("fit_vector_mapping: edges must come grouped by centre in runs of k = (row == row[0]).sum()")
+    lib.call("dc_mls_vector_mapping", pos.contiguous().float(), normal.contiguous().float(),
+             x_basis.contiguous().float(), y_basis.contiguous().float(), row, col, e, k,
+             wls.contiguous().float().reshape(-1, 6), coords.contiguous().float().reshape(-1, 2), out)
+    return out
+
+
 def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel_width=1, regularizer=0.001,
                    normalized=True, shape_regularizer=None):
     """grad_div_mls.py:197-277 -> (grad, div) as SparseOp."""

@@ -216,6 +216,8 @@ class Graph:
         e = edge_index.shape[1]
         k = e // num_points if k is None else int(k)
         assert k * num_points == e, "edge_index is not a fixed-degree centre-major kNN graph"
+        if k > 255:   # the aggregations keep the selected slot in one byte (advisor, round 5: say so here, not as a C-ABI error)
+            raise ValueError(f"graphs with k = {k} > 255 neighbours per point are not supported (uint8 slot of the aggregation)")
         nbr = edge_index[1].reshape(num_points, k).to(torch.int32).contiguous()
         ptr, nc, mx = ptr_info if ptr_info is not None else _ptr_from_batch(batch, num_points, edge_index.device)
         g = Graph(nbr, ptr, nc, mx)

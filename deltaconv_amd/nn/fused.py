@@ -62,6 +62,24 @@ def sync_group():
     return dp.sync_state()
 
 
+class BatchStats(int):
+    """The `use_batch_stats` flag of a block (truthy, int() == 1) that also remembers the data-parallel group its FORWARD
+    statistics were reduced over: the backward pass reduces over the same group whatever `dp.set_sync_bn` says by then
+    (advisor, round 5: a toggle between forward and backward gave global statistics forward and local means backward)."""
+
+    def __new__(cls, group):
+        self = int.__new__(cls, 1)
+        self.group = group
+        return self
+
+
+def group_of(use):
+    """Group of a block's forward statistics: carried by the flag (BatchStats), else the current state (plain True)."""
+    if not use:
+        return None
+    return use.group if isinstance(use, BatchStats) else sync_group()
+
+
 def _sync_stats(kernel_args, c, rows, dev, group):
     """Local fp64 sums via a dc_*_sums entry point -> all-reduced over `group`.  The kernels write TWO identical records
     [sum_0 | sum_1 | rows] (csrc/colreduce.h: SumsFin): the first is all-reduced in place, the second stays this rank's own --
@@ -659,13 +677,20 @@ def _hint_planes(w, transposed):
     lib.raw("dc_gemm_next_b_planes")(w.data_ptr(), e[need].data_ptr(), n * k, n if transposed else k, 1 if transposed else 0)
 
 
-USE_MFMA_TN = True      # A/B switch: hand-written fp32-MFMA kernel for the tall-skinny weight gradients
 OWN_TN_MAX_OUTPUTS = 1 << 21
 
 
+def _require_fp32_gpu(what, *tensors):
+    """The dense products exist as hand-written HIP kernels for fp32 device tensors only: no library GEMM, no CPU path."""
+    for t in tensors:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+            raise TypeError(f"{what}: 2-D float32 tensors on a HIP device only (got {t.dtype}, {t.device.type}, {t.dim()}-D); "
+                            "deltaconv_amd has no library / CPU product path")
+
+
 def gemm_tn(a, b):
-    """a.t() @ b for a [R,M], b [R,N] (weight gradient dW = dY^T X).  Tall-skinny problems go to the
-    hand-written fp32-MFMA split-K kernel (csrc/gemm_tn.hip); everything else to the library."""
+    """a.t() @ b for a [R,M], b [R,N] (weight gradient dW = dY^T X) on the hand-written fp32-MFMA split-K kernel
+    (csrc/gemm_tn.hip), whatever the shape."""
     r, m = a.shape
     n = b.shape[1]
     # measured (profiles/r01i_kernels.log, r01n, gpurun r02c): the MFMA kernels win or tie against the TUNED library
@@ -674,39 +699,31 @@ def gemm_tn(a, b):
     # and ahead of the untuned one.  Round 4: EVERY row count runs here (the kernel guards ragged shapes): the library's fp32
     # product came back 7e-3 off at [4096, 128]^T [4096, 256] (a reduced-precision algorithm: the pinned-slot gradient test
     # of tests/test_gpu_configs.py caught it on the 2-cloud ShapeNet step) -- no vendor GEMM is reachable for fp32 GPU inputs.
-    if (USE_MFMA_TN and a.is_cuda and r >= 1
-            and a.dtype == torch.float32 and b.dtype == torch.float32 and a.stride(1) == 1 and b.stride(1) == 1):
-        out = torch.empty(m, n, dtype=torch.float32, device=a.device)
-        # outputs beyond the kernel's workspace budget: column blocks of b, each its own launch into its column block of dW
-        # (round 5: the library fallback above 2^21 outputs is gone -- no vendor GEMM for fp32 GPU inputs, whatever the size)
-        nblk = max(1, min(n, OWN_TN_MAX_OUTPUTS // max(m, 1)))
-        for j0 in range(0, n, nblk):
-            nj = min(nblk, n - j0)
-            nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, nj)
-            ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
-            lib.call("dc_gemm_tn", a, a.stride(0), b[:, j0:j0 + nj], b.stride(0), r, m, nj, out[:, j0:j0 + nj], n, 0, ws,
-                     ws.numel() * 4)
-        return out
-    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and USE_MFMA_TN:
-        return gemm_tn(_rowmajor(a), _rowmajor(b))
-    return a.t() @ b        # CPU tensors / other dtypes / the lab switch only
+    _require_fp32_gpu("gemm_tn", a, b)
+    if a.stride(1) != 1 or b.stride(1) != 1:
+        a, b = _rowmajor(a), _rowmajor(b)
+    out = torch.empty(m, n, dtype=torch.float32, device=a.device)
+    if r == 0:                      # no rows: the empty sum (the kernels want r >= 1)
+        return out.zero_()
+    # outputs beyond the kernel's workspace budget: column blocks of b, each its own launch into its column block of dW
+    # (round 5: the library fallback above 2^21 outputs is gone -- no vendor GEMM for fp32 GPU inputs, whatever the size)
+    nblk = max(1, min(n, OWN_TN_MAX_OUTPUTS // max(m, 1)))
+    for j0 in range(0, n, nblk):
+        nj = min(nblk, n - j0)
+        nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, nj)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
+        lib.call("dc_gemm_tn", a, a.stride(0), b[:, j0:j0 + nj], b.stride(0), r, m, nj, out[:, j0:j0 + nj], n, 0, ws,
+                 ws.numel() * 4)
+    return out
 
 
 # ---- dense products of the per-point Linear layers: hand-written fp32-MFMA kernels (csrc/gemm.hip) --------------
-USE_OWN_GEMM = True        # A/B switch: False = vendor library (torch.mm) for the forward / input-gradient products
-OWN_GEMM_MIN_ROWS = 1      # every row count (<= 64 rows normally run on csrc/rowblock.hip before they get here); the kernels guard ragged shapes
-
-
 # Every per-point product runs on the hand-written kernels, the embedding MLP included: against the per-shape TUNED
 # vendor library its input gradient is 276 vs 240 us and its weight gradient ~312 vs ~300 us at the ModelNet40 shape
 # (profiles/r02f_step_timeline.txt, r02e_gemm_lab.txt) -- 1 % of the step -- but against the library's default
 # heuristic (any shape without a shipped TunableOp entry: the other configurations) the hand-written kernels win by
 # 1.3-1.5x (ShapeNet embedding: 376 + 241 us vs ~250 + ~250 us), and the path no longer depends on tuning files.
-
-
-def _own_gemm(x):
-    return (USE_OWN_GEMM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] >= OWN_GEMM_MIN_ROWS
-            and x.stride(1) == 1)
+# Round 6: the library branches (and their A/B switches) are deleted -- anything but 2-D fp32 device tensors raises.
 
 
 def _rowmajor(t):
@@ -718,12 +735,7 @@ def mm_nt(x, w, out=None):
     x, w = _rowmajor(x), _rowmajor(w)
     m, k = x.shape
     n = w.shape[0]
-    if not _own_gemm(x):
-        y = x @ w.t()
-        if out is None:
-            return y
-        out.copy_(y)
-        return out
+    _require_fp32_gpu("mm_nt", x, w)
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
     _hint_planes(w, False)
@@ -736,14 +748,7 @@ def mm_nn(dy, w, out=None, accumulate=False):
     dy, w = _rowmajor(dy), _rowmajor(w)
     m, n = dy.shape
     k = w.shape[1]
-    if not _own_gemm(dy):
-        if out is None:
-            return dy @ w
-        if accumulate:
-            out.addmm_(dy, w)
-        else:
-            torch.mm(dy, w, out=out) if out.is_contiguous() else out.copy_(dy @ w)
-        return out
+    _require_fp32_gpu("mm_nn", dy, w)
     if out is None:
         assert not accumulate
         out = torch.empty(m, k, dtype=torch.float32, device=dy.device)
@@ -783,8 +788,9 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
     rm, rv = (bn.running_mean, bn.running_var) if (track or not use_batch) else (None, None)
     coef = torch.empty(4, c, dtype=torch.float32, device=dev)
     h = torch.empty(m, n, dtype=torch.float32, device=dev)
+    _require_fp32_gpu("linear_stats", x, w)
     group = sync_group() if use_batch else None
-    if group is not None and _own_gemm(x):
+    if group is not None:
         # statistics of the GLOBAL batch (deltaconv_amd/dp.py): the same GEMM epilogue, cut at the reduction -- this rank's fp64
         # column sums + its row count are all-reduced, dc_bn_coeffs_from_sums finishes (round 5: the fused layer nodes keep
         # their epilogues under synchronised BatchNorm instead of falling back to the composed blocks)
@@ -799,8 +805,8 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
             lib.call("dc_linear_bn_sums_forward", x, x.stride(0), w, w.stride(0), m, n, k, h, n, sums, 0, ws, nb)
         dp.all_reduce_stats(sums[0], group)
         lib.call("dc_bn_coeffs_from_sums", sums[0], 0, c, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3])
-        return h, coef, True
-    if use_batch and _own_gemm(x) and group is None:
+        return h, coef, BatchStats(group)
+    if use_batch:
         nb = lib.raw("dc_linear_stats_workspace_bytes")(m, n, k, 0)
         ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=dev)
         _hint_planes(w, False)
@@ -810,20 +816,9 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
         else:
             lib.call("dc_linear_bn_stats_forward", x, x.stride(0), w, w.stride(0), m, n, k, h, n, gamma, beta,
                      float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
-        return h, coef, True
-    mm_nt(x, w, out=h)
-    if use_batch:
-        assert group is None, "synchronised BatchNorm runs through bn_act / vector_nonlin when the own GEMM kernels are off"
-        ws, nb = _ws(rows, c, dev)
-        if vn:
-            lib.call("dc_vn_stats", h, rows, c, n, 2 if vn == 2 else 0, gamma, beta, float(bn.eps), mom, rm, rv, coef[0],
-                     coef[1], coef[2], coef[3], ws, nb)
-        else:
-            lib.call("dc_bn_stats", h, m, n, n, gamma, beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2],
-                     coef[3], ws, nb)
-    else:
-        coef = eval_coeffs(gamma, beta, rm, rv, float(bn.eps), c)
-    return h, coef, use_batch
+        return h, coef, BatchStats(None)
+    mm_nt(x, w, out=h)                 # inference: coefficients from the running statistics
+    return h, eval_coeffs(gamma, beta, rm, rv, float(bn.eps), c), False
 
 
 FUSE_BN_BWD = True     # A/B switch: BatchNorm/activation backward folded into the consuming GEMMs (no dh tensor)
@@ -843,8 +838,9 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
     db = torch.empty(c, dtype=torch.float32, device=dev)
     ws, nb = _ws(r, c, dev)
     inp = _rowmajor(inp)
-    group = sync_group() if use_batch else None
-    if (FUSE_BN_BWD or group is not None) and _own_gemm(h) and USE_MFMA_TN and c * k <= OWN_TN_MAX_OUTPUTS:
+    _require_fp32_gpu("bn_block_backward", h, inp)
+    group = group_of(use_batch)        # the group of the FORWARD statistics
+    if (FUSE_BN_BWD or group is not None) and c * k <= OWN_TN_MAX_OUTPUTS:
         coefs = torch.empty(5 * c, dtype=torch.float32, device=dev)
         if group is not None:     # sums of this rank -> all-reduce -> the prologue coefficients from the global sums
             stats, local = _sync_stats(("dc_bn_act_backward_sums", lambda out: (dy, lddy, h, c, r, c, coef[2], coef[3], coef[0],
@@ -867,7 +863,9 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
             lib.call("dc_linear_bn_backward_input", dy, lddy, h, c, coefs, slope, W, W.stride(0), r, c, k, dinp,
                      dinp.stride(0), int(accumulate), 0)
         return dW, dg, db, dinp
-    assert group is None, "synchronised BatchNorm backward of a fused block needs the own GEMM kernels"
+    if group is not None:              # same shapes on every rank: every rank raises here, before any collective
+        raise NotImplementedError(f"synchronised BatchNorm backward of a fused block with {c} x {k} > {OWN_TN_MAX_OUTPUTS} "
+                                  "weight entries (the un-fused form has no split reduction)")
     dh = torch.empty_like(h)
     lib.call("dc_bn_act_backward", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope, int(use_batch),
              dh, c, dg, db, ws, nb)
@@ -884,8 +882,6 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, w, b):
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        if not _own_gemm(x):
-            return F.linear(x, w, b)
         y = mm_nt(x, w)
         if b is not None:
             y += b
@@ -1070,14 +1066,13 @@ class _RowLinear(torch.autograd.Function):
 
 
 def linear(x, w, b=None):
-    """F.linear on the hand-written GEMM kernels (2-D fp32 GPU inputs; otherwise torch)."""
+    """F.linear on the hand-written GEMM kernels: 2-D fp32 device tensors (anything else raises -- no library path)."""
+    _require_fp32_gpu("linear", x, w)
     if _rowblock_ok(x, w):
         return _RowLinear.apply(x, w, b)
-    if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32:
-        if USE_BIAS_ACT and b is not None and b.dtype == torch.float32:
-            return _LinearBiasAct.apply(_c(x), w, b, 1.0)        # bias in the activation kernel's pass, d b from its reduction
-        return _Linear.apply(x, w, b)
-    return F.linear(x, w, b)
+    if USE_BIAS_ACT and b is not None and b.dtype == torch.float32:
+        return _LinearBiasAct.apply(_c(x), w, b, 1.0)        # bias in the activation kernel's pass, d b from its reduction
+    return _Linear.apply(x, w, b)
 
 
 class _LinearBNAct(torch.autograd.Function):

@@ -121,7 +121,7 @@ def _vn_backward(dout, lddo, h, combine, coef, use, gamma):
     dh = torch.empty_like(h)
     dg, db = torch.empty(co, dtype=_F32, device=dev), torch.empty(co, dtype=_F32, device=dev)
     ws, nb = fused._ws(n, co, dev)
-    group = fused.sync_group() if use else None
+    group = fused.group_of(use)      # the group the FORWARD statistics were reduced over (fused.BatchStats)
     if group is not None:        # synchronised statistics: this rank's sums -> all-reduce -> apply with the global means
         stats, local = fused._sync_stats(("dc_vn_backward_sums", lambda out: (dout, lddo, h, ld, combine, n, co, coef[2], coef[3],
                                                                               coef[0], coef[1], out, ws, nb)), co, n, dev, group)

@@ -1,12 +1,15 @@
 """BatchNorm over rows and the vector non-linearity.  Module tree / parameter names mirror the
 reference (deltaconv/nn/nonlin.py:11-86) so its state_dicts load unchanged; the arithmetic runs in
 the fused HIP kernels of deltaconv_amd/csrc/nn.hip (see fused.py)."""
+import warnings
+
 import torch
 from torch import Tensor
 
 from . import fused
 
 EPS = 1e-8  # nonlin.py:8
+_WARNED_GENERIC = False
 
 
 class BatchNorm1d(torch.nn.Module):
@@ -48,7 +51,14 @@ class VectorNonLin(torch.nn.Module):
         """x: [2N,C]; combine=1: x is [2N,2C] = [P | Q]; combine=2: P/Q interleaved (fused.py / mlp.VectorBlock)."""
         if isinstance(self.nonlin, torch.nn.ReLU):
             return fused.vector_nonlin(x, combine, self)
-        # any other non-linearity: same formula through torch ops on the GPU
+        # any other non-linearity is an arbitrary module the HIP kernels (ReLU) cannot evaluate: the reference's formula
+        # (nonlin.py:67-79) composed from torch ops on the device -- said out loud, once, so that nobody times it as the
+        # product path (no model of the reference passes anything but the default ReLU)
+        global _WARNED_GENERIC
+        if not _WARNED_GENERIC:
+            _WARNED_GENERIC = True
+            warnings.warn(f"VectorNonLin(nonlin={self.nonlin.__class__.__name__}): only ReLU runs on the fused HIP kernels; "
+                          "this module is evaluated with composed torch ops")
         assert not combine
         n, c = x.shape
         w = x.view(-1, 2, c)

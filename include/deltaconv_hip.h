@@ -96,6 +96,29 @@ int dc_mls_assemble_shape(const float* pos, const float* normal, const float* x_
                           float shape_regularizer, int32_t normalized, float* G, float* D, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* The stages of build_grad_div on their own: the reference exports and tests them one by one
+ * (deltaconv/geometry/__init__.py:3; test/geometry/test_grad_div_mls.py:58-275).  Same device functions as the
+ * fused kernels behind dc_mls_assemble (csrc/point_math.h); fp32 in / fp32 out, fp64 inside.
+ * Edges are centre-major in groups of k (edge e belongs to group e / k), as everywhere in the reference
+ * (grad_div_mls.py:24-25,85,224). */
+/* coords_projected -- grad_div_mls.py:72-97: coords[E,2] = ((p_col - p_row) minus its normal part) . (x, y) of frame e / k */
+int dc_mls_coords(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                  const int32_t* row, const int32_t* col, int64_t num_edges, int32_t k, float* coords, void* stream);
+/* gaussian_weights -- grad_div_mls.py:100-116: dist[Nt*k] -> weights[Nt*k]; cloud_ptr[num_clouds+1] delimits the
+ * clouds whose mean edge length scales the kernel (batch=None: one cloud); workspace >= 8 * num_clouds bytes */
+int dc_mls_gaussian_weights(const float* dist, const int32_t* cloud_ptr, int32_t num_clouds, int32_t max_cloud_size,
+                            int32_t k, float kernel_width, float* weights, void* workspace, size_t workspace_bytes,
+                            void* stream);
+/* weighted_least_squares -- grad_div_mls.py:119-152: coords[Nt*k,2], weights[Nt*k] -> wls[Nt*k,6] =
+ * ((B^T W B + regularizer I)^-1 B^T W)^T per point (the shape_regularizer variant is a second call) */
+int dc_mls_wls(const float* coords, const float* weights, int32_t num_points, int32_t k, float regularizer, float* wls,
+               void* stream);
+/* fit_vector_mapping -- grad_div_mls.py:155-194: mapping[E,2,2] = g^-1 T per edge; row must be constant inside a
+ * group of k edges (the scatter_add over row, :165, is the sum over the group in slot order) */
+int dc_mls_vector_mapping(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+                          const int32_t* row, const int32_t* col, int64_t num_edges, int32_t k, const float* wls,
+                          const float* coords, float* mapping, void* stream);
+
 /* ---- operator applies (SparseTensor @ dense: deltanet_base.py:78; deltaconv.py:57,66;
  *      operators.py:27,33,40,43) ------------------------------------------------------------- */
 /* out[2Nt,C] = grad @ x[Nt,C] */
@@ -316,7 +339,8 @@ int dc_seg_reduce_backward(const float* dout, int64_t lddo, const uint8_t* arg, 
  * dc_bn_act call.  Backward: ONE recompute pass (three chained MFMA products: y2, du1 = (dy2 W2) act1', dW2 += dy2^T h1)
  * + a CSC closing pass; bit-reproducible (ordered reductions, in-edges in ascending edge id).  64 channels in both blocks.
  * stats_mode: 1 = batch statistics -> mean2 / invstd2 / scale2 / shift2 (+ running statistics), 2 = fp64 sums only
- * (sums[128] = [sum y2 | sum y2^2], synchronised BatchNorm), 0 = none.  coef1 / coef2 = [mean | invstd | scale | shift]
+ * (sums = double [2][2*64 + 1] = 258 doubles: two identical records [sum y2 | sum y2^2 | rows = n k], the layout of
+ * dc_bn_sums; finished by dc_bn_coeffs_from_sums after the all-reduce: synchronised BatchNorm), 0 = none.  coef1 / coef2 = [mean | invstd | scale | shift]
  * rows (4 x 64).  x [n, ci] / W1 [64, ci] (may be NULL): for ci <= 3 the edge pre-activation is evaluated as W1 (x_j - x_i)
  * per edge, the reference's own order of operations, instead of z_j - z_i.  Workspace: dc_edge2_workspace_bytes(n, k, backward). */
 size_t dc_edge2_workspace_bytes(int32_t n, int32_t k, int32_t backward);
@@ -428,7 +452,7 @@ int dc_linear_vn_stats_forward(const float* V, int64_t ldv, const float* Wst, in
                                float* scale, float* shift, int32_t tile, void* workspace, size_t workspace_bytes,
                                void* stream);
 
-/* the two statistics products with the reduction cut open (synchronised BatchNorm): sums[2 C] = the fp64 column sums of this
+/* the two statistics products with the reduction cut open (synchronised BatchNorm): sums = double [2][2*C + 1], the fp64 column sums of this
  * rank's rows (two records, as above), to be all-reduced and finished by dc_bn_coeffs_from_sums -- the fused layer nodes keep their GEMM epilogues
  * when BatchNorm statistics span the ranks of a data-parallel group. */
 int dc_linear_bn_sums_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, int64_t M, int32_t N, int32_t K,

@@ -85,6 +85,61 @@ void hc_mls_assemble_shape(const float* pos, const float* normal, const float* x
     }
 }
 
+// ---- the stages of build_grad_div on their own (dc_mls_coords / _gaussian_weights / _wls / _vector_mapping):
+// the loops of the four stage kernels of mls.hip around the same dcmath:: functions
+void hc_mls_coords(const float* pos, const float* normal, const float* xb, const float* yb, const int* row,
+                   const int* col, long num_edges, int k, float* coords) {
+    for (long e = 0; e < num_edges; ++e) {
+        const long f = e / k;
+        dcmath::Frame fr{dcmath::ld3(pos + 3 * (long)row[e]), dcmath::ld3(normal + 3 * f), dcmath::ld3(xb + 3 * f),
+                         dcmath::ld3(yb + 3 * f)};
+        const dcmath::EdgeGeom g = dcmath::edge_geom(fr, dcmath::ld3(pos + 3 * (long)col[e]));
+        coords[2 * e] = (float)g.u;
+        coords[2 * e + 1] = (float)g.v;
+    }
+}
+
+void hc_mls_gaussian_weights(const float* dist, const int* cloud_ptr, int num_clouds, int k, float kernel_width,
+                             float* weights) {
+    for (int c = 0; c < num_clouds; ++c) {
+        const int begin = cloud_ptr[c], n = cloud_ptr[c + 1] - begin;
+        double acc = 0;
+        for (int q = 0; q < n; ++q) {
+            double s = 0;
+            for (int e = 0; e < k; ++e) s += (double)dist[(long)(begin + q) * k + e];
+            acc += s / k;
+        }
+        const double avg = n > 0 ? acc / n : 0.0;
+        for (int q = 0; q < n; ++q) {
+            const long i = begin + q;
+            dcmath::gaussian_weights_point(dist + i * k, k, avg, (double)kernel_width, weights + i * k);
+        }
+    }
+}
+
+void hc_mls_wls(const float* coords, const float* weights, int num_points, int k, float regularizer, float* wls) {
+    for (long i = 0; i < num_points; ++i)
+        dcmath::wls_point(coords + i * k * 2, weights + i * k, k, (double)regularizer, wls + i * k * 6);
+}
+
+void hc_mls_vector_mapping(const float* pos, const float* normal, const float* xb, const float* yb, const int* row,
+                           const int* col, long num_edges, int k, const float* wls, const float* coords, float* out) {
+    for (long e = 0; e < num_edges; ++e) {
+        const long g0 = e / k * k, i = row[e], j = col[e];
+        const dcmath::Frame fi = dcmath::load_frame(pos, normal, xb, yb, i);
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < k; ++s) {
+            const dcmath::V3 d = dcmath::sub(dcmath::ld3(pos + 3 * (long)col[g0 + s]), fi.p);
+            const double h = dcmath::dot(fi.n, d);
+            for (int a = 0; a < 6; ++a) c[a] += (double)wls[(g0 + s) * 6 + a] * h;
+        }
+        double m[4];
+        dcmath::vector_map(fi, c, (double)coords[2 * e], (double)coords[2 * e + 1], dcmath::ld3(xb + 3 * j),
+                           dcmath::ld3(yb + 3 * j), m);
+        for (int a = 0; a < 4; ++a) out[4 * e + a] = (float)m[a];
+    }
+}
+
 // ---- ELL applies / aggregation: loop the per-thread bodies of ell_math.h over all threads ----
 // CSC build: same result as csc.hip (count -> per-cloud scan -> fill -> sort); the fill walks the
 // edges in REVERSE so that sort_column has real work to do.

@@ -90,7 +90,7 @@ def test_full_size_properties(name):
         assert torch.isfinite(g).all()
         snaps.append((out.detach().clone(), g.clone()))
     assert torch.equal(snaps[0][0], snaps[1][0]), "forward is not bit-reproducible"
-    assert rel_err(snaps[0][1], snaps[1][1]) < 1e-6
+    assert torch.equal(snaps[0][1], snaps[1][1]), "backward is not bit-reproducible"
     moved = [float((b_ - rm0[n_]).abs().max()) for n_, b_ in model.named_buffers() if "running_mean" in n_]
     assert min(moved) > 0
 
@@ -168,12 +168,16 @@ def test_reduced_batch_step_vs_oracle(name):
     assert worst_hip < 3 * worst_ref + floor
 
 
-@pytest.mark.parametrize("name,clouds", [("C2_modelnet40", 8), ("C4_shapenet", 2), ("C5_shapeseg", 2)])
-def test_pinned_slots_step_vs_oracle(name, clouds):
+@pytest.mark.parametrize("name,clouds", [("C2_modelnet40", 8), ("C3_scanobjectnn", 2), ("C4_shapenet", 2), ("C5_shapeseg", 2)])
+def test_pinned_slots_step_vs_oracle(name, clouds, monkeypatch):
     """The same train-mode step with the max-aggregation SELECTION pinned: the HIP layers report the slot they selected
     per (point, channel), the CPU oracle takes exactly those slots instead of its own arg-max
     (/root/reference/deltaconv/nn/deltaconv.py:52,54: scatter(..., reduce='max')), in fp64 and in fp32, so all three runs
-    differentiate the same aggregation branch.  What still separates them: rounding, and the KINKS of LeakyReLU / ReLU -- a
+    differentiate the same aggregation branch.  C3 (no normals, round 6): the tangent frames of estimate_basis carry a
+    gauge (the sign of the SVD's x-axis, the x-axis itself on near-isotropic neighbourhoods: SURVEY.md section 8(a) a3), so
+    the oracle is handed the frames the HIP path computed (dc_estimate_basis, itself pinned to the reference's fp64 frames by
+    tests/test_gpu_geometry.py::test_estimate_basis) -- with gauge and selection fixed, C3 sits under the same FLAT bounds
+    as the configurations with given normals.  What still separates them: rounding, and the KINKS of LeakyReLU / ReLU -- a
     pre-activation within rounding of zero flips its slope between two fp32 runs, and with a mean loss over a few thousand
     rows ONE flipped element moves one row of a weight gradient by ~1/sqrt(rows) of its largest entry (measured on the
     2-cloud ShapeNet step: a single flip in the head = 7e-3 in max norm; tools/debug/c4_head_grads.py).  A max-norm bound
@@ -195,6 +199,12 @@ def test_pinned_slots_step_vs_oracle(name, clouds):
     ref32, ref64 = _no_dropout(ref32.train()), _no_dropout(ref64.train())
     model = _no_dropout(model.to(DEV).train())
     bd = b.to(DEV)
+    if not normals:
+        import deltaconv_amd as dc
+        frames = [t.cpu() for t in dc.geometry.estimate_basis(bd.pos, dc.geometry.Graph.knn(bd.pos, 10, bd.batch),
+                                                              orientation=bd.pos)]
+        monkeypatch.setattr(oracle.geometry, "estimate_basis",
+                            lambda pos, nbr, orientation=None: tuple(f.to(pos.dtype) for f in frames))
     L.SLOT_TAP[0] = []
     try:
         ld = model(bd)

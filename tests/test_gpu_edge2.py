@@ -220,3 +220,43 @@ def test_edge_diff_and_segment_reduce_vs_torch(c, aggr):
     assert rel_err(xd.grad, xr.grad) < 1e-4
     if aggr in ("max", "min"):
         assert slots.shape == (n, c) and int(slots.max()) < k
+
+
+def test_edge2_forward_stats_mode_2_sums():
+    """stats_mode 2 (synchronised BatchNorm form, round-5 advisor finding): `sums` is double [2][2*64 + 1] -- two identical
+    records [sum y2 | sum y2^2 | n k] -- and dc_bn_coeffs_from_sums on it gives exactly mode 1's coefficients; nothing is
+    written behind the 258 doubles; ysel / arg do not depend on the mode."""
+    from deltaconv_amd._lib import lib
+    graph, x, params = _setup([300, 211], 20, 3, seed=5)
+    W1, g1, b1, W2, g2, b2 = (t.float().to(DEV).contiguous() for t in params)
+    xd = x.float().to(DEV).contiguous()
+    n, k, c = graph.n, graph.k, 64
+    f32 = dict(dtype=torch.float32, device=DEV)
+    nb = lib.raw("dc_edge2_workspace_bytes")(n, k, 0)
+    ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=DEV)
+    coef1 = torch.empty(4, c, **f32)
+    s1 = torch.empty(n, 3, **f32)
+    lib.call("dc_edge2_bn1_stats", xd, xd.stride(0), 3, W1, graph.nbr, n, k, g1, b1, EPS, 0.1, None, None, s1, coef1[0], coef1[1],
+             coef1[2], coef1[3], ws, nb)
+
+    def fwd(mode, coef2, sums):
+        ysel, arg = torch.empty(n, c, **f32), torch.empty(n, c, dtype=torch.uint8, device=DEV)
+        lib.call("dc_edge2_forward", None, xd, xd.stride(0), 3, W1, graph.nbr, n, k, W2, coef1[2], coef1[3], 0.2, mode, g2, b2,
+                 EPS, 0.1, None, None, ysel, arg, *(coef2 if coef2 is not None else (None,) * 4), sums, ws, nb)
+        return ysel, arg
+
+    coefA = torch.empty(4, c, **f32)
+    yA, aA = fwd(1, coefA, None)
+    GUARD = 7.25
+    sums = torch.full((2 * (2 * c + 1) + 64,), GUARD, dtype=torch.float64, device=DEV)
+    yB, aB = fwd(2, None, sums)
+    assert torch.equal(yA, yB) and torch.equal(aA, aB)
+    rec = sums[:2 * (2 * c + 1)].view(2, 2 * c + 1)
+    assert torch.equal(rec[0], rec[1]) and float(rec[0, 2 * c]) == n * k
+    assert bool((sums[2 * (2 * c + 1):] == GUARD).all()), "dc_edge2_forward wrote behind double [2][2*64 + 1]"
+    coefB = torch.empty(4, c, **f32)
+    lib.call("dc_bn_coeffs_from_sums", sums, 0, c, g2, b2, EPS, 0.1, None, None, coefB[0], coefB[1], coefB[2], coefB[3])
+    assert torch.equal(coefA, coefB)
+    # and the sums are what they say: fp64 column sums of y2 over all edges (reference formulation on [E, 64] tensors)
+    _, _, (y1, y2) = composed64(x, graph.nbr.cpu().long(), *params, 0.2, 0.2)
+    assert rel_err(rec[0, :c], y2.sum(0)) < 1e-5 and rel_err(rec[0, c:2 * c], (y2 * y2).sum(0)) < 1e-5
