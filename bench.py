@@ -4,6 +4,14 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Default = BASELINE configuration 2 (the one the metric is quoted on), weak scaling: 32 clouds per GPU.  The other
+configurations (deltaconv_amd/configs.py) and the STRONG-scaling form of a configuration -- BASELINE configs 4 / 5 are
+defined as a global batch of 16 / 8 clouds data-parallel over 8 GPUs -- are selected by flags:
+
+    python bench.py --config C4 --global-batch 16 --gpus 8      # 2 clouds per rank, "scaling": "strong", BatchNorm
+                                                                 # statistics over the global batch (= one process on 16)
+    python bench.py --config C5                                  # the whole configuration on one GPU
+
 One JSON line on rank 0 (contract in the task statement) carrying `roofline` (the sparse operator
 apply, measured live with HIP events) and `cpu_baseline` (the oracle = CPU port of the reference
 path, timed on this box's host cores on a bounded sample).
@@ -30,26 +38,54 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU (weak scaling)")
-    ap.add_argument("--points", type=int, default=1024)
-    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE.json configuration (deltaconv_amd/configs.py); C2 = the one the metric is quoted on")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="STRONG scaling: this many clouds in total, global-batch / world per rank, BatchNorm statistics over the "
+                         "global batch (BASELINE configs 4 / 5: --config C4 --global-batch 16, --config C5 --global-batch 8)")
+    ap.add_argument("--batch", type=int, default=None, help="clouds per GPU (weak scaling; default: the configuration's batch)")
+    ap.add_argument("--points", type=int, default=None, help="points per cloud (default: the configuration's)")
+    ap.add_argument("--k", type=int, default=None, help="neighbours (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exact-chain", action="store_true",
                     help="skip the second timing of the same step with every dense product on the exact fp32 MFMA chain")
-    ap.add_argument("--cpu-clouds", type=int, default=8, help="clouds in the CPU-baseline sample")
+    ap.add_argument("--cpu-clouds", type=int, default=None, help="clouds in the CPU-baseline sample (default 8 / 4 / 4 / 2 for C2 .. C5)")
     ap.add_argument("--no-cpu-full-batch", action="store_true",
                     help="skip the second CPU-baseline entry on the full batch of the configuration (~25 s)")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every kernel from Python each step instead of replaying the captured HIP graph")
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct synthetic batches cycled through")
-    ap.add_argument("--sync-bn", action="store_true",
+    ap.add_argument("--sync-bn", action="store_true", default=None,
                     help="BatchNorm statistics over the global batch (all-reduced fp64 sums); the data-parallel step is then ONE "
-                         "graph with its collectives captured")
+                         "graph with its collectives captured.  Default: on with --global-batch (strong scaling), off otherwise")
+    ap.add_argument("--no-sync-bn", dest="sync_bn", action="store_false")
     ap.add_argument("--spawn", action="store_true",
                     help="go through the self-launcher even with --gpus 1 (exercises the path `--gpus N > 1` takes; tests/test_gpu_dist.py)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gradient all-reduce path even with one rank (self-test)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    from deltaconv_amd.configs import CONFIGS
+    cfg = CONFIGS[args.config]
+    args.points = cfg["N"] if args.points is None else args.points
+    args.k = cfg["k"] if args.k is None else args.k
+    args.strong = args.global_batch is not None
+    if args.sync_bn is None:
+        args.sync_bn = args.strong
+    if args.cpu_clouds is None:
+        args.cpu_clouds = {"C2": 8, "C3": 4, "C4": 4, "C5": 2}[args.config]
+    if args.config != "C2":
+        args.no_cpu_full_batch = True       # the bounded sample only: a full C3 .. C5 batch is minutes of CPU work
+    return args
+
+
+def per_rank_clouds(args, world):
+    """Clouds of one rank: global-batch / world (strong scaling: fixed total work) or the configuration's batch per GPU (weak)."""
+    from deltaconv_amd.configs import CONFIGS
+    if args.strong:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+        return args.global_batch // world
+    return CONFIGS[args.config]["B"] if args.batch is None else args.batch
 
 
 def apply_roofline(graph, grad, div, C, iters=200):
@@ -268,6 +304,57 @@ def apply_roofline(graph, grad, div, C, iters=200):
                 mfma=mfma)
 
 
+
+STAMP_KINDS = {1: "div_curl_norm", 2: "hodge", 3: "div", 11: "div_curl_norm_T", 12: "hodge_T", 13: "grad_T_sum", 14: "knn_max_bwd",
+               15: "div_T", 16: "edge_mlp_bwd"}
+STAMP_BYTES = {1: lambda c, n, e: 20 * c * n + 12 * e, 2: lambda c, n, e: 16 * c * n + 12 * e, 3: lambda c, n, e: 12 * c * n + 12 * e,
+               11: lambda c, n, e: 36 * c * n + 12 * e, 12: lambda c, n, e: 24 * c * n + 12 * e, 13: lambda c, n, e: 16 * c * n + 12 * e,
+               14: lambda c, n, e: 9 * c * n + 4 * e}
+
+
+def in_step_stamps(model, calc_loss, static, opt, n, k, replays=12):
+    """Durations of the tiled operator kernels INSIDE the replayed training step, from device-clock stamps (csrc/common.h:
+    dc_stamp_in / dc_stamp_out -- earliest workgroup entry to latest workgroup exit with its stores complete, 100 MHz constant
+    clock): a SECOND capture of the same step with stamping armed (the timed step above never carries the stamps), replayed
+    `replays` times with the records reset in between; per kernel instance the median over the replays.
+    -> {name: [dict(C, us, bytes, frac) per instance in launch order]}"""
+    from deltaconv_amd._lib import lib
+    from deltaconv_amd.graph_step import GraphedTrainStep
+    slots = 2048
+    dev = static.pos.device
+    stamps = torch.zeros(slots, 4, dtype=torch.int64, device=dev)
+    raw = lib.raw("dc_stamp_buffer")
+    raw(stamps.data_ptr(), slots)
+    try:
+        g = GraphedTrainStep(model, calc_loss, static, optimizer=opt, warmup=1)
+    finally:
+        used = lib.raw("dc_stamp_count")()
+        tags = [lib.raw("dc_stamp_tag")(i) for i in range(used)]
+        raw(None, 0)
+    per = used // 2                       # one eager warm-up step + the captured one: the capture took the last `per` records
+    if per == 0 or used != 2 * per:
+        return None
+    first = used - per
+    samples = []
+    for _ in range(replays):
+        stamps[:, 0] = 2 ** 62
+        stamps[:, 1] = 0
+        g()
+        torch.cuda.synchronize()
+        rec = stamps[first:used].cpu()
+        samples.append((rec[:, 1] - rec[:, 0]).double() * 1e-2)          # 100 MHz ticks -> us
+    med = torch.stack(samples).median(0).values.tolist()
+    out = {}
+    e = n * k
+    for tag, us in zip(tags[first:used], med):
+        kind, c = tag // 1000, tag % 1000
+        nbytes = STAMP_BYTES[kind](c, n, e) if kind in STAMP_BYTES else None
+        out.setdefault(STAMP_KINDS.get(kind, str(kind)), []).append(
+            dict(C=c, us=round(us, 2), bytes=nbytes, frac=None if nbytes is None else round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)))
+    del g
+    return out
+
+
 def _physical_cores():
     """(physical cores, hardware threads) of this host from /proc/cpuinfo."""
     hw = os.cpu_count() or 1
@@ -295,15 +382,17 @@ def cpu_baseline(args):
     import statistics
     import oracle
     from deltaconv_amd.data import synthetic_batch
+    from deltaconv_amd import configs as C
     phys, hw = _physical_cores()
-    b = synthetic_batch(args.cpu_clouds, args.points, seed=2)
+    b = C.make_batch(args.config, args.cpu_clouds, 2, args.points)
     torch.manual_seed(1)
-    model = oracle.models.DeltaNetClassification(3, 40, num_neighbors=args.k).train()
+    model = C.build_model(args.config, oracle.models, args.k).train()
+    smooth = C.loss_smoothing(args.config)
 
     def one(batch=b):
         t0 = time.perf_counter()
         model.zero_grad()
-        oracle.loss.calc_loss(model(batch), batch.y).backward()
+        oracle.loss.calc_loss(model(batch), batch.y, smoothing=smooth).backward()
         return time.perf_counter() - t0
 
     trials = {}
@@ -317,7 +406,7 @@ def cpu_baseline(args):
         one()
     times = [one() for _ in range(10)]
     med = statistics.median(times)
-    small = synthetic_batch(2, args.points, seed=3)
+    small = C.make_batch(args.config, 2, 3, args.points)
     torch.set_num_threads(1)
     one(small)
     t1 = statistics.median([one(small) for _ in range(3)])
@@ -325,13 +414,16 @@ def cpu_baseline(args):
     # the SAME inputs as the GPU step: the full batch of the configuration, 1 warm-up + 2 timed steps
     full = None
     if not args.no_cpu_full_batch:
-        fb = synthetic_batch(args.batch, args.points, seed=100)
+        fb = C.make_batch(args.config, args.batch, 100, args.points)
         one(fb)
         tf = [one(fb) for _ in range(2)]
         full = dict(value=round(args.batch / statistics.median(tf), 3), unit="clouds/s", cores=best, clouds=args.batch,
                     sample=f"the bench batch itself ({args.batch} clouds x {args.points} pts, seed 100), 1 warm-up + 2 timed steps")
     return dict(value=args.cpu_clouds / med, unit="clouds/s", cores=best, kind="port", full_batch=full,
                 physical_cores=phys, hardware_threads=hw, one_thread_value=round(2 / t1, 3),
+                thread_scaling=("does NOT scale with threads: `cores` is the torch intra-op pool size that measured best, "
+                                f"{trials} clouds/s by pool size vs {round(2 / t1, 3)} on ONE thread -- many small ops per step; "
+                                "read the value as a roughly single-core restatement, not as a " + str(best) + "-core result"),
                 sample=f"oracle/ (torch-CPU restatement of the reference path), {args.cpu_clouds} clouds x "
                        f"{args.points} pts, k={args.k}, fwd+bwd train mode, 3 warm-up + 10 timed steps, median "
                        f"(min {args.cpu_clouds / max(times):.2f} / max {args.cpu_clouds / min(times):.2f} clouds/s) at "
@@ -375,18 +467,22 @@ def main(argv=None):
     if world != args.gpus and rank == 0:      # a launcher decides the world size; --gpus only documents it
         print(f"[bench] WORLD_SIZE={world} (launcher) overrides --gpus {args.gpus}", file=sys.stderr)
 
-    import deltaconv_amd as dc
-    from deltaconv_amd.utils import calc_loss
-    from deltaconv_amd.data import synthetic_batch
+    import deltaconv_amd as dc  # noqa: F401
+    from deltaconv_amd import configs as C
+    from deltaconv_amd.utils import calc_loss as _calc_loss
     from deltaconv_amd.dp import FlatGradDataParallel
 
+    cfg = C.CONFIGS[args.config]
+    args.batch = per_rank_clouds(args, world)
+    smooth = C.loss_smoothing(args.config)
+    calc_loss = lambda out, y: _calc_loss(out, y, smoothing=smooth)
     torch.manual_seed(1)
-    model = dc.models.DeltaNetClassification(3, 40, num_neighbors=args.k).to(dev).train()
+    model = C.build_model(args.config, k=args.k).to(dev).train()
     ddp = FlatGradDataParallel(model, always_reduce=args.force_dist, sync_bn=args.sync_bn and use_dist)
-    # train_modelnet.py:67 hyper-parameters; fused=True = the same update as one multi-tensor kernel
-    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-4, fused=True)
+    # the configuration's optimizer (train_modelnet.py:67 / train_shapeseg.py:82); fused=True = one multi-tensor kernel
+    opt = C.build_optimizer(args.config, model.parameters())
     # Inputs resident in HBM before the timed region; every step consumes a different batch.
-    batches = [synthetic_batch(args.batch, args.points, seed=100 + rank + 1000 * i).to(dev)
+    batches = [C.make_batch(args.config, args.batch, 100 + rank + 1000 * i, args.points).to(dev)
                for i in range(max(1, args.resident_batches))]
     data = batches[0]
     counter = [0]
@@ -409,7 +505,7 @@ def main(argv=None):
         # forward + loss + backward (+ SGD update when there is no all-reduce in between) replayed from
         # one captured HIP graph; same kernels, same work per step, one host call.
         from deltaconv_amd.graph_step import GraphedTrainStep
-        static = synthetic_batch(args.batch, args.points, seed=99 + rank).to(dev)
+        static = C.make_batch(args.config, args.batch, 99 + rank, args.points).to(dev)
         for _ in range(2):                                   # eager steps first: allocator, optimizer state
             ddp.zero_grad()
             calc_loss(ddp(static), static.y).backward()
@@ -472,22 +568,46 @@ def main(argv=None):
             print(f"[bench] exact-chain timing failed: {e!r}", file=sys.stderr)
         finally:
             _lib.raw("dc_set_option")(3, 0)
+    stamped = None
+    if rank == 0 and world == 1 and not use_dist and not args.no_graph:
+        try:
+            stamped = in_step_stamps(model, calc_loss, static, opt, args.batch * args.points, args.k)
+        except Exception as e:
+            print(f"[bench] in-step stamps failed: {e!r}", file=sys.stderr)
     if rank == 0:
         graph, grad, div = model.deltanet_base.build_operators(data)
-        roof = apply_roofline(graph, grad, div, 64)
+        roof = apply_roofline(graph, grad, div, cfg["C"])
+        graded = [r for r in (stamped or {}).get("div_curl_norm", []) if r["C"] == cfg["C"]]
+        if graded:
+            # THE graded number: the kernel as it runs inside the replayed training step (its real predecessors, its real
+            # operand strides), mean over its instances at C channels; the proxies stay beside it
+            us = sum(r["us"] for r in graded) / len(graded)
+            nbytes = graded[0]["bytes"]
+            roof.update(rotating_buffers=dict(achieved=roof["achieved"], frac=roof["frac"], us_per_launch=roof["us_per_launch"]),
+                        achieved=round(nbytes / (us * 1e-6) / 1e9, 1), frac=round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        us_per_launch=round(us, 2), in_step_instances=graded, in_step_kernels=stamped,
+                        measured=("`achieved` / `frac` / `us_per_launch`: the kernel INSIDE the replayed training step (device-clock "
+                                  "stamps: first workgroup entry -> last workgroup exit with its stores complete; median of 12 replays, "
+                                  "mean over the step's instances at this channel count); `rotating_buffers`: HIP events around graph "
+                                  "replays on 12 rotating operand sets; `*_l3_resident`: HIP events, one operand set"))
+        metric = ("point-clouds/sec fwd+bwd, ModelNet40 1024pt k=20, 1/2/4/8 MI355X" if args.config == "C2" else
+                  f"point-clouds/sec fwd+bwd, {cfg['title']} {args.points}pt k={args.k}, 1/2/4/8 MI355X")
         out = {
-            "metric": "point-clouds/sec fwd+bwd, ModelNet40 1024pt k=20, 1/2/4/8 MI355X",
+            "metric": metric,
             "value": args.batch * world * args.steps / dt, "unit": "clouds/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_note": ("fp32 tensors and fp32 accumulation everywhere; the dense per-point products multiply through six bf16 "
                            "partial products of a 3-plane split of each fp32 operand (error against fp64 at or below the exact fp32 "
                            "MFMA chain's: tests/test_gpu_gemm.py; DC_GEMM_EXACT=1 runs the exact chain)"),
             "data": "synthetic (seeded smooth closed surfaces with analytic normals, random-init weights)",
-            "config": {"workload": f"ModelNet40 classification, {args.points} points, k={args.k}, "
-                                   f"batch={args.batch} per GPU, fwd+bwd+SGD step, train-mode BN/Dropout, "
+            "config": {"workload": f"{cfg['title']}, {args.points} points, k={args.k}, "
+                                   + (f"global batch={args.batch * world} ({args.batch} per GPU, strong scaling), " if args.strong
+                                      else f"batch={args.batch} per GPU, ")
+                                   + f"fwd+bwd+{'SGD' if cfg['optimizer'] == 'sgd' else 'Adam'} step, train-mode BN/Dropout, "
+                                   + ("BatchNorm statistics over the global batch, " if (args.sync_bn and use_dist) else "")
                                    + launch,
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                       "name": args.config, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": roof,
             "exact_chain_ms_per_step": exact_ms,
         }

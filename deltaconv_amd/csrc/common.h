@@ -66,6 +66,23 @@ __device__ __forceinline__ void dc_store16(float* p, dc_f32x4 v) {
     else *reinterpret_cast<dc_f32x4*>(p) = v;
 }
 
+// Device-clock stamps of selected kernels: what bench.py reads the graded apply's duration INSIDE the replayed training step
+// from (HIP events cannot bracket one kernel of a captured graph).  dc_stamp_buffer(buf, slots) arms it: every later
+// launch of a stamped kernel family takes the next record of `buf` -- 4 x u64: [earliest workgroup entry | latest workgroup
+// exit with its stores complete | unused | unused], constant 100 MHz clock (s_memrealtime) -- at ENQUEUE time, so a launch
+// captured into a HIP graph keeps its record across replays; the caller resets the records (min = huge, max = 0) before a
+// replay.  Off (buf = NULL): the kernels get a null pointer and skip two scalar branches.
+unsigned long long* dc_stamp_next(int tag);        // host side; nullptr when stamping is off or the records are used up
+__device__ __forceinline__ void dc_stamp_in(unsigned long long* st) {
+    if (st && threadIdx.x == 0) atomicMin(st, (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void dc_stamp_out(unsigned long long* st) {
+    if (st && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicMax(st + 1, (unsigned long long)wall_clock64());
+    }
+}
+
 // Wave-level helpers -------------------------------------------------------------------------
 // Stream-ordered zero fill as a kernel (not hipMemsetAsync: a memset node inside a captured HIP graph
 // is a different code path from a kernel node; every entry point enqueues kernels only).

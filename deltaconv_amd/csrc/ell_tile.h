@@ -194,7 +194,8 @@ __global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const i
 template <int R, int P, class BODY>
 __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const int* __restrict__ plan,
                                                           const float* __restrict__ coef, const int* __restrict__ nbr,
-                                                          int slabs, int remap, int upw, const BODY body0) {
+                                                          int slabs, int remap, int upw, unsigned long long* stamp,
+                                                          const BODY body0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GM = Geom<R, P>;
     constexpr int NW = GM::NW, CAPR = GM::CAPR, RIT = GM::RIT;
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
     const long units = (long)L.T * slabs;
     const long u0 = dc_xcd_block(remap) * upw, u1 = min(u0 + (long)upw, units);
     if (u0 >= u1) return;
+    dc_stamp_in(stamp);
     const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
     const int wave = tid >> 6, lane64 = tid & 63;
     const int k = L.k, PK = L.PK;
@@ -350,11 +352,13 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
         cur = nxt;
     }
     if (pi >= 0) pbody.finish(pi, pc, ps0, ps1);
+    dc_stamp_out(stamp);
 }
 
 // ---- bodies (the arithmetic of ell_math.h, slot by slot) ---------------------------------------------------------
 // grad @ x (ell_math.h: grad_fwd)
 struct GradB {
+    static constexpr int TAG = 0;
     static constexpr bool COEF = true, SELF = false;
     static constexpr int KU = 4;                       // k-loop unroll of the persistent kernel
     static constexpr bool ROWPASS = false;
@@ -370,6 +374,7 @@ struct GradB {
 };
 // div @ v (div_fwd)
 struct DivB {
+    static constexpr int TAG = 3;                      // dc_stamp_tag kind
     static constexpr bool COEF = true, SELF = false;
     static constexpr int KU = 4;                       // k-loop unroll of the persistent kernel
     static constexpr bool ROWPASS = false;
@@ -382,6 +387,7 @@ struct DivB {
 };
 // [div v | curl v | norm v] (divcurlnorm_fwd)
 struct DivCurlNormB {
+    static constexpr int TAG = 1;
     static constexpr bool COEF = true, SELF = true;
     static constexpr int KU = 4;                       // k-loop unroll of the persistent kernel
     static constexpr bool ROWPASS = false;
@@ -406,6 +412,7 @@ struct DivCurlNormB {
 };
 // hodge Laplacian from [div v | curl v] (hodge_fwd): pieces = the two column blocks of one row
 struct HodgeB {
+    static constexpr int TAG = 2;
     static constexpr bool COEF = true, SELF = false;
     static constexpr int KU = 2;     // 4 puts the persistent kernel at 128 registers + 1 scratch spill (round-4 verdict); same op order
     static constexpr bool ROWPASS = false;
@@ -427,6 +434,7 @@ struct HodgeB {
 // max over the k neighbours, first maximal slot (knn_max_fwd / knn_max_affine_fwd); AFFINE: y = act(scale * h + shift)
 template <bool AFFINE>
 struct KnnMaxB {
+    static constexpr int TAG = 0;
     static constexpr bool COEF = false, SELF = false;
     static constexpr int KU = 4;
     // ROWPASS: BatchNorm + activation of the producing block are applied ONCE per unique row, in place in LDS, before the walk
@@ -499,7 +507,7 @@ inline void launch_one(const DcTilePlan& L, const int* plan, const float* coef, 
     if (upw < 2 && units >= 2L * device_cus()) upw = 2;
     if (dc_option(7) > 0) upw = dc_option(7);           // option 7 (lab): forced
     hipLaunchKernelGGL((tile_fwd_kernel<R, P, BODY>), dim3((unsigned)((units + upw - 1) / upw)), dim3(P * 16), lds, s, L, plan, coef, nbr,
-                       slabs, dc_option(DC_OPT_XCD_REMAP), upw, body);
+                       slabs, dc_option(DC_OPT_XCD_REMAP), upw, dc_stamp_next(1000 * BODY::TAG + C), body);
     }
 }
 template <int R, class BODY>

@@ -55,13 +55,15 @@ inline size_t lds_bytes(bool coef, bool arg) {
 //   void finish(long j, int c);
 template <int R, int P, class BODY>
 __global__ __launch_bounds__(P * 16) void tileT_kernel(DcTilePlanT L, const int* __restrict__ plan, const float* __restrict__ coefT,
-                                                       int slabs, int remap, int upw, const BODY body0) {
+                                                       int slabs, int remap, int upw, unsigned long long* stamp,
+                                                       const BODY body0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GM = Geom<R, P>;
     constexpr int NW = GM::NW, CAPR = GM::CAPR, RIT = GM::RIT;
     const long units = (long)L.T * slabs;
     const long u0 = dc_xcd_block(remap) * upw, u1 = min(u0 + (long)upw, units);
     if (u0 >= u1) return;
+    dc_stamp_in(stamp);
     const int tid = threadIdx.x, l16 = tid & 15, grp = tid >> 4;
     const int wave = tid >> 6, lane64 = tid & 63;
     const int k = L.k;
@@ -186,6 +188,7 @@ __global__ __launch_bounds__(P * 16) void tileT_kernel(DcTilePlanT L, const int*
         cur = nxt;
     }
     if (pj >= 0) pbody.finish(pj, pc);
+    dc_stamp_out(stamp);
 }
 
 // ---- bodies (the accumulators of ell_math.h: GradT, GradTSum, DivT, DivCurlNormT, HodgeT, KnnMaxT) ----------------------
@@ -196,6 +199,7 @@ constexpr int ST = DC_ST_ELL;   // store family of the transposed applies (commo
 // grad^T : dx[j] (+)= sum_e G[e,0] dy[2i] + G[e,1] dy[2i+1]; SUM: out[j] = a[j] (+ b[j]) + the sum (dc_apply_grad_T_sum)
 template <bool SUM>
 struct GradTB {
+    static constexpr int TAG = 13;                     // dc_stamp_tag kind
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 1;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -226,6 +230,7 @@ struct GradTB {
 };
 // div^T : dv[2j+a] (+)= sum_e D[e,a] dy[i]
 struct DivTB {
+    static constexpr int TAG = 15;                     // dc_stamp_tag kind
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -245,6 +250,7 @@ struct DivTB {
 };
 // backward of [div v | curl v | norm v] (ell_math.h: DivCurlNormT): pieces = dout[i, 0:C], dout[i, C:2C]
 struct DivCurlNormTB {
+    static constexpr int TAG = 11;                     // dc_stamp_tag kind
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -278,6 +284,7 @@ struct DivCurlNormTB {
 };
 // backward of the Hodge-Laplacian apply (HodgeT): pieces = dh[2i], dh[2i+1]
 struct HodgeTB {
+    static constexpr int TAG = 12;                     // dc_stamp_tag kind
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -302,6 +309,7 @@ struct HodgeTB {
 };
 // max-aggregation backward (KnnMaxT): dh[j,c] (+)= sum over in-edges (i,s) with arg[i,c] == s of dout[i,c]
 struct KnnMaxTB {
+    static constexpr int TAG = 14;                     // dc_stamp_tag kind
     static constexpr bool COEF = false, ARG = true;
     static constexpr int NST = 1;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -335,7 +343,7 @@ inline void launch_one(const DcTilePlanT& L, const int* plan, const float* coefT
     if (upw < 2 && units >= 2L * dctile::device_cus()) upw = 2;
     if (dc_option(7) > 0) upw = dc_option(7);
     hipLaunchKernelGGL((tileT_kernel<R, P, BODY>), dim3((unsigned)((units + upw - 1) / upw)), dim3(P * 16), lds, s, L, plan, coefT, slabs,
-                       dc_option(DC_OPT_XCD_REMAP), upw, body);
+                       dc_option(DC_OPT_XCD_REMAP), upw, dc_stamp_next(1000 * BODY::TAG + C), body);
 }
 template <int R, class BODY>
 inline void launch(const DcTilePlanT& L, const int* plan, const float* coefT, int C, BODY body, hipStream_t s) {

@@ -46,3 +46,26 @@ bool dc_ensure_lds(unsigned long long* done_mask, const void* kernel, size_t byt
     if (bit) __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
     return true;
 }
+
+// ---- device-clock stamps (common.h) --------------------------------------------------------------------------------------
+static unsigned long long* g_stamp_buf = nullptr;
+static int g_stamp_slots = 0, g_stamp_used = 0;
+static int g_stamp_tags[4096];
+unsigned long long* dc_stamp_next(int tag) {
+    if (!g_stamp_buf || g_stamp_used >= g_stamp_slots) return nullptr;
+    g_stamp_tags[g_stamp_used] = tag;
+    return g_stamp_buf + 4 * (size_t)g_stamp_used++;
+}
+// buf: device memory of slots x 4 x 8 bytes (NULL / 0 disarms); restarts the record counter
+DC_EXPORT int dc_stamp_buffer(uint64_t* buf, int32_t slots) {
+    if (slots < 0 || slots > 4096) {
+        dc_set_error("dc_stamp_buffer: at most 4096 records");
+        return DC_ERR_ARG;
+    }
+    g_stamp_buf = reinterpret_cast<unsigned long long*>(buf);
+    g_stamp_slots = buf ? slots : 0;
+    g_stamp_used = 0;
+    return DC_OK;
+}
+DC_EXPORT int32_t dc_stamp_count(void) { return g_stamp_used; }
+DC_EXPORT int32_t dc_stamp_tag(int32_t record) { return (record >= 0 && record < g_stamp_used) ? g_stamp_tags[record] : -1; }

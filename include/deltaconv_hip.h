@@ -45,6 +45,16 @@ const char* dc_last_error(void);
  * 9: value 1 = ignore pre-split weight planes (every product splits its weight operand in the K loop, as in round 3). */
 int dc_set_option(int32_t key, int32_t value);
 
+/* Measurement aid (bench.py `roofline.frac`): device-clock stamps of the tiled two-piece forward applies and the tiled transposed applies.  After
+ * dc_stamp_buffer(buf, slots) every launch of that family takes the next 4 x uint64 record of `buf` AT ENQUEUE TIME (a launch
+ * captured into a HIP graph keeps its record across replays): [0] earliest workgroup entry, [1] latest workgroup exit with
+ * its stores complete, constant 100 MHz clock; the caller sets [0] = huge, [1] = 0 before a replay.  dc_stamp_tag(record) =
+ * 1000 * kind + channels (forward: kind 1 = div|curl|norm, 2 = hodge, 3 = div; transposed: 11 = div|curl|norm^T, 12 = hodge^T,
+ * 13 = grad^T (+ sum), 14 = max-aggregation backward, 15 = div^T, 16 = layer-0 edge MLP backward).  buf = NULL disarms (the product default). */
+int dc_stamp_buffer(uint64_t* buf, int32_t slots);
+int32_t dc_stamp_count(void);
+int32_t dc_stamp_tag(int32_t record);
+
 /* ---- graph ------------------------------------------------------------------------------- */
 /* knn_graph(pos, k, batch, loop=True, flow='target_to_source')  (torch_cluster via
  * torch_geometric) -- deltaconv/models/deltanet_base.py:52,63.

@@ -244,10 +244,14 @@ def test_pinned_slots_step_vs_oracle(name, clouds, monkeypatch):
         rows.append((float((g1 - g3).abs().sum()) / l1, float((g2 - g3).abs().sum()) / l1, float((g1 - g3).abs().max()) / scale,
                      float((g2 - g3).abs().max()) / scale, scale / gmax, n1))
     rows.sort(reverse=True)
-    print(f"{name} pinned slots: logits {e_log:.2e}; worst parameters by L1 error (hip L1, oracle32 L1, hip max, oracle32 max, own scale / largest):")
+    e_log32 = rel_err(l32, l64)
+    print(f"{name} pinned slots: logits {e_log:.2e} (oracle32 {e_log32:.2e}); worst parameters by L1 error (hip L1, oracle32 L1, hip max, oracle32 max, own scale / largest):")
     for r in rows[:5]:
         print(f"   hip {r[0]:.2e}  oracle32 {r[1]:.2e}  | max norm: hip {r[2]:.2e}  oracle32 {r[3]:.2e}  scale {r[4]:.1e}  {r[5]}")
     med = sorted(r[0] for r in rows)[len(rows) // 2]
     print(f"   median hip L1 {med:.2e}; worst max-norm: hip {max(r[2] for r in rows):.2e}  oracle32 {max(r[3] for r in rows):.2e}")
-    assert e_log < 1e-4
+    # logits: flat 1e-4 with given normals (measured 2e-6 .. 5e-6); the noisy no-normals configuration (5 % outliers, jitter,
+    # lambda = 1e-2) is an order more rounding-sensitive in ANY fp32 implementation -- the oracle's own fp32 run sits at
+    # ~1e-4 of its fp64 run there (printed) -- flat 5e-4 (measured 1.7e-4)
+    assert e_log < (1e-4 if normals else 5e-4)
     assert rows[0][0] < 3e-3, rows[0]

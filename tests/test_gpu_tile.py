@@ -252,3 +252,39 @@ def test_model_identical_with_and_without_plan(kind):
     o0, g0 = run(False)
     assert torch.equal(o1, o0)
     assert len(g1) == len(g0) and all(torch.equal(a_, b_) for a_, b_ in zip(g1, g0))
+
+
+def test_device_clock_stamps_of_the_tiled_applies():
+    """dc_stamp_buffer (bench.py's in-step `roofline.frac`): armed, every tiled two-piece forward apply and tiled transposed
+    apply takes the next record at enqueue time -- [earliest entry, latest exit] on a 100 MHz clock, tag = 1000 * kind +
+    channels -- and computes the same bits as without stamps; disarmed, launches take no record."""
+    from deltaconv_amd import _ops
+    from deltaconv_amd._lib import lib
+    b, gr, grad, div = _setup((1024,) * 8, 20)
+    assert gr.tile_plan() is not None and gr.tile_plan_T() is not None
+    n, C = gr.n, 64
+    v = torch.randn(2 * n, C, device=DEV)
+    ref = torch.empty(n, 3 * C, device=DEV)
+    _ops.fwd_apply("div_curl_norm", div, v, C, C, ref, 3 * C)
+    stamps = torch.zeros(8, 4, dtype=torch.int64, device=DEV)
+    stamps[:, 0] = 2 ** 62
+    assert lib.raw("dc_stamp_buffer")(stamps.data_ptr(), 8) == 0
+    try:
+        out = torch.empty_like(ref)
+        _ops.fwd_apply("div_curl_norm", div, v, C, C, out, 3 * C)
+        dcn = torch.randn(n, 3 * C, device=DEV)
+        dv = torch.zeros(2 * n, C, device=DEV)
+        _ops.bwd_div_curl_norm(div, dcn, C, 3 * C, v, C, dv, C, 0)
+        used = lib.raw("dc_stamp_count")()
+        tags = [lib.raw("dc_stamp_tag")(i) for i in range(used)]
+    finally:
+        lib.raw("dc_stamp_buffer")(None, 0)
+    torch.cuda.synchronize()
+    assert tags == [1064, 11064] and lib.raw("dc_stamp_tag")(5) == -1
+    assert torch.equal(out, ref)
+    rec = stamps.cpu()
+    us = (rec[:2, 1] - rec[:2, 0]).double() * 1e-2
+    assert bool((us > 1.0).all()) and bool((us < 2000.0).all()), us           # a few us each (first launches: cold)
+    assert int(rec[2, 0]) == 2 ** 62 and int(rec[2, 1]) == 0                  # untouched records
+    _ops.fwd_apply("div_curl_norm", div, v, C, C, out, 3 * C)                 # disarmed: no record taken, same bits
+    assert lib.raw("dc_stamp_count")() == 0 and torch.equal(out, ref)

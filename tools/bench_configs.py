@@ -14,19 +14,14 @@ from deltaconv_amd.data import synthetic_batch
 from deltaconv_amd.utils import calc_loss
 from deltaconv_amd.graph_step import GraphedTrainStep
 
-CONFIGS = {
-    # name: (B, N, k, normals, kind, model kwargs, batch kwargs, optimizer)
-    "C1 modelnet40 B=2 (min. train batch)": (2, 1024, 20, True, "cls", dict(in_channels=3, num_classes=40), {}, "sgd"),
-    "C2 modelnet40 B=32": (32, 1024, 20, True, "cls", dict(in_channels=3, num_classes=40), {}, "sgd"),
-    "C3 scanobjectnn B=32 N=2048 (no normals)": (32, 2048, 20, False, "cls",
-        dict(in_channels=3, num_classes=15, conv_channels=[64, 64, 64, 128], grad_regularizer=1e-2),
-        dict(outlier_frac=0.05, jitter=0.005, num_classes=15), "sgd"),
-    "C4 shapenet B=16 N=2048": (16, 2048, 20, True, "seg", dict(in_channels=3, num_classes=50, categorical_vector=True),
-        dict(dup_frac=0.03, per_point_labels=True, categories=16, num_classes=50), "sgd"),
-    "C5 shapeseg B=8 N=4096 k=30": (8, 4096, 30, True, "seg",
-        dict(in_channels=3, num_classes=8, conv_channels=[128] * 8, mlp_depth=1, embedding_size=512),
-        dict(per_point_labels=True, num_classes=8), "adam"),
-}
+from deltaconv_amd import configs as C
+
+# name: (B, N, k, normals, kind, model kwargs, batch kwargs, optimizer) -- the table of deltaconv_amd/configs.py (+ C1)
+CONFIGS = {"C1 modelnet40 B=2 (min. train batch)": (2, 1024, 20, True, "cls", dict(in_channels=3, num_classes=40), {}, "sgd")}
+_NAMES = {"C2": "C2 modelnet40 B=32", "C3": "C3 scanobjectnn B=32 N=2048 (no normals)", "C4": "C4 shapenet B=16 N=2048",
+          "C5": "C5 shapeseg B=8 N=4096 k=30"}
+for _key, _c in C.CONFIGS.items():
+    CONFIGS[_NAMES[_key]] = (_c["B"], _c["N"], _c["k"], _c["normals"], _c["kind"], _c["model"], _c["batch"], _c["optimizer"])
 
 
 def timed(fn, steps, warmup=3):
