@@ -31,7 +31,11 @@ using dcell::vfma;
 using dcell::vzero;
 
 constexpr int CS = 64;        // channels per slab: 16 lanes x 4
-constexpr int CAP = 248;      // unique rows of a tile kept in LDS
+// unique rows of a tile kept in LDS (~165 unique rows per tile of 64 points at k = 20: 127 KB of two-piece rows, one workgroup
+// per CU).  Round-6 lab (profiles/r06_labs.txt): 124 rows for tiles of 32 points -- 64 KB, two workgroups of 512 threads per
+// CU, one's pieces landing while the other walks -- LOSES: div|curl|norm 13.7 -> 17.0 us, the transposed family +45 - 75 %
+// (3.0 x instead of 2.6 x halo rows and twice the per-tile overheads outweigh the overlap); the capacity stays one constant.
+template <int P> constexpr int cap_rows() { return 248; }
 __device__ __forceinline__ void store_nt(float* p, const Vec<4>& a) { dc_store16<DC_ST_TILE>(p, *reinterpret_cast<const dc_f32x4*>(&a)); }
 __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -41,6 +45,7 @@ __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
 template <int R, int P>
 struct Geom {
     static constexpr int NT = P * 16, NW = NT / 64;
+    static constexpr int CAP = cap_rows<P>();
     static constexpr int CAPR = (CAP * R + 4 * NW - 1) / (4 * NW) * (4 * NW);   // capacity in 256-byte pieces
     static constexpr int RIT = CAPR / (4 * NW);                                  // DMA instructions per wave
 };
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(P * 16) void tile_unit_kernel(DcTilePlan L, const i
                                                           int slabs, int remap, BODY body) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GM = Geom<R, P>;
-    constexpr int NW = GM::NW, CAPR = GM::CAPR, RIT = GM::RIT;
+    constexpr int NW = GM::NW, CAP = GM::CAP, CAPR = GM::CAPR, RIT = GM::RIT;
     const long b = dc_xcd_block(remap);
     const long tile = b / slabs;
     const int cb = (int)(b - tile * slabs) * CS;
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(P * 16) void tile_fwd_kernel(DcTilePlan L, const in
                                                           const BODY body0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GM = Geom<R, P>;
-    constexpr int NW = GM::NW, CAPR = GM::CAPR, RIT = GM::RIT;
+    constexpr int NW = GM::NW, CAP = GM::CAP, CAPR = GM::CAPR, RIT = GM::RIT;
     // Work unit = (tile, 64-channel slab); a workgroup owns `upw` CONSECUTIVE units (the slabs of a tile, then the next
     // tile of the same cloud: one set of row ids serves all slabs of its tile, and the ids of the next tile are requested
     // behind the DMA pieces of the current one, so their round trip -- a quarter of a workgroup's life when every unit

@@ -30,18 +30,19 @@ using dcell::G2;
 using dcell::Vec;
 using dcell::vfma;
 using dcell::vzero;
-using dctile::CAP;
 using dctile::CS;
 using dctile::dma16;
 using dctile::Geom;
 
-constexpr int ECAP = 2560;   // in-edge entries of a tile kept in LDS (mean P * k: 1280 at P = 64, k = 20; 1920 at k = 30)
+// in-edge entries of a tile kept in LDS (mean P * k: 1280 at P = 64, k = 20; 1920 at k = 30)
+template <int P> constexpr int ecap_entries() { return 2560; }
 
 template <int FAMILY>
 __device__ __forceinline__ void st16(float* p, const Vec<4>& a) { dc_store16<FAMILY>(p, *reinterpret_cast<const dc_f32x4*>(&a)); }
 
 template <int R, int P>
 inline size_t lds_bytes(bool coef, bool arg) {
+    constexpr int ECAP = ecap_entries<P>(), CAP = Geom<R, P>::CAP;
     return (size_t)Geom<R, P>::CAPR * 256 + (coef ? (size_t)ECAP * 8 : 0) + (size_t)ECAP * 4 + (arg ? (size_t)(CAP + 8) * 64 : 0) + 16;
 }
 
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(P * 16) void tileT_kernel(DcTilePlanT L, const int*
                                                        const BODY body0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using GM = Geom<R, P>;
-    constexpr int NW = GM::NW, CAPR = GM::CAPR, RIT = GM::RIT;
+    constexpr int NW = GM::NW, CAP = GM::CAP, CAPR = GM::CAPR, RIT = GM::RIT, ECAP = ecap_entries<P>();
     const long units = (long)L.T * slabs;
     const long u0 = dc_xcd_block(remap) * upw, u1 = min(u0 + (long)upw, units);
     if (u0 >= u1) return;
