@@ -1,4 +1,4 @@
-// Training loss in two launches: label-smoothed / plain mean cross entropy and its gradient.
+// Training loss in two launches (one for <= 64 rows, round 6): label-smoothed / plain mean cross entropy and its gradient.
 // Replaces ~25 tiny ATen launches (log_softmax, gather, sums, mean and their backward) of
 // /root/reference/experiments/utils.py:7-24 per step; at [32 x 40] logits those are pure launch latency.
 //   ce_rows_kernel : wave = row (lanes stride the classes), writes d loss / d logits and one fp64
@@ -66,6 +66,52 @@ __global__ __launch_bounds__(64) void ce_final_kernel(const double* __restrict__
     if (threadIdx.x == 0) *loss = (float)(s / (double)R);
 }
 
+// <= 64 rows (the classification nets: one logits row per cloud): ONE workgroup, wave = row(s), the row losses meet in LDS and
+// one wave adds them in exactly the association of the two-launch form below (blocks of WAVES rows in row order, lane b the
+// blocks b, b + 64, ..., then the butterfly): same bits, one launch less in a launch-bound corner of the step.
+constexpr int SMALL_ROWS = 64, SMALL_WAVES = 16;
+__global__ __launch_bounds__(64 * SMALL_WAVES) void ce_small_kernel(const float* __restrict__ x, long ldx,
+                                                                    const long* __restrict__ label, int R, int C, float eps,
+                                                                    float* __restrict__ dx, long lddx, float* __restrict__ loss) {
+    __shared__ double rowloss[SMALL_ROWS];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float inv_rows = 1.f / (float)R, q_off = dcloss::ce_q_off(C, eps), q_on = 1.f - eps;
+    for (int r = w; r < R; r += SMALL_WAVES) {
+        const float* xr = x + (long)r * ldx;
+        float m = -INFINITY;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+        m = dc_wave_max(m);
+        float se = 0.f, sx = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float v = xr[c];
+            se += expf(v - m);
+            sx += v;
+        }
+        se = dc_wave_sum(se);
+        sx = dc_wave_sum(sx);
+        const float lse = m + logf(se);
+        const long y = label[r];
+        const bool ok = y >= 0 && y < C;
+        const float bad = ok ? 0.f : nanf("");
+        for (int c = lane; c < C; c += 64)
+            dx[(long)r * lddx + c] = dcloss::ce_grad(xr[c], lse, (ok && c == y) ? q_on : q_off, inv_rows) + bad;
+        if (lane == 0) rowloss[r] = (double)(dcloss::ce_row_loss(ok ? xr[y] : 0.f, sx, lse, C, eps) + bad);
+    }
+    __syncthreads();
+    if (w == 0) {
+        const int nb = (R + WAVES - 1) / WAVES;           // the blocks of the two-launch form (rows_per_wave = 1 here)
+        double s = 0.0;
+        for (int b = lane; b < nb; b += 64) {
+            double part = 0.0;
+            for (int q = 0; q < WAVES; ++q)
+                if (b * WAVES + q < R) part += rowloss[b * WAVES + q];
+            s += part;
+        }
+        s = dc_wave_sum(s);
+        if (lane == 0) *loss = (float)(s / (double)R);
+    }
+}
+
 }  // namespace
 
 DC_EXPORT size_t dc_ce_loss_workspace_bytes(int64_t num_rows) {
@@ -84,6 +130,13 @@ DC_EXPORT int dc_ce_loss(const float* logits, int64_t ld_logits, const int64_t* 
         return DC_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (num_rows <= SMALL_ROWS) {
+        hipLaunchKernelGGL(ce_small_kernel, dim3(1), dim3(64 * SMALL_WAVES), 0, s, logits, (long)ld_logits,
+                           reinterpret_cast<const long*>(labels), (int)num_rows, num_classes, smoothing, dlogits,
+                           (long)ld_dlogits, loss);
+        DC_CHECK_LAUNCH("dc_ce_loss");
+        return DC_OK;
+    }
     const int rpw = rows_per_wave(num_rows);
     const int nb = dc_cdiv(num_rows, WAVES * rpw);
     double* partial = static_cast<double*>(workspace);

@@ -19,16 +19,24 @@ namespace {
 
 constexpr int AVG_THREADS = 1024;
 
+// The first launch of the assembly also does the two pieces of per-cloud / per-point set-up that used to be launches of their
+// own (round 6: -2 launches per step): it clears the cloud's infinity-norm word (mls_fit's atomicMax target) and, when
+// `normal` is given, writes the tangent frames of build_tangent_basis (grad_div_mls.py:50-69; same function, same bits as
+// dc_tangent_basis) that mls_fit / mls_div read afterwards.
 __global__ __launch_bounds__(AVG_THREADS) void mls_avgdist_kernel(const float* __restrict__ pos,
                                                                   const int* __restrict__ nbr,
                                                                   const int* __restrict__ cloud_ptr, int k,
-                                                                  double* __restrict__ avg) {
+                                                                  double* __restrict__ avg, unsigned* __restrict__ inf_bits,
+                                                                  const float* __restrict__ normal, float* __restrict__ xb,
+                                                                  float* __restrict__ yb) {
     __shared__ double part[AVG_THREADS / 64];
     const int cloud = blockIdx.x;
     const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
+    if (threadIdx.x == 0) inf_bits[cloud] = 0u;
     double acc = 0;
     for (int q = threadIdx.x; q < n; q += AVG_THREADS) {
         const long i = begin + q;
+        if (normal) dcmath::tangent_basis_point(normal + 3 * i, xb + 3 * i, yb + 3 * i);
         acc += dcmath::point_dist_sum(pos, nbr + i * k, i, k) / k;  // dist.mean(dim=1) (:112)
     }
     acc = dc_wave_sum(acc);
@@ -186,7 +194,7 @@ DC_EXPORT size_t dc_mls_workspace_bytes(int32_t num_clouds, int32_t num_points) 
 }
 
 namespace {
-int mls_assemble(const char* name, const float* pos, const float* normal, const float* x_basis, const float* y_basis,
+int mls_assemble(const char* name, const float* pos, const float* normal, float* x_basis, float* y_basis, bool make_basis,
                  const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
                  int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer, bool shape,
                  float shape_regularizer, int32_t normalized, float* G, float* D, void* workspace,
@@ -211,8 +219,8 @@ int mls_assemble(const char* name, const float* pos, const float* normal, const 
     unsigned* inf_bits = reinterpret_cast<unsigned*>(ws + align_up((size_t)num_clouds * 8, 256));
     double* coef = reinterpret_cast<double*>(ws + align_up((size_t)num_clouds * 8, 256) +
                                              align_up((size_t)num_clouds * 4, 256));
-    dc_zero_words(inf_bits, num_clouds, s);
-    hipLaunchKernelGGL(mls_avgdist_kernel, dim3(num_clouds), dim3(AVG_THREADS), 0, s, pos, nbr, cloud_ptr, k, avg);
+    hipLaunchKernelGGL(mls_avgdist_kernel, dim3(num_clouds), dim3(AVG_THREADS), 0, s, pos, nbr, cloud_ptr, k, avg, inf_bits,
+                       make_basis ? normal : nullptr, x_basis, y_basis);
     const dim3 grid(dc_cdiv(max_cloud_size, 128), num_clouds);
     if (shape)
         hipLaunchKernelGGL(mls_fit_kernel<true>, grid, dim3(128), 0, s, pos, normal, x_basis, y_basis, nbr, cloud_ptr, k,
@@ -236,8 +244,20 @@ DC_EXPORT int dc_mls_assemble(const float* pos, const float* normal, const float
                               int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer,
                               int32_t normalized, float* G, float* D, void* workspace, size_t workspace_bytes,
                               void* stream) {
-    return mls_assemble("dc_mls_assemble", pos, normal, x_basis, y_basis, nbr, cloud_ptr, num_clouds, num_points,
-                        max_cloud_size, k, kernel_width, regularizer, false, 0.f, normalized, G, D, workspace,
+    return mls_assemble("dc_mls_assemble", pos, normal, const_cast<float*>(x_basis), const_cast<float*>(y_basis), false, nbr,
+                        cloud_ptr, num_clouds, num_points, max_cloud_size, k, kernel_width, regularizer, false, 0.f, normalized,
+                        G, D, workspace, workspace_bytes, stream);
+}
+
+// build_tangent_basis + build_grad_div in one call (deltanet_base.py:59-61,69 with normals given): x_basis / y_basis are
+// OUTPUTS, written by the first launch of the assembly -- the model's path; same bits as dc_tangent_basis + dc_mls_assemble
+DC_EXPORT int dc_mls_assemble_normals(const float* pos, const float* normal, const int32_t* nbr, const int32_t* cloud_ptr,
+                                      int32_t num_clouds, int32_t num_points, int32_t max_cloud_size, int32_t k,
+                                      float kernel_width, float regularizer, int32_t normalized, float* x_basis,
+                                      float* y_basis, float* G, float* D, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    return mls_assemble("dc_mls_assemble_normals", pos, normal, x_basis, y_basis, true, nbr, cloud_ptr, num_clouds,
+                        num_points, max_cloud_size, k, kernel_width, regularizer, false, 0.f, normalized, G, D, workspace,
                         workspace_bytes, stream);
 }
 
@@ -248,9 +268,9 @@ DC_EXPORT int dc_mls_assemble_shape(const float* pos, const float* normal, const
                                     int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer,
                                     float shape_regularizer, int32_t normalized, float* G, float* D, void* workspace,
                                     size_t workspace_bytes, void* stream) {
-    return mls_assemble("dc_mls_assemble_shape", pos, normal, x_basis, y_basis, nbr, cloud_ptr, num_clouds, num_points,
-                        max_cloud_size, k, kernel_width, regularizer, true, shape_regularizer, normalized, G, D,
-                        workspace, workspace_bytes, stream);
+    return mls_assemble("dc_mls_assemble_shape", pos, normal, const_cast<float*>(x_basis), const_cast<float*>(y_basis), false,
+                        nbr, cloud_ptr, num_clouds, num_points, max_cloud_size, k, kernel_width, regularizer, true,
+                        shape_regularizer, normalized, G, D, workspace, workspace_bytes, stream);
 }
 
 // ---- stage entry points (the reference's public helpers, grad_div_mls.py:72,100,119,155) ------------------------

@@ -206,7 +206,8 @@ def fit_vector_mapping(pos, normal, x_basis, y_basis, edge_index, wls, coords):
 
 def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel_width=1, regularizer=0.001,
                    normalized=True, shape_regularizer=None):
-    """grad_div_mls.py:197-277 -> (grad, div) as SparseOp."""
+    """grad_div_mls.py:197-277 -> (grad, div) as SparseOp.  x_basis = y_basis = None (this package's models when the data
+    carries normals): the frames of build_tangent_basis(normal) are formed inside the assembly (dc_mls_assemble_normals)."""
     require_gpu()
     pos = pos.contiguous().float()
     n = pos.shape[0]
@@ -219,7 +220,12 @@ def build_grad_div(pos, normal, x_basis, y_basis, edge_index, batch=None, kernel
     D = torch.empty(n, g.k, 2, dtype=torch.float32, device=pos.device)
     nbytes = lib.raw("dc_mls_workspace_bytes")(g.num_clouds, n)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=pos.device)
-    if shape_regularizer is None:
+    if x_basis is None and y_basis is None and shape_regularizer is None:
+        xb = torch.empty(n, 3, dtype=torch.float32, device=pos.device)
+        yb = torch.empty(n, 3, dtype=torch.float32, device=pos.device)
+        lib.call("dc_mls_assemble_normals", pos, normal.contiguous().float(), g.nbr, g.ptr, g.num_clouds, n, g.max_cloud, g.k,
+                 float(kernel_width), float(regularizer), int(bool(normalized)), xb, yb, G, D, ws, ws.numel() * 8)
+    elif shape_regularizer is None:
         lib.call("dc_mls_assemble", pos, normal.contiguous().float(), x_basis.contiguous().float(),
                  y_basis.contiguous().float(), g.nbr, g.ptr, g.num_clouds, n, g.max_cloud, g.k, float(kernel_width),
                  float(regularizer), int(bool(normalized)), G, D, ws, ws.numel() * 8)

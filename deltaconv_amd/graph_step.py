@@ -141,11 +141,18 @@ class GraphedTrainStep:
         s = self.static
         if batch is s:
             return
+        dsts, srcs = [], []
         for name in ("pos", "norm", "x", "y", "category"):
             dst, src = getattr(s, name, None), getattr(batch, name, None)
             if dst is not None:
                 assert src is not None and src.shape == dst.shape, f"batch.{name}: static shape {tuple(dst.shape)}"
-                dst.copy_(src, non_blocking=True)
+                if src.device == dst.device and src.dtype == dst.dtype:
+                    dsts.append(dst)
+                    srcs.append(src)
+                else:
+                    dst.copy_(src, non_blocking=True)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)      # one multi-tensor launch per dtype instead of one copy per tensor
 
     def __call__(self, batch=None):
         if batch is not None:

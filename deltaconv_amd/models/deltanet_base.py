@@ -103,7 +103,7 @@ class DeltaNetBase(torch.nn.Module):
         graph = Graph.knn(pos, self.k, ptr_info=info)
         if hasattr(data, 'norm') and data.norm is not None:
             normal = data.norm
-            x_basis, y_basis = build_tangent_basis(normal)
+            x_basis = y_basis = None           # build_tangent_basis inside the assembly's first launch (dc_mls_assemble_normals)
         else:
             graph_normal = Graph.knn(pos, 10, ptr_info=info)
             normal, x_basis, y_basis = estimate_basis(pos, graph_normal, orientation=pos)

@@ -97,6 +97,13 @@ int dc_mls_assemble(const float* pos, const float* normal, const float* x_basis,
                     const int32_t* nbr, const int32_t* cloud_ptr, int32_t num_clouds, int32_t num_points,
                     int32_t max_cloud_size, int32_t k, float kernel_width, float regularizer, int32_t normalized,
                     float* G, float* D, void* workspace, size_t workspace_bytes, void* stream);
+/* build_tangent_basis + build_grad_div in one call -- the model's path when normals are given (deltanet_base.py:59-61,69):
+ * x_basis / y_basis [Nt,3] are OUTPUTS (written by the assembly's first launch); same values as dc_tangent_basis followed
+ * by dc_mls_assemble, two launches fewer. */
+int dc_mls_assemble_normals(const float* pos, const float* normal, const int32_t* nbr, const int32_t* cloud_ptr,
+                            int32_t num_clouds, int32_t num_points, int32_t max_cloud_size, int32_t k, float kernel_width,
+                            float regularizer, int32_t normalized, float* x_basis, float* y_basis, float* G, float* D,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* build_grad_div(..., shape_regularizer=s) -- grad_div_mls.py:241-244,266-267 (weighted_least_squares :146-150): the
  * gradient rows come from the fit regularised by `regularizer`, the surface coefficients behind the divergence rows
  * (fit_vector_mapping) from a second fit regularised by `shape_regularizer`. */

@@ -302,7 +302,8 @@ def test_bn_act_pool_fused(with_mean, train, B, N, C):
 
 
 @pytest.mark.parametrize("R,C,smoothing,strided", [(32, 40, True, False), (32768, 50, False, False), (1, 2, True, False),
-                                                    (100, 15, True, True), (7, 8, False, True)])
+                                                    (100, 15, True, True), (7, 8, False, True), (64, 40, True, False),
+                                                    (65, 40, True, True), (33, 130, False, False)])
 def test_fused_loss_matches_oracle(R, C, smoothing, strided):
     """dc_ce_loss (value + gradient, scaled by the incoming gradient) == experiments/utils.py:7-24 as restated
     in oracle/loss.py, incl. logits that are a column slice of a wider matrix."""
