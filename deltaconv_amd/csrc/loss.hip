@@ -130,7 +130,7 @@ DC_EXPORT int dc_ce_loss(const float* logits, int64_t ld_logits, const int64_t* 
         return DC_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (num_rows <= SMALL_ROWS) {
+    if (num_rows <= SMALL_ROWS && !dc_option(DC_OPT_CE_TWO_LAUNCH)) {
         hipLaunchKernelGGL(ce_small_kernel, dim3(1), dim3(64 * SMALL_WAVES), 0, s, logits, (long)ld_logits,
                            reinterpret_cast<const long*>(labels), (int)num_rows, num_classes, smoothing, dlogits,
                            (long)ld_dlogits, loss);

@@ -77,4 +77,29 @@ DC_HD void vn_bwd_dy(float yu, float yv, float du, float dv, float scale, float 
     dyv = fmaf(dv, s, w * yv);
 }
 
+// ---- dropout inside the row-block kernels (round 6) -------------------------------------------------------------------------
+// torch.nn.Dropout(p) between the blocks of the classification head (deltanet_classification.py:34-36): keep with
+// probability 1 - p, scale the kept values by 1 / (1 - p).  The draws come from Philox-4x32-10 (Salmon et al., SC'11; the
+// generator torch itself uses) keyed by the process seed, counter = (element, layer salt, training-step counter of the
+// block's BatchNorm = its num_batches_tracked, read on the device: a new mask in every replay of a captured step).
+// Mask streams differ from ATen's (another counter layout) -- no implementation-independent dropout stream exists.
+struct U4 {
+    unsigned x, y, z, w;
+};
+DC_HD unsigned mulhi32(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * (unsigned long long)b) >> 32); }
+DC_HD U4 philox4x32_10(U4 c, unsigned k0, unsigned k1) {
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = mulhi32(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = mulhi32(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = U4{hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+DC_HD bool dropout_keep(unsigned seed, long long step, unsigned salt, unsigned element, float p) {
+    const U4 r = philox4x32_10(U4{element, salt, (unsigned)step, (unsigned)((unsigned long long)step >> 32)}, seed, 0x64726F70u);
+    return (float)(r.x >> 8) * (1.0f / 16777216.0f) >= p;      // 24 uniform bits in [0, 1)
+}
+
 }  // namespace dcnn

@@ -92,7 +92,8 @@ __global__ __launch_bounds__(TPB * KSlices<CW>::KS) void rowblock_fwd_kernel(
     const float* __restrict__ X, long ldx, const float* __restrict__ W, long ldw, const float* __restrict__ bias, int M, int N,
     int K, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
     float* __restrict__ rvar, int mode, float slope, float* __restrict__ H, long ldh, float* __restrict__ coef,
-    float* __restrict__ Y, long ldy) {
+    float* __restrict__ Y, long ldy, float drop_p, unsigned seed, const long long* __restrict__ step, unsigned salt,
+    unsigned char* __restrict__ mask) {
     constexpr int RM = RB<CW>::RM, KS = KSlices<CW>::KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ks = threadIdx.x / TPB, tid = threadIdx.x - ks * TPB;           // k-slice, thread inside its 4 wavefronts
@@ -193,7 +194,13 @@ __global__ __launch_bounds__(TPB * KSlices<CW>::KS) void rowblock_fwd_kernel(
     }
     if (ok) {
         H[(long)m * ldh + n] = h;
-        Y[(long)m * ldy + n] = act(fmaf(scale, h, shift), slope);
+        float y = act(fmaf(scale, h, shift), slope);
+        if (drop_p > 0.f) {                                // Dropout(p) behind the block: mask kept for the backward pass
+            const bool keep = dcnn::dropout_keep(seed, *step, salt, (unsigned)(m * N + n), drop_p);
+            mask[(long)m * N + n] = keep ? 1 : 0;
+            y = keep ? y * (1.f / (1.f - drop_p)) : 0.f;
+        }
+        Y[(long)m * ldy + n] = y;
     }
 }
 
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(TPB * KSlices<CW>::KSB) void rowblock_bwd_kernel(
     const float* __restrict__ dY, long lddy, const float* __restrict__ H, long ldh, const float* __restrict__ coef,
     const float* __restrict__ gamma, float slope, int mode, const float* __restrict__ X, long ldx, int M, int N, int K,
     float* __restrict__ dW, long lddw, float* __restrict__ dbias, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dH, long lddh) {
+    float* __restrict__ dH, long lddh, const unsigned char* __restrict__ mask, float keep_scale) {
     constexpr int RM = RB<CW>::RM, KS = KSlices<CW>::KSB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ks = threadIdx.x / TPB, tid = threadIdx.x - ks * TPB;
@@ -211,7 +218,8 @@ __global__ __launch_bounds__(TPB * KSlices<CW>::KSB) void rowblock_bwd_kernel(
     const int n0 = (blockIdx.x * (TPB / 64) + wave) * CW;
     const int c = lane / RM, m = lane - c * RM, n = n0 + c;
     const bool col = n < N, ok = col && m < M;
-    const float dy = ok ? dY[(long)m * lddy + n] : 0.f;
+    float dy = ok ? dY[(long)m * lddy + n] : 0.f;
+    if (mask && ok) dy = mask[(long)m * N + n] ? dy * keep_scale : 0.f;      // backward of the Dropout behind the block
     float dh;
     if (mode == 0) {
         dh = dy;
@@ -280,11 +288,14 @@ DC_EXPORT int32_t dc_rowblock_max_rows(void) { return 64; }
 // H[M,N] = X[M,K] W[N,K]^T (+ bias); mode 1 / 2: coef[4,N] = (mean, invstd, scale, shift) of the BatchNorm over the M
 // rows (batch statistics, running statistics updated when given / running statistics), Y = leaky_slope(scale H + shift).
 // mode 0: Y = H (Y may alias H).  M <= dc_rowblock_max_rows(), K % 4 == 0, 16-byte aligned rows of X and W.
-DC_EXPORT int dc_rowblock_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int32_t M,
-                                  int32_t N, int32_t K, const float* gamma, const float* beta, float eps, float momentum,
-                                  float* running_mean, float* running_var, int32_t mode, float slope, float* H, int64_t ldh,
-                                  float* coef, float* Y, int64_t ldy, void* stream) {
+static int rowblock_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int32_t M,
+                            int32_t N, int32_t K, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, int32_t mode, float slope, float* H, int64_t ldh,
+                            float* coef, float* Y, int64_t ldy, float drop_p, unsigned seed, const long long* step,
+                            unsigned salt, unsigned char* mask, void* stream) {
     DC_REQUIRE(X && W && H && Y, "dc_rowblock_forward: null pointer");
+    DC_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || (mode != 0 && step && mask)),
+               "dc_rowblock_forward_dropout: 0 <= p < 1, a BatchNorm block, its step counter and a mask buffer");
     DC_REQUIRE(M >= 1 && M <= 64 && N >= 1 && K >= 4 && K % 4 == 0 && ldx >= K && ldw >= K && ldh >= N && ldy >= N,
                "dc_rowblock_forward: bad size (1 <= M <= 64, K %% 4 == 0)");
     DC_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && aligned16(X) && aligned16(W), "dc_rowblock_forward: rows must be 16-byte aligned");
@@ -301,21 +312,45 @@ DC_EXPORT int dc_rowblock_forward(const float* X, int64_t ldx, const float* W, i
     }
     if (M <= 32)
         hipLaunchKernelGGL((rowblock_fwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB * 4), lds, s, X, (long)ldx, W, (long)ldw, bias, M, N, K,
-                           gamma, beta, eps, momentum, running_mean, running_var, mode, slope, H, (long)ldh, coef, Y, (long)ldy);
+                           gamma, beta, eps, momentum, running_mean, running_var, mode, slope, H, (long)ldh, coef, Y, (long)ldy, drop_p,
+                           seed, step, salt, mask);
     else
         hipLaunchKernelGGL((rowblock_fwd_kernel<1>), dim3(dc_cdiv(N, 4)), dim3(TPB * 2), lds, s, X, (long)ldx, W, (long)ldw, bias, M, N, K,
-                           gamma, beta, eps, momentum, running_mean, running_var, mode, slope, H, (long)ldh, coef, Y, (long)ldy);
+                           gamma, beta, eps, momentum, running_mean, running_var, mode, slope, H, (long)ldh, coef, Y, (long)ldy, drop_p,
+                           seed, step, salt, mask);
     DC_CHECK_LAUNCH("dc_rowblock_forward");
     return DC_OK;
+}
+
+DC_EXPORT int dc_rowblock_forward(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, int32_t M,
+                                  int32_t N, int32_t K, const float* gamma, const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var, int32_t mode, float slope, float* H, int64_t ldh,
+                                  float* coef, float* Y, int64_t ldy, void* stream) {
+    return rowblock_forward(X, ldx, W, ldw, bias, M, N, K, gamma, beta, eps, momentum, running_mean, running_var, mode, slope, H,
+                            ldh, coef, Y, ldy, 0.f, 0u, nullptr, 0u, nullptr, stream);
+}
+
+// The block followed by torch.nn.Dropout(p) (deltanet_classification.py:34-36) in the same launch: Y = dropout(act(bn(X W^T))),
+// mask[M, N] (1 = kept) for dc_rowblock_backward_dropout.  Draws: Philox-4x32-10 keyed by `seed`, counter (element, salt,
+// *step) -- `step` = the block's BatchNorm num_batches_tracked on the device (advances once per training step: a new mask in
+// every replay of a captured graph), `salt` tells the dropout layers of a model apart.
+DC_EXPORT int dc_rowblock_forward_dropout(const float* X, int64_t ldx, const float* W, int64_t ldw, int32_t M, int32_t N,
+                                          int32_t K, const float* gamma, const float* beta, float eps, float momentum,
+                                          float* running_mean, float* running_var, int32_t mode, float slope, float* H,
+                                          int64_t ldh, float* coef, float* Y, int64_t ldy, float p, int32_t seed,
+                                          const int64_t* step, int32_t salt, uint8_t* mask, void* stream) {
+    return rowblock_forward(X, ldx, W, ldw, nullptr, M, N, K, gamma, beta, eps, momentum, running_mean, running_var, mode, slope,
+                            H, ldh, coef, Y, ldy, p, (unsigned)seed, reinterpret_cast<const long long*>(step), (unsigned)salt,
+                            mask, stream);
 }
 
 // Backward of dc_rowblock_forward up to the input gradient: dH[M,N] = BatchNorm / activation backward of dY (mode 0:
 // dH = dY), d gamma / d beta (mode 0: d bias) and dW[N,K] = dH^T X (skipped when dW is NULL).  d X = dH W is
 // dc_linear_backward_input(dH, W).
-DC_EXPORT int dc_rowblock_backward(const float* dY, int64_t lddy, const float* H, int64_t ldh, const float* coef,
-                                   const float* gamma, float slope, int32_t mode, const float* X, int64_t ldx, int32_t M,
-                                   int32_t N, int32_t K, float* dW, int64_t lddw, float* dbias, float* dgamma, float* dbeta,
-                                   float* dH, int64_t lddh, void* stream) {
+static int rowblock_backward(const float* dY, int64_t lddy, const float* H, int64_t ldh, const float* coef,
+                             const float* gamma, float slope, int32_t mode, const float* X, int64_t ldx, int32_t M,
+                             int32_t N, int32_t K, float* dW, int64_t lddw, float* dbias, float* dgamma, float* dbeta,
+                             float* dH, int64_t lddh, const unsigned char* mask, float keep_scale, void* stream) {
     DC_REQUIRE(dY && dH && (mode == 0 || (H && coef)) && (!dW || X), "dc_rowblock_backward: null pointer");
     DC_REQUIRE(M >= 1 && M <= 64 && N >= 1 && K >= 4 && K % 4 == 0 && lddy >= N && lddh >= N && (!dW || (ldx >= K && lddw >= K)),
                "dc_rowblock_backward: bad size (1 <= M <= 64, K %% 4 == 0)");
@@ -330,10 +365,28 @@ DC_EXPORT int dc_rowblock_backward(const float* dY, int64_t lddy, const float* H
     }
     if (M <= 32)
         hipLaunchKernelGGL((rowblock_bwd_kernel<2>), dim3(dc_cdiv(N, 8)), dim3(TPB * 2), lds, s, dY, (long)lddy, H, (long)ldh, coef, gamma,
-                           slope, mode, X, (long)ldx, M, N, K, dW, (long)lddw, dbias, dgamma, dbeta, dH, (long)lddh);
+                           slope, mode, X, (long)ldx, M, N, K, dW, (long)lddw, dbias, dgamma, dbeta, dH, (long)lddh, mask, keep_scale);
     else
         hipLaunchKernelGGL((rowblock_bwd_kernel<1>), dim3(dc_cdiv(N, 4)), dim3(TPB * 2), lds, s, dY, (long)lddy, H, (long)ldh, coef, gamma,
-                           slope, mode, X, (long)ldx, M, N, K, dW, (long)lddw, dbias, dgamma, dbeta, dH, (long)lddh);
+                           slope, mode, X, (long)ldx, M, N, K, dW, (long)lddw, dbias, dgamma, dbeta, dH, (long)lddh, mask, keep_scale);
     DC_CHECK_LAUNCH("dc_rowblock_backward");
     return DC_OK;
+}
+
+DC_EXPORT int dc_rowblock_backward(const float* dY, int64_t lddy, const float* H, int64_t ldh, const float* coef,
+                                   const float* gamma, float slope, int32_t mode, const float* X, int64_t ldx, int32_t M,
+                                   int32_t N, int32_t K, float* dW, int64_t lddw, float* dbias, float* dgamma, float* dbeta,
+                                   float* dH, int64_t lddh, void* stream) {
+    return rowblock_backward(dY, lddy, H, ldh, coef, gamma, slope, mode, X, ldx, M, N, K, dW, lddw, dbias, dgamma, dbeta, dH, lddh,
+                             nullptr, 1.f, stream);
+}
+
+// Backward of dc_rowblock_forward_dropout: dY is the gradient BEHIND the dropout; mask / p as in the forward call.
+DC_EXPORT int dc_rowblock_backward_dropout(const float* dY, int64_t lddy, const float* H, int64_t ldh, const float* coef,
+                                           const float* gamma, float slope, int32_t mode, const float* X, int64_t ldx, int32_t M,
+                                           int32_t N, int32_t K, float* dW, int64_t lddw, float* dgamma, float* dbeta, float* dH,
+                                           int64_t lddh, const uint8_t* mask, float p, void* stream) {
+    DC_REQUIRE(mask && p > 0.f && p < 1.f && mode != 0, "dc_rowblock_backward_dropout: mask, 0 < p < 1, a BatchNorm block");
+    return rowblock_backward(dY, lddy, H, ldh, coef, gamma, slope, mode, X, ldx, M, N, K, dW, lddw, nullptr, dgamma, dbeta, dH, lddh,
+                             mask, 1.f / (1.f - p), stream);
 }

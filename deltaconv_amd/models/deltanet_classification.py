@@ -5,7 +5,7 @@ from torch.nn import Sequential as Seq, Dropout
 from .deltanet_base import DeltaNetBase, _ptr_info
 from .pool import embed_and_pool
 from ..nn import MLP, fused
-from ..nn.mlp import Linear
+from ..nn.mlp import Linear, run_head
 from ..nn.layer import cat_outputs
 
 
@@ -28,4 +28,4 @@ class DeltaNetClassification(torch.nn.Module):
         conv_out = self.deltanet_base(data)
         # lin_embedding -> [global max | global mean] (deltanet_classification.py:42-49), pooling fused in
         x = embed_and_pool(self.lin_embedding, cat_outputs(conv_out), _ptr_info(data), with_mean=True)
-        return self.classification_head(x)
+        return run_head(self.classification_head, x)      # module by module: Dropout fused into the blocks' kernels

@@ -993,7 +993,8 @@ class _RowBlock(torch.autograd.Function):
     d beta, dW) + the input gradient on the MFMA GEMM.  (models/deltanet_classification.py:34-36; nn/mlp.py:7-11.)"""
 
     @staticmethod
-    def forward(ctx, x, w, gamma, beta, bn, slope):
+    def forward(ctx, x, w, gamma, beta, bn, slope, drop=None):
+        # drop = (p, salt): torch.nn.Dropout(p) behind the block, applied in the block's own kernels (csrc/rowblock.hip)
         x, w = _rowmajor(x), _rowmajor(w)
         m, k = x.shape
         n = w.shape[0]
@@ -1010,16 +1011,23 @@ class _RowBlock(torch.autograd.Function):
         h = torch.empty(m, n, dtype=torch.float32, device=dev)
         y = torch.empty(m, n, dtype=torch.float32, device=dev)
         coef = torch.empty(4, n, dtype=torch.float32, device=dev)
-        lib.call("dc_rowblock_forward", x, x.stride(0), w, w.stride(0), None, m, n, k, gamma, beta, float(bn.eps), mom, rm,
-                 rv, 1 if use_batch else 2, slope, h, n, coef, y, n)
-        ctx.save_for_backward(x, w, h, coef, gamma)
-        ctx.cfg = (use_batch, slope, gamma is not None, beta is not None)
+        mask = None
+        if drop is not None:
+            mask = torch.empty(m, n, dtype=torch.uint8, device=dev)
+            lib.call("dc_rowblock_forward_dropout", x, x.stride(0), w, w.stride(0), m, n, k, gamma, beta, float(bn.eps), mom, rm,
+                     rv, 1 if use_batch else 2, slope, h, n, coef, y, n, float(drop[0]), _seed32(), bn.num_batches_tracked,
+                     int(drop[1]), mask)
+        else:
+            lib.call("dc_rowblock_forward", x, x.stride(0), w, w.stride(0), None, m, n, k, gamma, beta, float(bn.eps), mom, rm,
+                     rv, 1 if use_batch else 2, slope, h, n, coef, y, n)
+        ctx.save_for_backward(x, w, h, coef, gamma, mask)
+        ctx.cfg = (use_batch, slope, gamma is not None, beta is not None, None if drop is None else float(drop[0]))
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, h, coef, gamma = ctx.saved_tensors
-        use_batch, slope, has_g, has_b = ctx.cfg
+        x, w, h, coef, gamma, mask = ctx.saved_tensors
+        use_batch, slope, has_g, has_b, drop_p = ctx.cfg
         dy = _c(dy)
         m, n = dy.shape
         k = x.shape[1]
@@ -1028,10 +1036,14 @@ class _RowBlock(torch.autograd.Function):
         dw = torch.empty(n, k, dtype=torch.float32, device=dev)
         dgamma = torch.empty(n, dtype=torch.float32, device=dev)
         dbeta = torch.empty(n, dtype=torch.float32, device=dev)
-        lib.call("dc_rowblock_backward", dy, dy.stride(0), h, n, coef, gamma, slope, 1 if use_batch else 2, x, x.stride(0),
-                 m, n, k, dw, k, None, dgamma, dbeta, dh, n)
+        if mask is not None:
+            lib.call("dc_rowblock_backward_dropout", dy, dy.stride(0), h, n, coef, gamma, slope, 1 if use_batch else 2, x,
+                     x.stride(0), m, n, k, dw, k, dgamma, dbeta, dh, n, mask, drop_p)
+        else:
+            lib.call("dc_rowblock_backward", dy, dy.stride(0), h, n, coef, gamma, slope, 1 if use_batch else 2, x, x.stride(0),
+                     m, n, k, dw, k, None, dgamma, dbeta, dh, n)
         dx = _rowblock_dx(dh, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, dgamma if has_g else None, dbeta if has_b else None, None, None
+        return dx, dw, dgamma if has_g else None, dbeta if has_b else None, None, None, None
 
 
 class _RowLinear(torch.autograd.Function):
@@ -1101,8 +1113,28 @@ class _LinearBNAct(torch.autograd.Function):
         return (dx, dw, dgamma if has_g else None, dbeta if has_b else None, None, None, (dy if has_res else None))
 
 
-def linear_bn_act(x, lin, bn, slope, residual=None):
-    """[Linear(no bias) -> BatchNorm1d -> leaky(slope)](x) (+ residual); lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d."""
+def _seed32():
+    """The process seed (torch.manual_seed) folded to 31 bits: the key of the row-block dropout streams."""
+    s = int(torch.initial_seed())
+    return (s ^ (s >> 31)) & 0x7fffffff
+
+
+USE_ROWBLOCK_DROPOUT = True     # A/B switch: False = torch.nn.Dropout behind the block (ATen fused_dropout + masked_scale)
+
+
+def rowblock_dropout_ok(x, lin, bn, residual=None):
+    """Can `Dropout` behind the block [lin -> bn -> act] run inside the block's kernels?  (<= 64 rows, a BatchNorm whose
+    num_batches_tracked advances every training step: the device-side counter of the mask stream.)"""
+    return (USE_ROWBLOCK_DROPOUT and lin.bias is None and residual is None and _rowblock_ok(x, lin.weight) and bn.training
+            and bn.track_running_stats and bn.num_batches_tracked is not None and bn.num_batches_tracked.is_cuda)
+
+
+def linear_bn_act(x, lin, bn, slope, residual=None, dropout=None):
+    """[Linear(no bias) -> BatchNorm1d -> leaky(slope)](x) (+ residual); lin: torch.nn.Linear, bn: torch.nn.BatchNorm1d.
+    dropout = (p, salt): only with rowblock_dropout_ok(...) -- Dropout(p) behind the block, in the block's kernels."""
+    if dropout is not None:
+        assert rowblock_dropout_ok(x, lin, bn, residual)
+        return _RowBlock.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope), (float(dropout[0]), int(dropout[1])))
     if lin.bias is None and residual is None and _rowblock_ok(x, lin.weight):
         return _RowBlock.apply(x, lin.weight, bn.weight, bn.bias, bn, float(slope))
     if lin.bias is None and x.dim() == 2 and x.is_cuda and x.dtype == torch.float32:     # (synchronised statistics included)

@@ -23,13 +23,17 @@ Lin = Linear
 class MLPBlock(Seq):
     """[Linear -> BatchNorm1d -> nonlin]; forward(x, residual=None) = nonlin(bn(lin(x))) + residual."""
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, dropout=None):
         lin, bn, act = self[0], self[1], self[2]
         slope = fused.slope_of(act)
         if slope is None:                       # exotic activation: BN fused, activation through torch
             out = act(fused.linear_bn_act(x, lin, bn.bn, 1.0))
             return out if residual is None else out + residual
-        return fused.linear_bn_act(x, lin, bn.bn, slope, residual)
+        return fused.linear_bn_act(x, lin, bn.bn, slope, residual, dropout)
+
+    def dropout_ok(self, x):
+        """Can a Dropout behind this block run inside the block's kernels (fused.rowblock_dropout_ok)?"""
+        return fused.slope_of(self[2]) is not None and fused.rowblock_dropout_ok(x, self[0], self[1].bn)
 
 
 class VectorBlock(Seq):
@@ -82,11 +86,23 @@ def run_mlp(mlp, x, residual=None):
 def run_head(modules, x):
     """A head Sequential (or a slice of one) module by module, with `Linear(bias) -> LeakyReLU | ReLU` pairs run as one
     fused call (deltaconv/models/deltanet_segmentation.py:45-51: Linear(256, 128), LeakyReLU(0.2), Linear(128, classes))."""
-    mods = list(modules)
+    mods = []
+    for mod in modules:                      # an MLP inside a head is a Sequential of blocks: walk the blocks themselves
+        mods.extend(list(mod) if (isinstance(mod, Seq) and len(mod) and all(isinstance(b, MLPBlock) for b in mod)) else [mod])
     i = 0
+    salt = 0
     while i < len(mods):
         mod = mods[i]
         nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if isinstance(nxt, torch.nn.Dropout):
+            salt += 1                        # every Dropout of the head has its own mask stream, fused or not
+            # MLP block -> Dropout (deltanet_classification.py:34-36) on a handful of rows: the dropout runs inside the
+            # block's own kernels (csrc/rowblock.hip) -- four ATen launches fewer per training step
+            if (isinstance(mod, MLPBlock) and nxt.training and 0.0 < nxt.p < 1.0 and not nxt.inplace and torch.is_grad_enabled()
+                    and mod.dropout_ok(x)):
+                x = mod(x, dropout=(nxt.p, salt))
+                i += 2
+                continue
         slope = fused.slope_of(nxt) if isinstance(nxt, (LeakyReLU, torch.nn.ReLU)) else None
         if isinstance(mod, torch.nn.Linear) and mod.bias is not None and slope is not None and not getattr(nxt, "inplace", False):
             x = fused.linear_bias_act(x, mod.weight, mod.bias, slope)

@@ -42,7 +42,8 @@ const char* dc_last_error(void);
  * percent of a K loop (0 = default 50, negative = off); 5 / 6: force the weight-gradient tile (1..4) / slab count;
  * 7: units (tile x 64-channel slab) per workgroup of the persistent two-piece tiled applies (0 = launcher's choice);
  * 8: value 1 = CSC count / scan / fill by one workgroup per cloud (round 3) instead of eight column ranges per cloud;
- * 9: value 1 = ignore pre-split weight planes (every product splits its weight operand in the K loop, as in round 3). */
+ * 9: value 1 = ignore pre-split weight planes (every product splits its weight operand in the K loop, as in round 3);
+ * 10: value 1 = cross-entropy of <= 64 rows through the two-launch form (same bits as the one-launch form). */
 int dc_set_option(int32_t key, int32_t value);
 
 /* Measurement aid (bench.py `roofline.frac`): device-clock stamps of the tiled two-piece forward applies and the tiled transposed applies.  After
@@ -546,6 +547,20 @@ int dc_rowblock_forward(const float* X, int64_t ldx, const float* W, int64_t ldw
 int dc_rowblock_backward(const float* dY, int64_t lddy, const float* H, int64_t ldh, const float* coef, const float* gamma,
                          float slope, int32_t mode, const float* X, int64_t ldx, int32_t M, int32_t N, int32_t K, float* dW,
                          int64_t lddw, float* dbias, float* dgamma, float* dbeta, float* dH, int64_t lddh, void* stream);
+/* The block FOLLOWED BY torch.nn.Dropout(p) (deltaconv/models/deltanet_classification.py:34-36: MLP -> Dropout(0.5) -> MLP ->
+ * Dropout(0.5) -> Linear) in the block's own launches: forward Y = dropout(act(bn(X W^T))) and mask[M, N] (1 = kept);
+ * backward takes the gradient behind the dropout.  Draws: Philox-4x32-10 keyed by `seed`, counter (element, salt, *step);
+ * `step` points at the block's BatchNorm num_batches_tracked on the device (a new mask in every training step, also in
+ * replays of a captured graph), `salt` tells the dropout layers of a model apart.  mode 1 | 2 as above. */
+int dc_rowblock_forward_dropout(const float* X, int64_t ldx, const float* W, int64_t ldw, int32_t M, int32_t N, int32_t K,
+                                const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                float* running_var, int32_t mode, float slope, float* H, int64_t ldh, float* coef, float* Y,
+                                int64_t ldy, float p, int32_t seed, const int64_t* step, int32_t salt, uint8_t* mask,
+                                void* stream);
+int dc_rowblock_backward_dropout(const float* dY, int64_t lddy, const float* H, int64_t ldh, const float* coef,
+                                 const float* gamma, float slope, int32_t mode, const float* X, int64_t ldx, int32_t M,
+                                 int32_t N, int32_t K, float* dW, int64_t lddw, float* dgamma, float* dbeta, float* dH,
+                                 int64_t lddh, const uint8_t* mask, float p, void* stream);
 
 #ifdef __cplusplus
 }

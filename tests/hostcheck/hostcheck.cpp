@@ -261,6 +261,15 @@ void hc_grad_T_sum(int V, const float* coef, const int* tptr, const int* tedge, 
         }
 }
 
+// Philox-4x32-10 of nn_math.h (the dropout draws of the row-block kernels): known-answer vectors + the keep decision
+void hc_philox(const unsigned* ctr, unsigned k0, unsigned k1, unsigned* out) {
+    const dcnn::U4 r = dcnn::philox4x32_10(dcnn::U4{ctr[0], ctr[1], ctr[2], ctr[3]}, k0, k1);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+void hc_dropout_keep(unsigned seed, long long step, unsigned salt, int n, float p, unsigned char* keep) {
+    for (int i = 0; i < n; ++i) keep[i] = dcnn::dropout_keep(seed, step, salt, (unsigned)i, p) ? 1 : 0;
+}
+
 // ---- fused BN / activation / vector non-linearity: serial loops over the formulas of nn_math.h ----
 static void hc_coeffs(const std::vector<double>& s1, const std::vector<double>& s2, long R, int C, const float* gamma,
                       const float* beta, float eps, float* mean, float* invstd, float* scale, float* shift) {

@@ -168,6 +168,18 @@ def test_build_grad_div_shape_regularizer_golden():
     assert torch.equal(grad0.coef, grad.coef) and rel_err(div0.coef.reshape(-1), g["div_val_f64"]) > 1e-3
 
 
+def test_build_grad_div_with_frames_formed_inside():
+    """build_grad_div(pos, normal, None, None, ...) -- the model's path: dc_mls_assemble_normals forms the frames of
+    build_tangent_basis in the assembly's first launch -- gives the bits of build_tangent_basis + build_grad_div."""
+    import deltaconv_amd as dc
+    b = synthetic_batch(3, 0, seed=36, sizes=[700, 1024, 33]).to(DEV)
+    gr = dc.geometry.Graph.knn(b.pos, 20, b.batch)
+    xb, yb = dc.geometry.build_tangent_basis(b.norm)
+    g0, d0 = dc.geometry.build_grad_div(b.pos, b.norm, xb, yb, gr, b.batch, regularizer=1e-3)
+    g1, d1 = dc.geometry.build_grad_div(b.pos, b.norm, None, None, gr, b.batch, regularizer=1e-3)
+    assert torch.equal(g0.coef, g1.coef) and torch.equal(d0.coef, d1.coef)
+
+
 # ---------------------------------------------------------------------------------- CSC
 def test_csc():
     from deltaconv_amd.geometry import Graph

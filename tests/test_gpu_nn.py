@@ -516,3 +516,96 @@ def test_linear_bias_act_vs_torch(rows, k, c, slope):
         lin.weight.copy_(w); lin.bias.copy_(b)
     y = lin(x.float().to(DEV))
     assert rel_err(y, torch.nn.functional.linear(x, w, b)) < 1e-5
+
+
+@pytest.mark.parametrize("R,C", [(2, 40), (32, 40), (61, 15), (64, 7)])
+def test_fused_loss_one_launch_same_bits_as_two(R, C):
+    """<= 64 logits rows: the one-launch cross-entropy (round 6) adds the row losses in the association of the two-launch form."""
+    from deltaconv_amd._lib import lib
+    from deltaconv_amd.utils import calc_loss
+    torch.manual_seed(R + C)
+    x = (torch.randn(R, C, device=DEV) * 4).requires_grad_(True)
+    y = torch.randint(0, C, (R,), device=DEV)
+    one = calc_loss(x, y)
+    one.backward()
+    g1 = x.grad.clone()
+    x.grad = None
+    lib.raw("dc_set_option")(10, 1)
+    try:
+        two = calc_loss(x, y)
+        two.backward()
+    finally:
+        lib.raw("dc_set_option")(10, 0)
+    assert float(one) == float(two) and torch.equal(g1, x.grad)
+
+
+@pytest.mark.parametrize("M,K,N,p", [(32, 2048, 512, 0.5), (32, 512, 256, 0.5), (8, 64, 40, 0.25), (64, 256, 96, 0.1)])
+def test_rowblock_dropout_fused_equals_block_then_dropout(M, K, N, p):
+    """MLP block -> Dropout(p) of the classification head (deltanet_classification.py:34-36) inside the block's own kernels
+    (dc_rowblock_forward_dropout / _backward_dropout): with the mask the fused call drew, forward and every gradient equal the
+    un-fused block followed by mask * 1 / (1 - p); the mask keeps a fraction 1 - p and changes with the step counter and the
+    layer salt."""
+    import copy
+    import deltaconv_amd as dc
+    torch.manual_seed(M + N)
+    blk = dc.nn.MLP([K, N]).to(DEV).train()[0]
+    with torch.no_grad():
+        blk[1].bn.weight.uniform_(0.5, 1.5); blk[1].bn.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(M, K, device=DEV)
+    dy = torch.randn(M, N, device=DEV)
+    a, b = copy.deepcopy(blk), copy.deepcopy(blk)
+    xa = x.clone().requires_grad_(True)
+    assert a.dropout_ok(xa)
+    ya = a(xa, dropout=(p, 1))
+    ya.backward(dy)
+    mask = (ya != 0).float()
+    assert abs(float(mask.mean()) - (1 - p)) < 5 * (p * (1 - p) / (M * N)) ** 0.5 + 0.02
+    xb = x.clone().requires_grad_(True)
+    yb = b(xb) * mask * (1.0 / (1.0 - p))
+    yb.backward(dy)
+    tol = 0.0 if p == 0.5 else 1e-6
+    assert rel_err(ya, yb) <= tol
+    assert rel_err(xa.grad, xb.grad) <= max(tol, 1e-6)       # (the input gradient runs through the split-product GEMM in both)
+    for (n1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_err(p1.grad, p2.grad) <= max(tol, 1e-6), n1
+    for (n1, b1), (_, b2) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(b1, b2), n1                        # running statistics, num_batches_tracked: untouched by the dropout
+    # next training step (the BatchNorm's step counter moved), another salt: other masks; same step + salt: the same mask
+    m2 = (a(x, dropout=(p, 1)) != 0)
+    assert float((m2 != mask.bool()).float().mean()) > 0.5 * p * (1 - p)
+    c1, c2, c3 = copy.deepcopy(a), copy.deepcopy(a), copy.deepcopy(a)
+    k1, k2, k3 = (c1(x, dropout=(p, 1)) != 0), (c2(x, dropout=(p, 1)) != 0), (c3(x, dropout=(p, 2)) != 0)
+    assert torch.equal(k1, k2) and float((k1 != k3).float().mean()) > 0.5 * p * (1 - p)
+
+
+def test_classification_head_dropout_runs_in_the_row_blocks():
+    """The whole classification net in training mode: the two Dropout(0.5) of the head run inside the row-block kernels
+    (no torch RNG consumed), draw a new mask every step -- also in replays of a captured step -- and vanish in eval mode;
+    with the switch off the same net runs torch's dropout."""
+    import deltaconv_amd as dc
+    from deltaconv_amd.nn import fused
+    from deltaconv_amd.graph_step import GraphedTrainStep
+    from deltaconv_amd.utils import calc_loss
+    torch.manual_seed(3)
+    model = dc.models.DeltaNetClassification(3, 40).to(DEV).train()
+    b = synthetic_batch(4, 256, seed=9).to(DEV)
+    state = torch.cuda.get_rng_state()
+    out1 = model(b).detach().clone()
+    assert torch.equal(torch.cuda.get_rng_state(), state), "the fused dropout must not consume torch's generator"
+    out2 = model(b).detach().clone()
+    assert not torch.equal(out1, out2) and torch.isfinite(out1).all()          # new masks (and new running statistics)
+    fused.USE_ROWBLOCK_DROPOUT = False
+    try:
+        model(b)
+        assert not torch.equal(torch.cuda.get_rng_state(), state)            # torch's dropout drew from the generator
+    finally:
+        fused.USE_ROWBLOCK_DROPOUT = True
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(b).clone(), model(b).clone()
+    assert torch.equal(e1, e2)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)                          # lr 0: only the masks / statistics change
+    g = GraphedTrainStep(model, calc_loss, b, optimizer=opt)
+    losses = [float(g()) for _ in range(4)]
+    assert len(set(losses)) == 4 and all(l == l for l in losses), losses       # every replay: another mask

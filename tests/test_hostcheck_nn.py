@@ -156,3 +156,32 @@ def test_ce_loss_row_formula(hc, R, C, smoothing):
     got = hc.hc_ce_loss(P(x.detach()), P(y), R, C, 0.2 if smoothing else 0.0, P(dx))
     assert abs(got - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
     assert rel_err(dx, x.grad) < 5e-6 or float((dx - x.grad).abs().max()) < 1e-7
+
+
+def test_philox_known_answers_and_dropout_keep(hc):
+    """The dropout draws of the row-block kernels (csrc/nn_math.h): Philox-4x32-10 against the known-answer vectors of the
+    Random123 distribution (kat_vectors: counter / key all zero, all ones, digits of pi), and the keep decision."""
+    import ctypes
+    import numpy as np
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c = (ctypes.c_uint32 * 4)(*ctr)
+        out = (ctypes.c_uint32 * 4)()
+        hc.hc_philox(c, ctypes.c_uint32(key[0]), ctypes.c_uint32(key[1]), out)
+        assert tuple(out) == want, [hex(v) for v in out]
+    n = 1 << 16
+    keep = np.zeros(n, dtype=np.uint8)
+    for p in (0.5, 0.1):
+        hc.hc_dropout_keep(ctypes.c_uint32(1234), ctypes.c_longlong(7), ctypes.c_uint32(1), n, ctypes.c_float(p),
+                           keep.ctypes.data_as(ctypes.c_void_p))
+        assert abs(keep.mean() - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-3          # 4 sigma
+    a = keep.copy()
+    hc.hc_dropout_keep(ctypes.c_uint32(1234), ctypes.c_longlong(8), ctypes.c_uint32(1), n, ctypes.c_float(0.1),
+                       keep.ctypes.data_as(ctypes.c_void_p))
+    assert (a != keep).mean() > 0.1                   # another step: another mask
+    b = keep.copy()
+    hc.hc_dropout_keep(ctypes.c_uint32(1234), ctypes.c_longlong(8), ctypes.c_uint32(2), n, ctypes.c_float(0.1),
+                       keep.ctypes.data_as(ctypes.c_void_p))
+    assert (b != keep).mean() > 0.1                   # another layer: another mask
