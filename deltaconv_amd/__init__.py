@@ -13,7 +13,7 @@ import os as _os
 # off; the flag is read when the HIP runtime initialises, so it is defaulted here, at import.
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
-from . import geometry, nn, models, transforms, datasets   # noqa: F401
+from . import geometry, nn, models, transforms, datasets, optim   # noqa: F401
 from .data import Batch              # noqa: F401
 
 __version__ = (0, 1, 0)

@@ -562,6 +562,14 @@ int dc_rowblock_backward_dropout(const float* dY, int64_t lddy, const float* H, 
                                  int32_t N, int32_t K, float* dW, int64_t lddw, float* dgamma, float* dbeta, float* dH,
                                  int64_t lddh, const uint8_t* mask, float p, void* stream);
 
+/* ---- optimizer step (step glue: experiments/train_modelnet.py:67, train_scanobjectnn.py:77, train_shapenet.py:95) -------- */
+/* torch.optim.SGD(lr, momentum, weight_decay) (dampening 0, no Nesterov) over ALL parameters in one launch (96 tensors per
+ * launch):  g' = g + weight_decay p;  buf = momentum buf + g';  p -= lr buf  (buf starts at zero).  params / grads / bufs /
+ * numel: HOST arrays of `count` device addresses / element counts (fp32, contiguous); lr: DEVICE scalar (a scheduler writes
+ * it between replays of a captured step). */
+int dc_sgd_step(const int64_t* params, const int64_t* grads, const int64_t* bufs, const int64_t* numel, int32_t count,
+                const float* lr, float momentum, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

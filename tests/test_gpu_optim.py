@@ -1,0 +1,116 @@
+"""deltaconv_amd.optim.SGD (csrc/optim.hip: dc_sgd_step) against torch.optim.SGD -- the optimizer of the reference's
+training scripts (experiments/train_modelnet.py:67: lr 0.1, momentum 0.9, weight decay 1e-4, cosine schedule).
+Tolerance: 1e-6 of the parameter scale per step (fused multiply-adds here, separate roundings in ATen)."""
+import pytest
+import torch
+
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SHAPES = [(1,), (3,), (5, 7), (4097,), (64, 64), (1024, 512), (40, 256), (256,)]
+
+
+def _pair(shapes, seed=0, **kw):
+    import deltaconv_amd as dc
+    g = torch.Generator().manual_seed(seed)
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    return pa, pb, dc.optim.SGD(pa, **kw), torch.optim.SGD(pb, **kw), g
+
+
+@pytest.mark.parametrize("kw", [dict(lr=0.1, momentum=0.9, weight_decay=1e-4), dict(lr=0.01, momentum=0.0, weight_decay=0.0),
+                                dict(lr=0.5, momentum=0.5, weight_decay=1e-2)])
+def test_sgd_matches_torch_over_steps(kw):
+    pa, pb, oa, ob, g = _pair(SHAPES, **kw)
+    sched_a = torch.optim.lr_scheduler.CosineAnnealingLR(oa, 6, eta_min=0.001)
+    sched_b = torch.optim.lr_scheduler.CosineAnnealingLR(ob, 6, eta_min=0.001)
+    for step in range(6):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(*a.shape, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+        sched_a.step(); sched_b.step()                      # the learning rate moves between the steps
+        for a, b in zip(pa, pb):
+            assert rel_err(a, b) < 2e-6, (step, tuple(a.shape))
+    for a, b in zip(pa, pb):
+        assert rel_err(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"]) < 2e-6 or kw["momentum"] == 0.0
+
+
+def test_sgd_many_tensors_unaligned_views_and_missing_grads():
+    """> 96 tensors (two launches), parameters that are unaligned views of a larger buffer (scalar path), parameters without a
+    gradient (skipped, like torch)."""
+    import deltaconv_amd as dc
+    g = torch.Generator().manual_seed(1)
+    base_a = torch.randn(200 * 37 + 3, generator=g).to(DEV)
+    base_b = base_a.clone()
+    pa = [torch.nn.Parameter(base_a[1 + i * 37:1 + i * 37 + 35]) for i in range(200)]
+    pb = [torch.nn.Parameter(base_b[1 + i * 37:1 + i * 37 + 35]) for i in range(200)]
+    oa = dc.optim.SGD(pa, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    ob = torch.optim.SGD(pb, lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i % 7 == 3:
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(35, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    assert rel_err(base_a, base_b) < 2e-6
+    assert torch.equal(base_a[:1], base_b[:1]) and torch.equal(base_a[-2:], base_b[-2:])       # nothing outside the views moved
+
+
+def test_sgd_state_dict_and_fallback_groups():
+    """state_dict round trip with torch.optim.SGD in both directions; a Nesterov group runs torch's own step."""
+    import deltaconv_amd as dc
+    pa, pb, oa, ob, g = _pair([(33,), (8, 8)], lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for a, b in zip(pa, pb):
+        gr = torch.randn(*a.shape, generator=g).to(DEV)
+        a.grad, b.grad = gr.clone(), gr.clone()
+    oa.step(); ob.step()
+    ob.load_state_dict(oa.state_dict())                     # ours -> torch
+    oa.load_state_dict(ob.state_dict())                     # and back
+    for a, b in zip(pa, pb):
+        gr = torch.randn(*a.shape, generator=g).to(DEV)
+        a.grad, b.grad = gr.clone(), gr.clone()
+    oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert rel_err(a, b) < 2e-6
+    qa, qb = torch.nn.Parameter(torch.ones(5, device=DEV)), torch.nn.Parameter(torch.ones(5, device=DEV))
+    na = dc.optim.SGD([qa], lr=0.1, momentum=0.9, nesterov=True)
+    nb = torch.optim.SGD([qb], lr=0.1, momentum=0.9, nesterov=True)
+    qa.grad, qb.grad = torch.full((5,), 2.0, device=DEV), torch.full((5,), 2.0, device=DEV)
+    na.step(); nb.step()
+    assert torch.equal(qa, qb)
+
+
+def test_sgd_learning_rate_moves_between_graph_replays():
+    """The captured step reads the learning rate from a device scalar: a scheduler step between replays takes effect
+    without a re-capture."""
+    import deltaconv_amd as dc
+    p = torch.nn.Parameter(torch.zeros(1000, device=DEV))
+    p.grad = torch.ones(1000, device=DEV)
+    opt = dc.optim.SGD([p], lr=0.5, momentum=0.0)
+    opt.step()                                              # eager first step: state + device scalar exist
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        opt.step()
+    before = p.detach().clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(p, before - 0.5)
+    opt.param_groups[0]["lr"] = 0.125
+    opt.sync_lr()
+    before = p.detach().clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.allclose(p, before - 0.125)
+    q = torch.nn.Parameter(torch.zeros(4, device=DEV))
+    q.grad = torch.ones(4, device=DEV)
+    fresh = dc.optim.SGD([q], lr=0.1)
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="before capturing"):
+        with torch.cuda.graph(g2):
+            fresh.step()
