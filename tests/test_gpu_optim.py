@@ -85,7 +85,7 @@ def test_sgd_state_dict_and_fallback_groups():
     assert torch.equal(qa, qb)
 
 
-def test_sgd_learning_rate_moves_between_graph_replays():
+def test_sgd_learning_rate_moves_between_graph_replays(monkeypatch):
     """The captured step reads the learning rate from a device scalar: a scheduler step between replays takes effect
     without a re-capture."""
     import deltaconv_amd as dc
@@ -110,7 +110,6 @@ def test_sgd_learning_rate_moves_between_graph_replays():
     q = torch.nn.Parameter(torch.zeros(4, device=DEV))
     q.grad = torch.ones(4, device=DEV)
     fresh = dc.optim.SGD([q], lr=0.1)
-    g2 = torch.cuda.CUDAGraph()
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)      # (no real capture: nothing to poison)
     with pytest.raises(RuntimeError, match="before capturing"):
-        with torch.cuda.graph(g2):
-            fresh.step()
+        fresh.step()
