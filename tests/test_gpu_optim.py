@@ -34,8 +34,9 @@ def test_sgd_matches_torch_over_steps(kw):
         sched_a.step(); sched_b.step()                      # the learning rate moves between the steps
         for a, b in zip(pa, pb):
             assert rel_err(a, b) < 2e-6, (step, tuple(a.shape))
-    for a, b in zip(pa, pb):
-        assert rel_err(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"]) < 2e-6 or kw["momentum"] == 0.0
+    if kw["momentum"] != 0.0:                               # (torch keeps no buffer without momentum)
+        for a, b in zip(pa, pb):
+            assert rel_err(oa.state[a]["momentum_buffer"], ob.state[b]["momentum_buffer"]) < 2e-6
 
 
 def test_sgd_many_tensors_unaligned_views_and_missing_grads():
@@ -69,8 +70,9 @@ def test_sgd_state_dict_and_fallback_groups():
         gr = torch.randn(*a.shape, generator=g).to(DEV)
         a.grad, b.grad = gr.clone(), gr.clone()
     oa.step(); ob.step()
-    ob.load_state_dict(oa.state_dict())                     # ours -> torch
-    oa.load_state_dict(ob.state_dict())                     # and back
+    import copy
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))      # ours -> torch (deep copy: load_state_dict adopts same-dtype tensors)
+    oa.load_state_dict(copy.deepcopy(ob.state_dict()))      # and back
     for a, b in zip(pa, pb):
         gr = torch.randn(*a.shape, generator=g).to(DEV)
         a.grad, b.grad = gr.clone(), gr.clone()
