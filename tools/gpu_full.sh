@@ -15,6 +15,9 @@ d = json.load(open("$OUT/bench.json"))
 print("ms_per_step", d["ms_per_step"], "value", d["value"], "exact", d.get("exact_chain_ms_per_step"))
 r = d["roofline"]
 print("in_step", r.get("in_step"))
+print("graded: frac", r.get("frac"), "us", r.get("us_per_launch"), "execution_only", r.get("execution_only"), "dispatch", r.get("dispatch"))
+for name, rows in (r.get("in_step_kernels") or {}).items():
+    print("  in-step", name, [(x["C"], x["us"], x["frac"]) for x in rows])
 for fam in ("family", "family_gather_path", "family_T", "family_T_gather_path"):
     print(fam, {k: (v["us"], v["frac"]) for k, v in (r.get(fam) or {}).items()})
 print("cpu", (d.get("cpu_baseline") or {}).get("value"))

@@ -14,7 +14,7 @@ import json
 d = json.load(open("$OUT/bench.json"))
 r = d["roofline"]
 print("C2 ms_per_step", round(d["ms_per_step"], 4), "exact", d.get("exact_chain_ms_per_step"))
-print("frac", r["frac"], "us", r["us_per_launch"], "rotating", r.get("rotating_buffers"), "l3", r.get("us_per_launch_l3_resident"))
+print("frac", r["frac"], "us", r["us_per_launch"], "execution_only", r.get("execution_only"), "dispatch", r.get("dispatch"), "rotating", r.get("rotating_buffers"), "l3", r.get("us_per_launch_l3_resident"))
 for name, rows in (r.get("in_step_kernels") or {}).items():
     print("  in-step", name, [(x["C"], x["us"], x["frac"]) for x in rows])
 PY
