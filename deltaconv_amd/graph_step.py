@@ -69,6 +69,7 @@ class GraphedTrainStep:
             _ptr_info(self.static)              # cloud offsets of the static batch: a host read, never inside the capture
         if self._one is None:                   # made outside the capture (inside, it would be a captured fill again)
             self._one = torch.ones((), dtype=torch.float32, device=self.params[0].device)
+            self._one._dc_unit_seed = True      # utils._CELoss.backward: d loss / d logits needs no scaling by this seed
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                       # warm-up outside the capture (allocator, tuning)
@@ -122,6 +123,7 @@ class GraphedTrainStep:
             # loss.backward() seeds the pass with ones_like(loss): a fill launch in every replay (~5 us of launch floor)
             if self._one is None or self._one.dtype != loss.dtype or self._one.device != loss.device:
                 self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+                self._one._dc_unit_seed = True
             torch.autograd.backward(loss, grad_tensors=(self._one,))
         else:
             loss.backward()
@@ -141,18 +143,14 @@ class GraphedTrainStep:
         s = self.static
         if batch is s:
             return
-        dsts, srcs = [], []
         for name in ("pos", "norm", "x", "y", "category"):
             dst, src = getattr(s, name, None), getattr(batch, name, None)
             if dst is not None:
                 assert src is not None and src.shape == dst.shape, f"batch.{name}: static shape {tuple(dst.shape)}"
-                if src.device == dst.device and src.dtype == dst.dtype:
-                    dsts.append(dst)
-                    srcs.append(src)
-                else:
-                    dst.copy_(src, non_blocking=True)
-        if dsts:
-            torch._foreach_copy_(dsts, srcs)      # one multi-tensor launch per dtype instead of one copy per tensor
+                # one plain device copy per tensor: torch._foreach_copy_ was tried (round 6) and is SLOWER here -- mixed
+                # dtypes / sizes take its slow path, 38 us of host gap in front of each of its launches
+                # (profiles/r06g_step_timeline.txt) against three back-to-back 4.7 us copies
+                dst.copy_(src, non_blocking=True)
 
     def __call__(self, batch=None):
         if batch is not None:

@@ -25,6 +25,8 @@ class _CELoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlogits,) = ctx.saved_tensors
+        if getattr(g, "_dc_unit_seed", False):      # graph_step.py seeds the backward pass with a tensor it KNOWS to be 1.0:
+            return dlogits, None, None              # no scaling launch (a marked tensor is never written after creation)
         return dlogits * g, None, None
 
 
