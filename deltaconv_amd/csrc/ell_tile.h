@@ -37,9 +37,13 @@ constexpr int CS = 64;        // channels per slab: 16 lanes x 4
 // (3.0 x instead of 2.6 x halo rows and twice the per-tile overheads outweigh the overlap); the capacity stays one constant.
 template <int P> constexpr int cap_rows() { return 248; }
 __device__ __forceinline__ void store_nt(float* p, const Vec<4>& a) { dc_store16<DC_ST_TILE>(p, *reinterpret_cast<const dc_f32x4*>(&a)); }
+// cache policy of the LDS-DMA pieces (gfx942+ CPol bits: 1 = sc0, 2 = nt, 16 = sc1): lab switch, see profiles/r06_labs.txt
+#ifndef DC_DMA_AUX
+#define DC_DMA_AUX 0
+#endif
 __device__ __forceinline__ void dma16(const void* src, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, DC_DMA_AUX);
 }
 
 template <int R, int P>
