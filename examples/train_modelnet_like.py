@@ -87,7 +87,7 @@ def main():
     torch.manual_seed(1)
     model = DeltaNetClassification(3, 40, num_neighbors=args.k, grad_regularizer=args.grad_regularizer).to(dev)
     ddp = FlatGradDataParallel(model)
-    opt = torch.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4, fused=True)
+    opt = deltaconv.optim.SGD(model.parameters(), lr=args.lr, momentum=0.9, weight_decay=1e-4)   # torch.optim.SGD, step = one launch
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, args.epochs, eta_min=0.001)
     if args.data is None:
         train = make_split(args.train_batches, args.batch_size, args.num_points, 1000 * (rank + 1), dev)

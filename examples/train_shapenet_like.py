@@ -103,7 +103,7 @@ def main():
     torch.manual_seed(1)
     model = shapenet_model(args, 50).to(dev)
     ddp = FlatGradDataParallel(model)
-    opt = torch.optim.SGD(model.parameters(), lr=100 * args.lr, momentum=args.momentum, weight_decay=1e-4, fused=True)
+    opt = deltaconv.optim.SGD(model.parameters(), lr=100 * args.lr, momentum=args.momentum, weight_decay=1e-4)   # torch.optim.SGD, step = one launch
     sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, args.epochs, eta_min=args.lr)
     if args.data is None:
         train = synthetic_split(args.train_batches, args, 1000 * (rank + 1), dev)
