@@ -74,3 +74,21 @@ def test_plain_command_self_launches_its_ranks():
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+
+
+@pytest.mark.parametrize("config,gb", [("C4", 2), ("C5", 2)])
+def test_strong_scaling_form_under_the_launcher(config, gb):
+    """`bench.py --config C4|C5 --global-batch B` (round 6: BASELINE configs 4 / 5 are a global batch over 8 GPUs) through the
+    launcher with one rank and --force-dist: global-batch / world clouds per rank, "scaling": "strong", BatchNorm statistics
+    over the global batch (the step is ONE captured graph with its collectives), the segmentation nets, SGD / Adam."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29561" if config == "C4" else "29562", os.path.join(ROOT, "bench.py"), "--gpus", "1",
+           "--config", config, "--global-batch", str(gb), "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-exact-chain",
+           "--force-dist"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["config"]["name"] == config and d["config"]["global_batch"] == gb and d["value"] > 0
+    assert "BatchNorm statistics over the global batch" in d["config"]["workload"]
+    assert "one HIP graph" in d["config"]["workload"], d["config"]["workload"]
