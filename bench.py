@@ -52,6 +52,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-clouds", type=int, default=None, help="clouds in the CPU-baseline sample (default 8 / 4 / 4 / 2 for C2 .. C5)")
     ap.add_argument("--no-cpu-full-batch", action="store_true",
                     help="skip the second CPU-baseline entry on the full batch of the configuration (~25 s)")
+    ap.add_argument("--no-in-step-stamps", action="store_true",
+                    help="skip the second capture of the step with device-clock stamps (kernel-trace runs: the stamp replays would be "
+                         "the last steps of the trace); `roofline.frac` is then the rotating-buffer number")
     ap.add_argument("--no-graph", action="store_true",
                     help="enqueue every kernel from Python each step instead of replaying the captured HIP graph")
     ap.add_argument("--resident-batches", type=int, default=4, help="distinct synthetic batches cycled through")
@@ -86,6 +89,12 @@ def per_rank_clouds(args, world):
             raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
         return args.global_batch // world
     return CONFIGS[args.config]["B"] if args.batch is None else args.batch
+
+
+def _capture_mode():
+    """With a process group alive its watchdog thread may query events while this thread captures: a global-mode capture would
+    be invalidated by that call (deltaconv_amd/graph_step.py)."""
+    return "thread_local" if dist.is_initialized() else "global"
 
 
 def apply_roofline(graph, grad, div, C, iters=200):
@@ -153,7 +162,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
             # is as long as these kernels, eager launches would time the host
             per = 50
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
                 for _ in range(per):
                     fn()
             g.replay()
@@ -183,7 +192,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
         rawb(stamps.data_ptr(), per)
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
                 for _ in range(per):
                     fn()
             used = lib.raw("dc_stamp_count")()
@@ -216,7 +225,7 @@ def apply_roofline(graph, grad, div, C, iters=200):
             c()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
             for _ in range(rounds):
                 for c in calls:
                     c()
@@ -601,7 +610,7 @@ def main(argv=None):
         finally:
             _lib.raw("dc_set_option")(3, 0)
     stamped = None
-    if rank == 0 and world == 1 and not use_dist and not args.no_graph:
+    if rank == 0 and world == 1 and not use_dist and not args.no_graph and not args.no_in_step_stamps:
         try:
             stamped = in_step_stamps(model, calc_loss, static, opt, args.batch * args.points, args.k)
         except Exception as e:

@@ -22,7 +22,7 @@ for fam in ("family", "family_gather_path", "family_T", "family_T_gather_path"):
     print(fam, {k: (v["us"], v["frac"]) for k, v in (r.get(fam) or {}).items()})
 print("cpu", (d.get("cpu_baseline") or {}).get("value"))
 PY
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-chain > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact-chain --no-in-step-stamps > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/prof_summary.py $OUT/prof > $OUT/kernel_summary.txt 2>&1
 python tools/step_timeline.py $OUT/prof > $OUT/step_timeline.txt 2>&1; tail -1 $OUT/step_timeline.txt
