@@ -1116,6 +1116,9 @@ class _LinearBNAct(torch.autograd.Function):
 def _seed32():
     """The process seed (torch.manual_seed) folded to 31 bits: the key of the row-block dropout streams."""
     s = int(torch.initial_seed())
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():      # data-parallel ranks share the seed: their dropout masks must not coincide
+        s ^= (dist.get_rank() + 1) * 0x9E3779B1
     return (s ^ (s >> 31)) & 0x7fffffff
 
 
