@@ -39,7 +39,11 @@ __global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int 
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[q][j] = 0.0;
+#ifndef DC_COLRED_UNROLL
+#define DC_COLRED_UNROLL 1
+#endif
     if (c0 < C) {
+#pragma unroll DC_COLRED_UNROLL
         for (long r = r0 + rl; r < r1; r += RT) {
             double t[NQ][V];
             f(r, c0, t);
@@ -180,10 +184,13 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // ---- host helpers --------------------------------------------------------------------------
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-// rows per block: enough blocks (~1500) to fill 256 CUs even for narrow matrices; multiple of RT
+// rows per block: enough blocks (~768: three per CU) to fill 256 CUs even for narrow matrices; multiple of RT
 inline int rows_per_chunk(long R, int C) {
     const long coltiles = (C + CT * 4 - 1) / (CT * 4);
-    long rpc = (R * coltiles / 1536 + RT - 1) / RT * RT;
+#ifndef DC_COLRED_BLOCKS
+#define DC_COLRED_BLOCKS 768      // round 6, same-box A/B of the step (profiles/r06_labs.txt item 6): 768 beats 1536 / 3072 / 384
+#endif
+    long rpc = (R * coltiles / DC_COLRED_BLOCKS + RT - 1) / RT * RT;
     return (int)std::min<long>(std::max<long>(rpc, RT), 512);
 }
 inline int chunks_of(long R, int C) { const int rpc = rows_per_chunk(R, C); return (int)((R + rpc - 1) / rpc); }

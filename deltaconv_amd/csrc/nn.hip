@@ -109,7 +109,10 @@ __global__ __launch_bounds__(TPB) void tile_kernel(long R, int C, int rpc, BODY 
     body.init(c0);
     const long r0 = (long)blockIdx.x * rpc;
     const long r1 = min(r0 + rpc, R);
-#pragma unroll 2
+#ifndef DC_TILE_UNROLL
+#define DC_TILE_UNROLL 2
+#endif
+#pragma unroll DC_TILE_UNROLL
     for (long r = r0 + rl; r < r1; r += RT) body.row(r, c0);
 }
 
@@ -358,7 +361,10 @@ struct PoolBwdBody {
 template <int V, class BODY>
 void run_tile(BODY body, long R, int C, hipStream_t s) {
     const long coltiles = dc_cdiv(C, CT * V);
-    long rpc = (R * coltiles / 2048 + RT - 1) / RT * RT;      // ~2048 blocks, >= 1 row per thread
+#ifndef DC_TILE_BLOCKS
+#define DC_TILE_BLOCKS 1024     // round 6, same-box A/B of the step (profiles/r06_labs.txt item 6): 1024 beats 2048 / 4096 / 512
+#endif
+    long rpc = (R * coltiles / DC_TILE_BLOCKS + RT - 1) / RT * RT;      // ~1024 blocks, >= 1 row per thread
     rpc = std::min<long>(std::max<long>(rpc, RT), 1024);
     dim3 grid(dc_cdiv(R, rpc), (unsigned)coltiles);
     hipLaunchKernelGGL((tile_kernel<V, BODY>), grid, dim3(TPB), 0, s, R, C, (int)rpc, body);
