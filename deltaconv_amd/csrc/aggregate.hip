@@ -242,6 +242,28 @@ DC_EXPORT int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, i
     return DC_OK;
 }
 
+// max aggregation with the layer's last s_mlp block in its epilogue (ell_tile.h: KnnMaxB::h2): out = act2(bn2(h2)) + max_j act(bn(h_j)),
+// i.e. `x = s_mlp(...) + x_max` of nn/deltaconv.py:59 with both BatchNorm + activation pairs folded in; out2 (may be NULL) = second copy
+DC_EXPORT int dc_knn_max_affine_residual_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles, int32_t k,
+                                               int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale,
+                                               const float* shift, float slope, const float* h2, int64_t ldh2,
+                                               const float* scale2, const float* shift2, float slope2, float* out, int64_t ldo,
+                                               float* out2, int64_t ldo2, uint8_t* arg, void* stream) {
+    DC_REQUIRE(plan && nbr && h && scale && shift && h2 && scale2 && shift2 && out && arg, "dc_knn_max_affine_residual_tiled: null pointer");
+    DC_REQUIRE(n >= 0 && num_tiles >= 0 && k >= 2 && k % 2 == 0 && k <= 64 && (P == 32 || P == 64) && P * k <= 2048,
+               "dc_knn_max_affine_residual_tiled: bad size");
+    DC_REQUIRE(dctile::eligible(C, {(long)ldh, (long)ldo, (long)ldh2, (long)(out2 ? ldo2 : 4)}, {h, out, arg, h2, scale2, shift2, out2}),
+               "dc_knn_max_affine_residual_tiled: needs C %% 64 == 0 and 16-byte aligned rows / coefficient vectors");
+    DC_REQUIRE(ldh >= C && ldo >= C && ldh2 >= C && (!out2 || ldo2 >= C), "dc_knn_max_affine_residual_tiled: leading dimension smaller than the row");
+    if (n == 0) return DC_OK;
+    const DcTilePlan L = dc_tile_plan_layout(num_tiles, k, P);
+    dctile::KnnMaxB<true> body{h, (long)ldh, 0, scale, shift, slope, out, (long)ldo, arg, (long)C};
+    body.h2 = h2; body.ldh2 = ldh2; body.scale2 = scale2; body.shift2 = shift2; body.slope2 = slope2; body.out2 = out2; body.ldo2 = ldo2;
+    dctile::launch<1>(L, plan, nullptr, nbr, C, body, static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_knn_max_affine_residual_tiled");
+    return DC_OK;
+}
+
 // ---- max-aggregation backward from the transposed tile plan (ell_tileT.h): same sums in the same order, rows + slot words in LDS
 DC_EXPORT int dc_knn_max_backward_tiled(const int32_t* planT, int32_t n, int32_t num_clouds, int32_t num_tiles, int32_t k,
                                         int32_t P, const uint8_t* arg, const float* dout, int32_t C, int64_t ldo, float* dh,

@@ -452,6 +452,12 @@ struct KnnMaxB {
     static constexpr bool ROWPASS = AFFINE;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const float *scale, *shift; float slope; float* out; long ldo; unsigned char* arg; long lda;
+    // optional epilogue (round 6): the layer's LAST s_mlp block rides along -- out = act2(scale2 h2[i] + shift2) + max, the
+    // residual form of deltaconv.py:59 (`x = s_mlp(...) + x_max`), also written to out2 (the layer's block of the heads' concat
+    // buffer): the separate BatchNorm / activation pass over [n, C] and the x_max round trip go away.  Same two addends as
+    // dc_bn_act2 with a residual: same bits.
+    const float* h2 = nullptr; long ldh2 = 0; const float *scale2 = nullptr, *shift2 = nullptr; float slope2 = 0.f;
+    float* out2 = nullptr; long ldo2 = 0;
     Vec<4> best; unsigned slot[4]; float sc[4], sh[4];
     __device__ void init(int c) {
         if (AFFINE)
@@ -475,7 +481,20 @@ struct KnnMaxB {
         }
     }
     __device__ void finish(long i, int c, const Vec<4>&, const Vec<4>&) {
-        store_nt(out + i * ldo + c, best);
+        if (h2) {
+            const Vec<4> v = dcell::vload<4>(h2 + i * ldh2 + c), s2 = dcell::vload<4>(scale2 + c), t2 = dcell::vload<4>(shift2 + c);
+            Vec<4> y;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float z = fmaf(s2.v[q], v.v[q], t2.v[q]);
+                y.v[q] = (z > 0.f ? z : slope2 * z) + best.v[q];
+            }
+            // x' is read again by the very next launches (grad apply, the next layer's products): a plain store keeps it cached
+            *reinterpret_cast<dc_f32x4*>(out + i * ldo + c) = *reinterpret_cast<const dc_f32x4*>(&y);
+            if (out2) store_nt(out2 + i * ldo2 + c, y);
+        } else {
+            store_nt(out + i * ldo + c, best);
+        }
         // the four slot bytes as one 32-bit store (c and lda are multiples of 4)
         const unsigned w = slot[0] | (slot[1] << 8) | (slot[2] << 16) | (slot[3] << 24);
         __builtin_nontemporal_store(w, reinterpret_cast<unsigned*>(arg + i * lda + c));

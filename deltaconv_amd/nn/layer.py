@@ -64,6 +64,10 @@ class LayerCfg:
         self.dup = dup     # (buffer [n, sum co], column offset): x' is written into that column block as well
 
 
+# A/B switch: the max aggregation takes the last s_mlp block's BatchNorm / activation / residual into its epilogue (tile plan only)
+FUSE_MAX_RESIDUAL = [True]
+
+
 def _padded(rows, cols, block, f32):
     """[rows, cols] fp32 matrix whose column `block` starts on a 16-byte boundary and whose row stride is a multiple of
     4 floats: a view behind (-block) % 4 spare columns of a wider buffer when that is possible, else a plain matrix."""
@@ -162,6 +166,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
 
         # ---- scalar stream, max aggregation over the k neighbours (deltaconv.py:50-54)
         max_saved = None
+        pending_max = None
         if nm == 0:
             x_max, ldm = _rows(x_max_ext)
         else:
@@ -197,10 +202,10 @@ class DeltaConvLayerFn(torch.autograd.Function):
             else:
                 hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
                 arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
-                _ops.fwd_knn_max(g, hm, co, co, x_max, co, arg, affine=(coef_m[2], coef_m[3], slope_m))
+                # the gather itself waits for the last s_mlp block (below): from the tile plan it takes that block's BatchNorm /
+                # activation pass and the residual add into its epilogue (round 6: one launch and the x_max round trip less)
+                pending_max = (hm, coef_m, slope_m, arg)
                 max_saved = (arg,)
-                if SLOT_TAP[0] is not None:
-                    SLOT_TAP[0].append(arg.clone())
                 saved_m.append((inp, hm, coef_m, use_m))
 
         # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)
@@ -229,8 +234,20 @@ class DeltaConvLayerFn(torch.autograd.Function):
         # the block view is created HERE (inside the node, like the chain views): an outside view object
         # must not be returned as an output of an autograd Function
         x_dup = cfg.dup[0][:, cfg.dup[1]:cfg.dup[1] + co] if cfg.dup is not None else None
-        call("dc_bn_act2", hs, n, co, co, coef_s[2], coef_s[3], cfg.slopes_s[-1], x_max, ldm, x_new, ldxn, x_dup,
-             x_dup.stride(0) if x_dup is not None else 0)
+        fused_max = False
+        if pending_max is not None:
+            hm, coef_m, slope_m, arg = pending_max
+            if FUSE_MAX_RESIDUAL[0]:
+                fused_max = _ops.fwd_knn_max_residual(g, hm, co, co, (coef_m[2], coef_m[3], slope_m), hs, co,
+                                                      (coef_s[2], coef_s[3], cfg.slopes_s[-1]), x_new, ldxn, x_dup,
+                                                      x_dup.stride(0) if x_dup is not None else 0, arg)
+            if not fused_max:
+                _ops.fwd_knn_max(g, hm, co, co, x_max, co, arg, affine=(coef_m[2], coef_m[3], slope_m))
+            if SLOT_TAP[0] is not None:
+                SLOT_TAP[0].append(arg.clone())
+        if not fused_max:
+            call("dc_bn_act2", hs, n, co, co, coef_s[2], coef_s[3], cfg.slopes_s[-1], x_max, ldm, x_new, ldxn, x_dup,
+                 x_dup.stride(0) if x_dup is not None else 0)
 
         # ---- vector stream: [v | hodge v | grad x'] and its 90-degree rotation -> v_mlp (deltaconv.py:64-68)
         v_new = None                       # without vector stream the caller passes v through (deltaconv.py:64,70)

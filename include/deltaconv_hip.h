@@ -204,6 +204,15 @@ int dc_knn_max_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t
 int dc_knn_max_affine_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles, int32_t k,
                             int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale, const float* shift,
                             float slope, float* out, int64_t ldo, uint8_t* arg, void* stream);
+/* The same with the layer's last s_mlp block in its epilogue (round 6): out = act2(scale2 h2 + shift2) + max_j act(scale h_j + shift)
+ * = `x = self.s_mlp(x) + x_max` of deltaconv/nn/deltaconv.py:54-59 with both BatchNorm + LeakyReLU pairs folded in; out2 (may be
+ * NULL, row stride ldo2) receives a second copy (the layer's block of the heads' torch.cat buffer).  Same bits as
+ * dc_knn_max_affine_tiled followed by dc_bn_act2 with the maximum as residual. */
+int dc_knn_max_affine_residual_tiled(const int32_t* plan, const int32_t* nbr, int32_t n, int32_t num_tiles, int32_t k,
+                                     int32_t P, const float* h, int32_t C, int64_t ldh, const float* scale,
+                                     const float* shift, float slope, const float* h2, int64_t ldh2, const float* scale2,
+                                     const float* shift2, float slope2, float* out, int64_t ldo, float* out2, int64_t ldo2,
+                                     uint8_t* arg, void* stream);
 
 /* ---- transposed applies / max-aggregation backward from the TRANSPOSED TILE PLAN (round 4) -----------------------
  * Same operations as dc_apply_{grad,grad_T_sum,div,hodge,div_curl_norm}_T and dc_knn_max_backward, i.e. the backward of

@@ -288,3 +288,43 @@ def test_device_clock_stamps_of_the_tiled_applies():
     assert int(rec[2, 0]) == 2 ** 62 and int(rec[2, 1]) == 0                  # untouched records
     _ops.fwd_apply("div_curl_norm", div, v, C, C, out, 3 * C)                 # disarmed: no record taken, same bits
     assert lib.raw("dc_stamp_count")() == 0 and torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("kind,train", [("cls", True), ("seg2", True), ("cls", False)])
+def test_max_aggregation_with_residual_block_epilogue_is_bit_identical(kind, train):
+    """Round 6: from the tile plan the max aggregation takes the layer's last s_mlp block (BatchNorm + activation + the residual
+    add of deltaconv.py:59) into its epilogue (dc_knn_max_affine_residual_tiled).  Same addends as the two-launch form: logits,
+    every gradient and every BatchNorm buffer identical bit for bit; depth-2 blocks (the part-segmentation net) and inference
+    coefficients included."""
+    import os
+    from deltaconv_amd.models import DeltaNetClassification, DeltaNetSegmentation
+    from deltaconv_amd.nn import layer as L
+    from deltaconv_amd.utils import calc_loss
+    seg = kind != "cls"
+    b = synthetic_batch(3, 512, seed=13, per_point_labels=seg, num_classes=8 if seg else 40).to(DEV)
+
+    def run(fuse):
+        L.FUSE_MAX_RESIDUAL[0] = fuse
+        os.environ["DC_TILE_P"] = "64"
+        try:
+            torch.manual_seed(5)
+            m = (DeltaNetSegmentation(3, 8, mlp_depth=2) if seg else DeltaNetClassification(3, 40)).to(DEV).train(train)
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+            if not train:
+                with torch.no_grad():
+                    return m(b).clone(), [], []
+            out = m(b)
+            calc_loss(out, b.y, smoothing=not seg).backward()
+            return (out.detach(), [p.grad.clone() for p in m.parameters() if p.grad is not None],
+                    [t.clone() for t in m.buffers()])
+        finally:
+            L.FUSE_MAX_RESIDUAL[0] = True
+            os.environ.pop("DC_TILE_P", None)
+
+    o1, g1, b1 = run(True)
+    o0, g0, b0 = run(False)
+    assert torch.equal(o1, o0)
+    assert len(g1) == len(g0) and all(torch.equal(a_, b_) for a_, b_ in zip(g1, g0))
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(b1, b0))
