@@ -29,6 +29,8 @@ all-reduce the fp64 sums their kernels hand out between a product and its finali
 Dense GEMMs: hand-written fp32-MFMA kernels (csrc/gemm.hip forward + input gradient, the forward ones with the
 BatchNorm statistics of the block in their epilogue; csrc/gemm_tn.hip weight gradient).
 """
+import os
+
 import torch
 
 from .._lib import lib
@@ -65,7 +67,7 @@ class LayerCfg:
 
 
 # A/B switch: the max aggregation takes the last s_mlp block's BatchNorm / activation / residual into its epilogue (tile plan only)
-FUSE_MAX_RESIDUAL = [True]
+FUSE_MAX_RESIDUAL = [os.environ.get("DC_FUSE_MAX_RESIDUAL", "1") != "0"]
 
 
 def _padded(rows, cols, block, f32):

@@ -11,7 +11,8 @@ from deltaconv_amd.data import synthetic_batch
 from deltaconv_amd.utils import calc_loss
 from deltaconv_amd.graph_step import GraphedTrainStep
 src = open(os.path.join(ROOT, "tools", "bench_configs.py")).read()
-ns = {}
+from deltaconv_amd import configs as _C
+ns = {"C": _C}
 exec(src[src.index("CONFIGS = {"):src.index("def timed(")], ns)
 import importlib
 mod, attr = importlib.import_module(sys.argv[1]), sys.argv[2]
