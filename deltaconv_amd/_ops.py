@@ -53,13 +53,16 @@ def fwd_knn_max(g, h, c, ldh, out, ldo, arg, affine=None):
 
 def fwd_knn_max_residual(g, h, c, ldh, affine, h2, ldh2, affine2, out, ldo, out2, ldo2, arg):
     """out = act2(bn2(h2)) + max_j act(bn(h_j)) (+ second copy out2): the max aggregation with the layer's last s_mlp block in its
-    epilogue (deltaconv.py:54-59).  Only from the tile plan; returns False when it does not apply (the caller runs the two steps)."""
+    epilogue (deltaconv.py:54-59): from the tile plan when it applies, else through the gather path.  Returns False only for an
+    activation without a slope (the caller then runs the two steps)."""
     if affine2[2] is None:
         return False
     ops = [(h, ldh), (out, ldo), (arg, 4), (h2, ldh2), (affine2[0], 4), (affine2[1], 4)] + ([(out2, ldo2)] if out2 is not None else [])
     plan = _tiled(g, c, *ops)
-    if plan is None:
-        return False
+    if plan is None:            # the gather-path twin: any C / alignment / k
+        lib.call("dc_knn_max_affine_residual", g.nbr, g.n, g.k, h, c, ldh, affine[0], affine[1], affine[2], h2, ldh2, affine2[0],
+                 affine2[1], float(affine2[2]), out, ldo, out2, ldo2, arg)
+        return True
     lib.call("dc_knn_max_affine_residual_tiled", plan.blob, g.nbr, *plan.args, h, c, ldh, affine[0], affine[1], affine[2], h2, ldh2,
              affine2[0], affine2[1], float(affine2[2]), out, ldo, out2, ldo2, arg)
     return True

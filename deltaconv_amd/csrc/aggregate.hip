@@ -29,6 +29,16 @@ struct KnnMaxAffineF {
 };
 
 template <int V>
+struct KnnMaxAffineResF {
+    const float* h; long ldh; const float *scale, *shift; float slope; const float* h2; long ldh2; const float *scale2, *shift2;
+    float slope2; float* out; long ldo; float* out2; long ldo2; unsigned char* arg; long lda;
+    __device__ void operator()(long i, int c0, Row r, int k) const {
+        knn_max_affine_residual_fwd<V>(i, c0, r.ids, k, h, ldh, scale, shift, slope, h2, ldh2, scale2, shift2, slope2, out, ldo, out2,
+                                       ldo2, arg, lda);
+    }
+};
+
+template <int V>
 struct KnnSumF {
     const float* h; long ldh; float scale; float* out; long ldo;
     __device__ void operator()(long i, int c0, Row r, int k) const { knn_sum_fwd<V>(i, c0, r.ids, k, h, ldh, scale, out, ldo); }
@@ -149,6 +159,27 @@ DC_EXPORT int dc_knn_max_affine(const int32_t* nbr, int32_t n, int32_t k, const 
         launch_fwd<1>(n, C, nullptr, nbr, k,
                       KnnMaxAffineF<1>{h, (long)ldh, scale, shift, slope, out, (long)ldo, arg, (long)C}, s);
     DC_CHECK_LAUNCH("dc_knn_max_affine");
+    return DC_OK;
+}
+
+// out[i,c] = act2(scale2_c h2[i,c] + shift2_c) + max_s act(scale_c h[nbr[i,s],c] + shift_c) (+ second copy out2): the gather-path twin
+// of dc_knn_max_affine_residual_tiled (any C / alignment / k)
+DC_EXPORT int dc_knn_max_affine_residual(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh,
+                                         const float* scale, const float* shift, float slope, const float* h2, int64_t ldh2,
+                                         const float* scale2, const float* shift2, float slope2, float* out, int64_t ldo,
+                                         float* out2, int64_t ldo2, uint8_t* arg, void* stream) {
+    DC_REQUIRE(nbr && h && scale && shift && h2 && scale2 && shift2 && out && arg, "dc_knn_max_affine_residual: null pointer");
+    DC_REQUIRE(n >= 0 && k >= 1 && k <= 255 && C >= 0, "dc_knn_max_affine_residual: bad size (k <= 255)");
+    DC_REQUIRE(ldh >= C && ldo >= C && ldh2 >= C && (!out2 || ldo2 >= C), "dc_knn_max_affine_residual: leading dimension smaller than the row");
+    if (n == 0 || C == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (pick_v(C, {(long)ldh, (long)ldo, (long)ldh2, (long)(out2 ? ldo2 : 4)}, {h, out, h2, out2}) == 4)
+        launch_fwd<4>(n, C, nullptr, nbr, k, KnnMaxAffineResF<4>{h, (long)ldh, scale, shift, slope, h2, (long)ldh2, scale2, shift2, slope2,
+                                                                 out, (long)ldo, out2, (long)ldo2, arg, (long)C}, s);
+    else
+        launch_fwd<1>(n, C, nullptr, nbr, k, KnnMaxAffineResF<1>{h, (long)ldh, scale, shift, slope, h2, (long)ldh2, scale2, shift2, slope2,
+                                                                 out, (long)ldo, out2, (long)ldo2, arg, (long)C}, s);
+    DC_CHECK_LAUNCH("dc_knn_max_affine_residual");
     return DC_OK;
 }
 

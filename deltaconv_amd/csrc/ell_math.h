@@ -232,6 +232,50 @@ DC_HD void knn_max_affine_fwd(long i, int c0, const int* ids, int k, const float
     for (int q = 0; q < V; ++q) arg[i * lda + c0 + q] = slot[q];
 }
 
+// The same with the layer's last s_mlp block in its epilogue (round 6): out = act2(scale2 h2[i] + shift2) + max  -- the residual
+// form `x = s_mlp(...) + x_max` of deltaconv.py:59; same two addends as dc_bn_act2 with the maximum as residual (same bits);
+// out2 (may be null): second copy, the layer's block of the heads' concat buffer.
+template <int V>
+DC_HD void knn_max_affine_residual_fwd(long i, int c0, const int* ids, int k, const float* h, long ldh, const float* scale,
+                                       const float* shift, float slope, const float* h2, long ldh2, const float* scale2,
+                                       const float* shift2, float slope2, float* out, long ldo, float* out2, long ldo2,
+                                       unsigned char* arg, long lda) {
+    float sc[V], sh[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { sc[q] = scale[c0 + q]; sh[q] = shift[c0 + q]; }
+    Vec<V> best = vload<V>(h + (long)ids[0] * ldh + c0);
+    unsigned char slot[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        const float z = fmaf(sc[q], best.v[q], sh[q]);
+        best.v[q] = z > 0.f ? z : slope * z;
+        slot[q] = 0;
+    }
+#pragma unroll 4
+    for (int s = 1; s < k; ++s) {
+        const Vec<V> hv = vload<V>(h + (long)ids[s] * ldh + c0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float z = fmaf(sc[q], hv.v[q], sh[q]);
+            const float y = z > 0.f ? z : slope * z;
+            const bool up = y > best.v[q];
+            best.v[q] = up ? y : best.v[q];
+            slot[q] = up ? (unsigned char)s : slot[q];
+        }
+    }
+    const Vec<V> v2 = vload<V>(h2 + i * ldh2 + c0);
+    Vec<V> y;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        const float z = fmaf(scale2[c0 + q], v2.v[q], shift2[c0 + q]);
+        y.v[q] = (z > 0.f ? z : slope2 * z) + best.v[q];
+    }
+    vstore<V>(out + i * ldo + c0, y);
+    if (out2) vstore<V>(out2 + i * ldo2 + c0, y);
+#pragma unroll
+    for (int q = 0; q < V; ++q) arg[i * lda + c0 + q] = slot[q];
+}
+
 // ---- transposed applies (backward of the above; the operators carry no gradient) ---------------
 // A column of the transposed operator = the in-edges of point j, ascending edge id.  Each op is an
 // accumulator: init(), step(i, s, g, c0) once per in-edge (i = source point, s = its slot,

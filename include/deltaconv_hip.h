@@ -261,6 +261,13 @@ int dc_knn_max(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t
 int dc_knn_max_affine(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh,
                       const float* scale, const float* shift, float slope, float* out, int64_t ldo, uint8_t* arg,
                       void* stream);
+/* The same with the layer's last s_mlp block in its epilogue (round 6; tiled twin: dc_knn_max_affine_residual_tiled):
+ * out = act2(scale2 h2 + shift2) + max_s act(scale h[nbr[i,s]] + shift) = `x = self.s_mlp(x) + x_max` of nn/deltaconv.py:54-59 with both
+ * BatchNorm + LeakyReLU pairs folded in; out2 (may be NULL): second copy.  Same bits as dc_knn_max_affine + dc_bn_act2(residual). */
+int dc_knn_max_affine_residual(const int32_t* nbr, int32_t n, int32_t k, const float* h, int32_t C, int64_t ldh,
+                               const float* scale, const float* shift, float slope, const float* h2, int64_t ldh2,
+                               const float* scale2, const float* shift2, float slope2, float* out, int64_t ldo, float* out2,
+                               int64_t ldo2, uint8_t* arg, void* stream);
 int dc_knn_max_backward(const int32_t* tptr, const int32_t* tedge, int32_t n, int32_t k, const uint8_t* arg,
                         const float* dout, int32_t C, int64_t ldo, float* dh, int64_t ldh, int32_t accumulate,
                         void* stream);

@@ -218,6 +218,18 @@ void hc_knn_max_affine(int V, const int* nbr, int n, int k, const float* h, int 
         }
 }
 
+void hc_knn_max_affine_residual(int V, const int* nbr, int n, int k, const float* h, int C, long ldh, const float* scale,
+                                const float* shift, float slope, const float* h2, long ldh2, const float* scale2,
+                                const float* shift2, float slope2, float* out, long ldo, float* out2, long ldo2,
+                                unsigned char* arg) {
+    using namespace dcell;
+    for (long i = 0; i < n; ++i)
+        for (int c0 = 0; c0 < C; c0 += V) {
+            if (V == 4) knn_max_affine_residual_fwd<4>(i, c0, nbr + i * k, k, h, ldh, scale, shift, slope, h2, ldh2, scale2, shift2, slope2, out, ldo, out2, ldo2, arg, C);
+            else knn_max_affine_residual_fwd<1>(i, c0, nbr + i * k, k, h, ldh, scale, shift, slope, h2, ldh2, scale2, shift2, slope2, out, ldo, out2, ldo2, arg, C);
+        }
+}
+
 void hc_knn_max_bwd(int V, const int* tptr, const int* tedge, int n, int k, const unsigned char* arg,
                     const float* dout, int C, long ldo, float* dh, long ldh, int acc) {
     using namespace dcell;

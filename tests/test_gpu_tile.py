@@ -290,10 +290,12 @@ def test_device_clock_stamps_of_the_tiled_applies():
     assert lib.raw("dc_stamp_count")() == 0 and torch.equal(out, ref)
 
 
+@pytest.mark.parametrize("plan", [True, False])
 @pytest.mark.parametrize("kind,train", [("cls", True), ("seg2", True), ("cls", False)])
-def test_max_aggregation_with_residual_block_epilogue_is_bit_identical(kind, train):
+def test_max_aggregation_with_residual_block_epilogue_is_bit_identical(kind, train, plan):
     """Round 6: from the tile plan the max aggregation takes the layer's last s_mlp block (BatchNorm + activation + the residual
-    add of deltaconv.py:59) into its epilogue (dc_knn_max_affine_residual_tiled).  Same addends as the two-launch form: logits,
+    add of deltaconv.py:59) into its epilogue (dc_knn_max_affine_residual_tiled; plan = False: the gather-path twin
+    dc_knn_max_affine_residual, what small batches and k = 30 run).  Same addends as the two-launch form: logits,
     every gradient and every BatchNorm buffer identical bit for bit; depth-2 blocks (the part-segmentation net) and inference
     coefficients included."""
     import os
@@ -305,7 +307,8 @@ def test_max_aggregation_with_residual_block_epilogue_is_bit_identical(kind, tra
 
     def run(fuse):
         L.FUSE_MAX_RESIDUAL[0] = fuse
-        os.environ["DC_TILE_P"] = "64"
+        if plan:
+            os.environ["DC_TILE_P"] = "64"
         try:
             torch.manual_seed(5)
             m = (DeltaNetSegmentation(3, 8, mlp_depth=2) if seg else DeltaNetClassification(3, 40)).to(DEV).train(train)

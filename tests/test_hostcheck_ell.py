@@ -26,6 +26,8 @@ def hc():
     lib.hc_knn_max.argtypes = [ci, vp, ci, ci, vp, ci, cl, vp, cl, vp]
     lib.hc_knn_max_bwd.argtypes = [ci, vp, vp, ci, ci, vp, vp, ci, cl, vp, cl, ci]
     lib.hc_knn_max_affine.argtypes = [ci, vp, ci, ci, vp, ci, cl, vp, vp, ctypes.c_float, vp, cl, vp]
+    lib.hc_knn_max_affine_residual.argtypes = [ci, vp, ci, ci, vp, ci, cl, vp, vp, ctypes.c_float, vp, cl, vp, vp, ctypes.c_float, vp, cl,
+                                               vp, cl, vp]
     lib.hc_knn_sum.argtypes = [ci, vp, ci, ci, vp, ci, cl, ctypes.c_float, vp, cl]
     lib.hc_knn_sum_bwd.argtypes = [ci, vp, vp, ci, ci, vp, ci, cl, ctypes.c_float, vp, cl, ci]
     lib.hc_grad_T_sum.argtypes = [ci, vp, vp, vp, ci, ci, vp, ci, cl, vp, cl, vp, cl, vp, cl]
@@ -178,6 +180,22 @@ def test_forward_and_transposed(hc, graph, C, pad):
     arg2 = torch.zeros(n, C, dtype=torch.uint8)
     hc.hc_knn_max_affine(V, P(nbr32), n, k, P(hb2), C, ld, P(sc.contiguous()), P(sh.contiguous()), 0.25, P(out2), ld, P(arg2))
     assert torch.equal(out2[:, :C], mx) and torch.equal(arg2.long(), slot)
+
+    # round 6: the layer's last s_mlp block in the epilogue (dc_knn_max_affine_residual): act2(scale2 h2 + shift2) + max, the same
+    # two addends as dc_bn_act2 with the maximum as residual -> same bits as "affine max, then block + residual" on ARBITRARY values
+    hr, h2 = torch.randn(n, C), torch.randn(n, C)
+    s1, t1, s2, t2 = torch.randn(C), torch.randn(C), torch.randn(C), torch.randn(C)
+    hb3 = torch.zeros(n, ld); hb3[:, :C] = hr
+    hb4 = torch.zeros(n, ld); hb4[:, :C] = h2
+    mx3, arg3 = buf(n, C, ld), torch.zeros(n, C, dtype=torch.uint8)
+    hc.hc_knn_max_affine(V, P(nbr32), n, k, P(hb3), C, ld, P(s1), P(t1), 0.2, P(mx3), ld, P(arg3))
+    z2 = torch.addcmul(t2, s2, h2)                                       # fmaf(scale2, h2, shift2): one rounding
+    want = torch.where(z2 > 0, z2, 0.2 * z2) + mx3[:, :C]
+    out3, dup3, arg4 = buf(n, C, ld), buf(n, C, ld), torch.zeros(n, C, dtype=torch.uint8)
+    hc.hc_knn_max_affine_residual(V, P(nbr32), n, k, P(hb3), C, ld, P(s1), P(t1), 0.2, P(hb4), ld, P(s2), P(t2),
+                                  0.2, P(out3), ld, P(dup3), ld, P(arg4))
+    assert torch.equal(arg4, arg3) and torch.equal(out3[:, :C], dup3[:, :C])
+    assert rel_err(out3[:, :C], want) < 2e-7                              # (torch's addcmul may or may not fuse: bits on the GPU test)
 
 
 @pytest.mark.parametrize("C,pad", [(8, 0), (8, 4), (5, 0)])
