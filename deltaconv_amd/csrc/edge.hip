@@ -46,7 +46,12 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ shift, float slope,
                                                          float* __restrict__ out, long ldo,
-                                                         unsigned char* __restrict__ arg) {
+                                                         unsigned char* __restrict__ arg,
+                                                         // optional epilogue (round 6): the layer's last s_mlp block rides along,
+                                                         // out = act2(scale2 h2 + shift2) + x_max (deltaconv.py:59), copy in out2
+                                                         const float* __restrict__ h2, long ldh2,
+                                                         const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                         float slope2, float* __restrict__ out2, long ldo2) {
     const long total = n * groups;
     const int C = groups * V;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
@@ -59,6 +64,12 @@ __global__ __launch_bounds__(256) void edge_apply_kernel(const float* __restrict
             const int c = c0 + q;
             o.v[q] = dcnn::act(fmaf(scale[c], pick(scale[c], mx.v[q], mn.v[q]), shift[c]), slope);
             if (arg) arg[i * C + c] = scale[c] >= 0.f ? argmax[i * C + c] : argmin[i * C + c];
+        }
+        if (h2) {
+            const FV<V> x = ldv<V>(h2 + i * ldh2 + c0);
+#pragma unroll
+            for (int q = 0; q < V; ++q) o.v[q] = dcnn::act(fmaf(scale2[c0 + q], x.v[q], shift2[c0 + q]), slope2) + o.v[q];
+            if (out2) stv<V>(out2 + i * ldo2 + c0, o);
         }
         stv<V>(out + i * ldo + c0, o);
     }
@@ -149,21 +160,56 @@ DC_EXPORT int dc_edge_gather_stats(const float* y, int64_t ldy, const int32_t* n
 }
 
 // out[i,c] = leaky_slope(scale_c * (scale_c >= 0 ? amax : amin) + shift_c); arg (may be NULL) = slot
+static int edge_max_apply(const char* name, const float* amax, const float* amin, const uint8_t* argmax, const uint8_t* argmin,
+                          int32_t n, int32_t C, const float* scale, const float* shift, float slope, float* out, int64_t ldo,
+                          uint8_t* arg, const float* h2, int64_t ldh2, const float* scale2, const float* shift2, float slope2,
+                          float* out2, int64_t ldo2, void* stream) {
+    if (!(amax && amin && argmax && argmin && scale && shift && out)) {
+        dc_set_error("%s: null pointer", name);
+        return DC_ERR_ARG;
+    }
+    if (!(n >= 0 && C >= 1 && ldo >= C && slope >= 0.f && (!h2 || (ldh2 >= C && (!out2 || ldo2 >= C))))) {
+        dc_set_error("%s: bad size / negative slope", name);
+        return DC_ERR_ARG;
+    }
+    if (n == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (C % 4 == 0 && ldo % 4 == 0 && al16(out) && al16(amax) && al16(amin) &&
+        (!h2 || (ldh2 % 4 == 0 && al16(h2) && (!out2 || (ldo2 % 4 == 0 && al16(out2))))))
+        hipLaunchKernelGGL(edge_apply_kernel<4>, dim3(stream_grid((long)n * (C / 4))), dim3(256), 0, s, amax, amin, argmax,
+                           argmin, (long)n, C / 4, scale, shift, slope, out, (long)ldo, arg, h2, (long)ldh2, scale2, shift2, slope2,
+                           out2, (long)ldo2);
+    else
+        hipLaunchKernelGGL(edge_apply_kernel<1>, dim3(stream_grid((long)n * C)), dim3(256), 0, s, amax, amin, argmax,
+                           argmin, (long)n, C, scale, shift, slope, out, (long)ldo, arg, h2, (long)ldh2, scale2, shift2, slope2, out2,
+                           (long)ldo2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        dc_set_error("%s: %s", name, hipGetErrorString(e));
+        return DC_ERR_LAUNCH;
+    }
+    return DC_OK;
+}
+
 DC_EXPORT int dc_edge_max_apply(const float* amax, const float* amin, const uint8_t* argmax, const uint8_t* argmin,
                                 int32_t n, int32_t C, const float* scale, const float* shift, float slope, float* out,
                                 int64_t ldo, uint8_t* arg, void* stream) {
-    DC_REQUIRE(amax && amin && argmax && argmin && scale && shift && out, "dc_edge_max_apply: null pointer");
-    DC_REQUIRE(n >= 0 && C >= 1 && ldo >= C && slope >= 0.f, "dc_edge_max_apply: bad size / negative slope");
-    if (n == 0) return DC_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (C % 4 == 0 && ldo % 4 == 0 && al16(out) && al16(amax) && al16(amin))
-        hipLaunchKernelGGL(edge_apply_kernel<4>, dim3(stream_grid((long)n * (C / 4))), dim3(256), 0, s, amax, amin, argmax,
-                           argmin, (long)n, C / 4, scale, shift, slope, out, (long)ldo, arg);
-    else
-        hipLaunchKernelGGL(edge_apply_kernel<1>, dim3(stream_grid((long)n * C)), dim3(256), 0, s, amax, amin, argmax,
-                           argmin, (long)n, C, scale, shift, slope, out, (long)ldo, arg);
-    DC_CHECK_LAUNCH("dc_edge_max_apply");
-    return DC_OK;
+    return edge_max_apply("dc_edge_max_apply", amax, amin, argmax, argmin, n, C, scale, shift, slope, out, ldo, arg, nullptr, 0,
+                          nullptr, nullptr, 0.f, nullptr, 0, stream);
+}
+
+// The same with the layer's last s_mlp block in its epilogue (round 6, as dc_knn_max_affine_residual for the other layers):
+// out = act2(scale2 h2 + shift2) + x_max, second copy in out2 (may be NULL).  Same bits as dc_edge_max_apply + dc_bn_act2(residual).
+DC_EXPORT int dc_edge_max_apply_residual(const float* amax, const float* amin, const uint8_t* argmax, const uint8_t* argmin,
+                                         int32_t n, int32_t C, const float* scale, const float* shift, float slope,
+                                         const float* h2, int64_t ldh2, const float* scale2, const float* shift2, float slope2,
+                                         float* out, int64_t ldo, float* out2, int64_t ldo2, uint8_t* arg, void* stream) {
+    if (!(h2 && scale2 && shift2)) {
+        dc_set_error("dc_edge_max_apply_residual: null pointer");
+        return DC_ERR_ARG;
+    }
+    return edge_max_apply("dc_edge_max_apply_residual", amax, amin, argmax, argmin, n, C, scale, shift, slope, out, ldo, arg, h2, ldh2,
+                          scale2, shift2, slope2, out2, ldo2, stream);
 }
 
 // Backward of the pair above: dy[Nt,C] (gradient w.r.t. y = Linear(x)), dgamma, dbeta.

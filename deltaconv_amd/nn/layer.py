@@ -168,7 +168,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
 
         # ---- scalar stream, max aggregation over the k neighbours (deltaconv.py:50-54)
         max_saved = None
-        pending_max = None
+        pending_max = pending_edge = None
         if nm == 0:
             x_max, ldm = _rows(x_max_ext)
         else:
@@ -195,11 +195,9 @@ class DeltaConvLayerFn(torch.autograd.Function):
                      rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
                      coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)
                 argsel = torch.empty(n, co, dtype=torch.uint8, device=dev)   # the selected slot: backward from the tile plan
-                call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], slope_m,
-                     x_max, co, argsel)
+                # (applied below, behind the last s_mlp block, whose BatchNorm / activation / residual add it takes along)
+                pending_edge = (stat, args, coef_m, slope_m, argsel)
                 max_saved = (stat, args, argsel)
-                if SLOT_TAP[0] is not None:
-                    SLOT_TAP[0].append(argsel.clone())
                 saved_m.append((inp, y0, coef_m, use_m))
             else:
                 hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
@@ -247,6 +245,17 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 _ops.fwd_knn_max(g, hm, co, co, x_max, co, arg, affine=(coef_m[2], coef_m[3], slope_m))
             if SLOT_TAP[0] is not None:
                 SLOT_TAP[0].append(arg.clone())
+        if pending_edge is not None:
+            stat, args, coef_m, slope_m, argsel = pending_edge
+            if FUSE_MAX_RESIDUAL[0] and cfg.slopes_s[-1] is not None:
+                call("dc_edge_max_apply_residual", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], slope_m, hs, co,
+                     coef_s[2], coef_s[3], float(cfg.slopes_s[-1]), x_new, ldxn, x_dup, x_dup.stride(0) if x_dup is not None else 0,
+                     argsel)
+                fused_max = True
+            else:
+                call("dc_edge_max_apply", stat[0], stat[1], args[0], args[1], n, co, coef_m[2], coef_m[3], slope_m, x_max, co, argsel)
+            if SLOT_TAP[0] is not None:
+                SLOT_TAP[0].append(argsel.clone())
         if not fused_max:
             call("dc_bn_act2", hs, n, co, co, coef_s[2], coef_s[3], cfg.slopes_s[-1], x_max, ldm, x_new, ldxn, x_dup,
                  x_dup.stride(0) if x_dup is not None else 0)

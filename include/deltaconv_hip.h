@@ -335,6 +335,13 @@ int dc_edge_gather_stats(const float* y, int64_t ldy, const int32_t* nbr, int32_
 int dc_edge_max_apply(const float* amax, const float* amin, const uint8_t* argmax, const uint8_t* argmin, int32_t n,
                       int32_t C, const float* scale, const float* shift, float slope, float* out, int64_t ldo,
                       uint8_t* arg, void* stream);
+/* dc_edge_max_apply with the layer's last s_mlp block in its epilogue (round 6): out = act2(scale2 h2 + shift2) + x_max
+ * (`x = self.s_mlp(x) + x_max`, deltaconv/nn/deltaconv.py:59), second copy in out2 (may be NULL).  Same bits as
+ * dc_edge_max_apply followed by dc_bn_act2 with x_max as residual. */
+int dc_edge_max_apply_residual(const float* amax, const float* amin, const uint8_t* argmax, const uint8_t* argmin, int32_t n,
+                               int32_t C, const float* scale, const float* shift, float slope, const float* h2,
+                               int64_t ldh2, const float* scale2, const float* shift2, float slope2, float* out,
+                               int64_t ldo, float* out2, int64_t ldo2, uint8_t* arg, void* stream);
 int dc_edge_max_backward(const float* dout, int64_t lddo, const float* y, int64_t ldy, const int32_t* tptr,
                          const int32_t* tedge, int32_t n, int32_t k, int32_t C, const float* amax, const float* amin,
                          const uint8_t* argmax, const uint8_t* argmin, const float* s1pt, const float* scale,
