@@ -184,17 +184,20 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 
 // ---- host helpers --------------------------------------------------------------------------
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-// rows per block: enough blocks (~768: three per CU) to fill 256 CUs even for narrow matrices; multiple of RT
-inline int rows_per_chunk(long R, int C) {
-    const long coltiles = (C + CT * 4 - 1) / (CT * 4);
+// rows per block: enough blocks (~768: three per CU) to fill 256 CUs even for narrow matrices; multiple of RT.  The GATHERING
+// reduction of the layer-0 edge statistics (edge.hip: EdgeStatsF, k row gathers per element) wants twice as many, shorter
+// workgroups (30 vs 35 us at C2): `blocks` is a parameter of the launch, the workspace is sized for the larger count.
 #ifndef DC_COLRED_BLOCKS
 #define DC_COLRED_BLOCKS 768      // round 6, same-box A/B of the step (profiles/r06_labs.txt item 6): 768 beats 1536 / 3072 / 384
 #endif
-    long rpc = (R * coltiles / DC_COLRED_BLOCKS + RT - 1) / RT * RT;
+constexpr int COLRED_BLOCKS_MAX = 2 * DC_COLRED_BLOCKS;
+inline int rows_per_chunk(long R, int C, int blocks = DC_COLRED_BLOCKS) {
+    const long coltiles = (C + CT * 4 - 1) / (CT * 4);
+    long rpc = (R * coltiles / blocks + RT - 1) / RT * RT;
     return (int)std::min<long>(std::max<long>(rpc, RT), 512);
 }
-inline int chunks_of(long R, int C) { const int rpc = rows_per_chunk(R, C); return (int)((R + rpc - 1) / rpc); }
-inline size_t ws_need(long R, int C) { return ((size_t)chunks_of(R, C) * 2 * C + 2 * (size_t)C) * 8 + 2 * (size_t)C * 4; }
+inline int chunks_of(long R, int C, int blocks = DC_COLRED_BLOCKS) { const int rpc = rows_per_chunk(R, C, blocks); return (int)((R + rpc - 1) / rpc); }
+inline size_t ws_need(long R, int C) { return ((size_t)chunks_of(R, C, COLRED_BLOCKS_MAX) * 2 * C + 2 * (size_t)C) * 8 + 2 * (size_t)C * 4; }
 inline int stream_grid(long total) { return (int)std::min<long>((total + 255) / 256, 256L * 16); }
 
 struct Ws {
@@ -203,15 +206,15 @@ struct Ws {
 inline Ws carve(void* ws, long R, int C) {
     Ws w;
     w.partial = static_cast<double*>(ws);
-    w.sums = w.partial + (size_t)chunks_of(R, C) * 2 * C;
+    w.sums = w.partial + (size_t)chunks_of(R, C, COLRED_BLOCKS_MAX) * 2 * C;
     w.m1 = reinterpret_cast<float*>(w.sums + 2 * (size_t)C);
     w.m2 = w.m1 + C;
     return w;
 }
 
 template <int V, class F, class FIN>
-void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s, FIN fin) {
-    const int rpc = rows_per_chunk(R, C), chunks = chunks_of(R, C);
+void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s, FIN fin, int blocks = DC_COLRED_BLOCKS) {
+    const int rpc = rows_per_chunk(R, C, blocks), chunks = chunks_of(R, C, blocks);
     dim3 grid(chunks, dc_cdiv(C, CT * V));
     hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, chunks, rpc, w.partial);
     hipLaunchKernelGGL((colreduce_final_kernel<FIN>), dim3(C), dim3(64), 0, s, w.partial, chunks, C, fin);

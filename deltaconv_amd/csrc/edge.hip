@@ -151,9 +151,9 @@ DC_EXPORT int dc_edge_gather_stats(const float* y, int64_t ldy, const int32_t* n
     const EdgeStatsF<1> f1{y, (long)ldy, nbr, k, amax, amin, argmax, argmin, s1pt, (long)C, (long)C};
     if (compute_stats) {   // statistics over all E = n*k edges
         const BnFin fin{(long)n * k, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
-        if (v4) run_colreduce<4>(f4, n, C, w, s, fin); else run_colreduce<1>(f1, n, C, w, s, fin);
+        if (v4) run_colreduce<4>(f4, n, C, w, s, fin, COLRED_BLOCKS_MAX); else run_colreduce<1>(f1, n, C, w, s, fin, COLRED_BLOCKS_MAX);
     } else {
-        if (v4) run_colreduce<4>(f4, n, C, w, s, NoFin{}); else run_colreduce<1>(f1, n, C, w, s, NoFin{});
+        if (v4) run_colreduce<4>(f4, n, C, w, s, NoFin{}, COLRED_BLOCKS_MAX); else run_colreduce<1>(f1, n, C, w, s, NoFin{}, COLRED_BLOCKS_MAX);
     }
     DC_CHECK_LAUNCH("dc_edge_gather_stats");
     return DC_OK;
