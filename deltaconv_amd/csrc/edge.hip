@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(long total, int groups, i
 // (ascending edge id) order and the same closing expression as edge_bwd_point: bit-identical.
 struct EdgeTB {
     static constexpr int TAG = 16;
+    static constexpr int CAPT = 248, ECAPT = 2560, WGS = 1;
     static constexpr bool COEF = false, ARG = true;
     static constexpr int NST = 1;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;      // in = y, in + hs = dzs (same row stride)

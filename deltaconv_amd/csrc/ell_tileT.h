@@ -40,10 +40,19 @@ template <int P> constexpr int ecap_entries() { return 2560; }
 template <int FAMILY>
 __device__ __forceinline__ void st16(float* p, const Vec<4>& a) { dc_store16<FAMILY>(p, *reinterpret_cast<const dc_f32x4*>(&a)); }
 
-template <int R, int P>
-inline size_t lds_bytes(bool coef, bool arg) {
-    constexpr int ECAP = ecap_entries<P>(), CAP = Geom<R, P>::CAP;
-    return (size_t)Geom<R, P>::CAPR * 256 + (coef ? (size_t)ECAP * 8 : 0) + (size_t)ECAP * 4 + (arg ? (size_t)(CAP + 8) * 64 : 0) + 16;
+// capacity of a body's kernel: BODY::CAPT unique source rows / BODY::ECAPT in-edge entries in LDS, BODY::WGS waves per SIMD asked of
+// the compiler (HIP's second __launch_bounds__ argument: the register budget).  Default: the forward kernels' 248 rows, 2560 entries, one workgroup per CU.
+template <int R, int P, class BODY>
+struct TGeom {
+    static constexpr int NW = P * 16 / 64;
+    static constexpr int CAP = BODY::CAPT, ECAP = BODY::ECAPT;
+    static constexpr int CAPR = (CAP * R + 4 * NW - 1) / (4 * NW) * (4 * NW);
+    static constexpr int RIT = CAPR / (4 * NW);
+};
+template <int R, int P, class BODY>
+inline size_t lds_bytes() {
+    using TG = TGeom<R, P, BODY>;
+    return (size_t)TG::CAPR * 256 + (BODY::COEF ? (size_t)TG::ECAP * 8 : 0) + (size_t)TG::ECAP * 4 + (BODY::ARG ? (size_t)(TG::CAP + 8) * 64 : 0) + 16;
 }
 
 // BODY (per-thread accumulator object, copied from the kernel argument):
@@ -55,12 +64,12 @@ inline size_t lds_bytes(bool coef, bool arg) {
 //   void step(int s, G2 g, const Vec<4>& p0, const Vec<4>& p1, unsigned aw);
 //   void finish(long j, int c);
 template <int R, int P, class BODY>
-__global__ __launch_bounds__(P * 16) void tileT_kernel(DcTilePlanT L, const int* __restrict__ plan, const float* __restrict__ coefT,
+__global__ __launch_bounds__(P * 16, BODY::WGS) void tileT_kernel(DcTilePlanT L, const int* __restrict__ plan, const float* __restrict__ coefT,
                                                        int slabs, int remap, int upw, unsigned long long* stamp,
                                                        const BODY body0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using GM = Geom<R, P>;
-    constexpr int NW = GM::NW, CAP = GM::CAP, CAPR = GM::CAPR, RIT = GM::RIT, ECAP = ecap_entries<P>();
+    using GM = TGeom<R, P, BODY>;
+    constexpr int NW = GM::NW, CAP = GM::CAP, CAPR = GM::CAPR, RIT = GM::RIT, ECAP = GM::ECAP;
     const long units = (long)L.T * slabs;
     const long u0 = dc_xcd_block(remap) * upw, u1 = min(u0 + (long)upw, units);
     if (u0 >= u1) return;
@@ -201,6 +210,7 @@ constexpr int ST = DC_ST_ELL;   // store family of the transposed applies (commo
 template <bool SUM>
 struct GradTB {
     static constexpr int TAG = 13;                     // dc_stamp_tag kind
+    static constexpr int CAPT = 248, ECAPT = 2560, WGS = 1;
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 1;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -232,6 +242,7 @@ struct GradTB {
 // div^T : dv[2j+a] (+)= sum_e D[e,a] dy[i]
 struct DivTB {
     static constexpr int TAG = 15;                     // dc_stamp_tag kind
+    static constexpr int CAPT = 248, ECAPT = 2560, WGS = 1;
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -252,6 +263,7 @@ struct DivTB {
 // backward of [div v | curl v | norm v] (ell_math.h: DivCurlNormT): pieces = dout[i, 0:C], dout[i, C:2C]
 struct DivCurlNormTB {
     static constexpr int TAG = 11;                     // dc_stamp_tag kind
+    static constexpr int CAPT = 248, ECAPT = 2560, WGS = 1;
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -286,6 +298,7 @@ struct DivCurlNormTB {
 // backward of the Hodge-Laplacian apply (HodgeT): pieces = dh[2i], dh[2i+1]
 struct HodgeTB {
     static constexpr int TAG = 12;                     // dc_stamp_tag kind
+    static constexpr int CAPT = 248, ECAPT = 2560, WGS = 1;
     static constexpr bool COEF = true, ARG = false;
     static constexpr int NST = 2;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -311,6 +324,11 @@ struct HodgeTB {
 // max-aggregation backward (KnnMaxT): dh[j,c] (+)= sum over in-edges (i,s) with arg[i,c] == s of dout[i,c]
 struct KnnMaxTB {
     static constexpr int TAG = 14;                     // dc_stamp_tag kind
+#if defined(DC_KNNMAXT_2WG) && DC_KNNMAXT_2WG
+    static constexpr int CAPT = 192, ECAPT = 1536, WGS = 8;   // lab: 66 KB of LDS, 8 waves per SIMD = <= 64 registers: two workgroups per CU
+#else
+    static constexpr int CAPT = 248, ECAPT = 2560, WGS = 1;
+#endif
     static constexpr bool COEF = false, ARG = true;
     static constexpr int NST = 1;
     const float* in; long ldj, hs; const unsigned char* arg; long lda;
@@ -334,14 +352,14 @@ struct KnnMaxTB {
 template <int R, int P, class BODY>
 inline void launch_one(const DcTilePlanT& L, const int* plan, const float* coefT, int C, BODY body, hipStream_t s) {
     const int slabs = C / CS;
-    const size_t lds = lds_bytes<R, P>(BODY::COEF, BODY::ARG);
+    const size_t lds = lds_bytes<R, P, BODY>();
     static unsigned long long attr_set = 0;             // > 64 KiB of dynamic LDS: once per kernel and device (common.h)
     if (!dc_ensure_lds(&attr_set, reinterpret_cast<const void*>(&tileT_kernel<R, P, BODY>), 160 * 1024, "tiled transposed apply")) return;
     const long units = (long)L.T * slabs;
     const long per_cu = std::max<long>(1, std::min<long>(2048 / (P * 16), (160 * 1024) / (long)lds));
     const long capacity = per_cu * dctile::device_cus();
     int upw = (int)((units + capacity - 1) / capacity);
-    if (upw < 2 && units >= 2L * dctile::device_cus()) upw = 2;
+    if (upw < 2 && units >= 2L * dctile::device_cus() && per_cu < 2) upw = 2;   // (two workgroups per CU overlap by themselves)
     if (dc_option(7) > 0) upw = dc_option(7);
     hipLaunchKernelGGL((tileT_kernel<R, P, BODY>), dim3((unsigned)((units + upw - 1) / upw)), dim3(P * 16), lds, s, L, plan, coefT, slabs,
                        dc_option(DC_OPT_XCD_REMAP), upw, dc_stamp_next(1000 * BODY::TAG + C), body);
