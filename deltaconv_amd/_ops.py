@@ -13,6 +13,36 @@ def _f32c(t):
     return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
 
 
+def copy_many(pairs):
+    """dst.copy_(src) for every (src, dst) of `pairs` in ONE launch (csrc/optim.hip: dc_copy_many): 1-D / 2-D device tensors of
+    equal shape and dtype (4- or 8-byte elements), unit stride along the last dimension, rows may be strided.  Pairs it
+    does not take (other layouts / dtypes / devices) go through torch's copy, one launch each."""
+    table = []
+    for src, dst in pairs:
+        es = src.element_size()
+        ok = (src.is_cuda and dst.is_cuda and src.device == dst.device and src.dtype == dst.dtype and src.shape == dst.shape
+              and src.dim() in (1, 2) and es in (4, 8) and src.numel() < (1 << 30)
+              and (src.numel() == 0 or (src.stride(-1) == 1 and dst.stride(-1) == 1)))
+        if not ok:
+            dst.copy_(src, non_blocking=True)
+            continue
+        if src.numel() == 0:
+            continue
+        w = es // 4
+        rows, cols = (1, src.shape[0]) if src.dim() == 1 else src.shape
+        lds, ldd = (cols, cols) if src.dim() == 1 else (src.stride(0), dst.stride(0))
+        if rows > 1 and (lds < cols or ldd < cols):
+            dst.copy_(src, non_blocking=True)           # broadcast / overlapping rows
+            continue
+        table.append((src.data_ptr(), dst.data_ptr(), lds * w, ldd * w, rows, cols * w))
+    if table:
+        import ctypes
+        n = len(table)
+        i64, i32 = ctypes.c_int64 * n, ctypes.c_int32 * n
+        col = lambda j: [e[j] for e in table]
+        lib.call("dc_copy_many", i64(*col(0)), i64(*col(1)), i64(*col(2)), i64(*col(3)), i32(*col(4)), i32(*col(5)), n)
+
+
 # ---- forward applies / max aggregation: from the graph's tile plan when it applies (neighbour rows in LDS,
 # csrc/ell_tile.h), else through the gather path.  Same results bit for bit; `a`, `out` may be column blocks of wider
 # buffers (leading dimensions lda / ldo).

@@ -190,6 +190,98 @@ static void launch_tn_reduce(const float* partial, int slabs, long mn, int N, fl
                            accumulate);
 }
 
+// Several ordered slab reductions in ONE launch (round 6): an autograd node that forms three or four weight gradients (a DeltaConv
+// layer: v_mlp, s_mlp, max-aggregation Linear) queues their partial tiles and sums them all at the end of its backward -- one
+// launch instead of one per weight (inside a replayed step a launch costs ~4.7 us whatever it does).  Same association as the two
+// kernels above, hence the same bits: chain q = 0.f + p_q + p_(q+16) + ..., then the chains in order on top of 0.f (empty chains
+// add +0.f, which changes nothing: no sum here is ever -0.f).  Table by value in the kernel arguments; each entry runs in the form
+// the single launch would have taken (first version: one serial loop per thread over up to 128 slabs -- the step got 0.22 ms SLOWER,
+// profiles/r06_labs.txt item 8).
+constexpr int TNR_MAX = 16;
+struct TnReduceTable {
+    const float* partial[TNR_MAX];
+    float* C[TNR_MAX];
+    long mn[TNR_MAX], ldc[TNR_MAX];
+    int N[TNR_MAX], slabs[TNR_MAX], accumulate[TNR_MAX];
+    int first_block[TNR_MAX + 1];          // prefix sums of the entries' block counts
+    int count;
+};
+// an entry is "streamed" (block = 1024 elements, every chain holds one slab, all 16-byte loads of a thread in flight) when it has
+// at most 16 slabs and 16-byte geometry; else "chained" (block = 64 elements x 16 chains over 4 waves, scalar accesses)
+__host__ __device__ inline bool tnr_streamed(const float* partial, const float* C, long mn, long ldc, int N, int slabs) {
+    return slabs <= 16 && mn % 4 == 0 && N % 4 == 0 && ldc % 4 == 0 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+}
+__global__ __launch_bounds__(256) void gemm_tn_reduce_many_kernel(TnReduceTable t) {
+    __shared__ float sm[16][64];
+    int lo = 0, hi = t.count;
+    const int blk = blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.first_block[mid] <= blk) lo = mid;
+        else hi = mid;
+    }
+    const float* __restrict__ partial = t.partial[lo];
+    float* __restrict__ C = t.C[lo];
+    const long mn = t.mn[lo], ldc = t.ldc[lo];
+    const int N = t.N[lo], slabs = t.slabs[lo], accumulate = t.accumulate[lo];
+    const int local = blk - t.first_block[lo];
+    if (tnr_streamed(partial, C, mn, ldc, N, slabs)) {               // uniform over the entry
+        const long e = ((long)local * 256 + threadIdx.x) * 4;
+        if (e >= mn) return;
+        float v[16][4];
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl)
+            if (sl < slabs) {
+                const float4 q = *reinterpret_cast<const float4*>(partial + (long)sl * mn + e);
+                v[sl][0] = q.x; v[sl][1] = q.y; v[sl][2] = q.z; v[sl][3] = q.w;
+            }
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl)
+            if (sl < slabs)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[j] += (0.f + v[sl][j]);
+        float* dst = C + (e / N) * ldc + (e % N);
+        float4 o = {sum[0], sum[1], sum[2], sum[3]};
+        if (accumulate) {
+            const float4 d = *reinterpret_cast<const float4*>(dst);
+            o.x = d.x + o.x; o.y = d.y + o.y; o.z = d.z + o.z; o.w = d.w + o.w;
+        }
+        *reinterpret_cast<float4*>(dst) = o;
+        return;
+    }
+    // chained: wave w carries chains w, w + 4, w + 8, w + 12 (chain q = slabs q, q + 16, ... in order), four independent
+    // accumulators with their loads in flight together; then the 16 chains in order through LDS
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long e = (long)local * 64 + lane;
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e < mn) {
+#pragma unroll 2
+        for (int s0 = 0; s0 < slabs; s0 += 16) {
+            float x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sl = s0 + w + 4 * j;
+                x[j] = sl < slabs ? partial[(long)sl * mn + e] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (s0 + w + 4 * j < slabs) c[j] += x[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sm[w + 4 * j][lane] = c[j];
+    __syncthreads();
+    if (w == 0 && e < mn) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += sm[q][lane];
+        float* dst = C + (e / N) * ldc + (e % N);
+        *dst = accumulate ? *dst + sum : sum;
+    }
+}
+
 struct Plan {
     int wm, wn, tiles_m, tiles_n, slabs, rows_per_slab;
 };
@@ -284,5 +376,74 @@ DC_EXPORT int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const 
     const long mn = (long)N * K;
     launch_tn_reduce(partial, slabs, mn, K, dW, (long)lddw, accumulate, s);
     DC_CHECK_LAUNCH("dc_linear_bn_backward_weight");
+    return DC_OK;
+}
+
+// ---- the same weight gradients with the slab reduction deferred: product now, ONE reduction launch for several weights later ----
+// dc_gemm_tn_slabs / dc_linear_bn_backward_weight_slabs: the partial tiles [slabs][M][N] only (workspace as above); *slabs <- how
+// many there are (host int).  dc_gemm_tn_reduce_many: C_i[M_i, N_i] (ldc_i) (+)= the ordered sum of the slabs of entry i, for
+// `count` entries (host arrays), bit-identical to what dc_gemm_tn / dc_linear_bn_backward_weight write.  Stream-ordered, capturable.
+DC_EXPORT int dc_gemm_tn_slabs(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N,
+                               void* workspace, size_t workspace_bytes, int32_t* slabs, void* stream) {
+    DC_REQUIRE(A && B && slabs, "dc_gemm_tn_slabs: null pointer");
+    DC_REQUIRE(R >= 1 && M >= 1 && N >= 1, "dc_gemm_tn_slabs: bad size");
+    DC_REQUIRE(lda >= M && ldb >= N, "dc_gemm_tn_slabs: leading dimension smaller than the row");
+    DC_REQUIRE(lda < (1 << 21) && ldb < (1 << 21), "dc_gemm_tn_slabs: leading dimension above 2^21 elements");
+    if (!workspace || workspace_bytes < dc_gemm_tn_workspace_bytes(R, M, N)) {
+        dc_set_error("dc_gemm_tn_slabs: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    *slabs = dc_tn_lds_launch(A, (long)lda, B, (long)ldb, (long)R, M, N, static_cast<float*>(workspace),
+                              static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_gemm_tn_slabs");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_linear_bn_backward_weight_slabs(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
+                                                 float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K,
+                                                 void* workspace, size_t workspace_bytes, int32_t* slabs, void* stream) {
+    DC_REQUIRE(dy && h && coefs && X && slabs, "dc_linear_bn_backward_weight_slabs: null pointer");
+    DC_REQUIRE(R >= 1 && N >= 1 && K >= 1 && lddy >= N && ldh >= N && ldx >= K, "dc_linear_bn_backward_weight_slabs: bad size");
+    DC_REQUIRE(lddy < (1 << 21) && ldh < (1 << 21) && ldx < (1 << 21),
+               "dc_linear_bn_backward_weight_slabs: leading dimension above 2^21 elements");
+    if (!workspace || workspace_bytes < dc_gemm_tn_workspace_bytes(R, N, K)) {
+        dc_set_error("dc_linear_bn_backward_weight_slabs: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    *slabs = dc_tn_lds_launch(dy, (long)lddy, X, (long)ldx, (long)R, N, K, static_cast<float*>(workspace),
+                              static_cast<hipStream_t>(stream), h, (long)ldh, coefs, slope);
+    DC_CHECK_LAUNCH("dc_linear_bn_backward_weight_slabs");
+    return DC_OK;
+}
+
+DC_EXPORT int dc_gemm_tn_reduce_many(const int64_t* partials, const int64_t* outs, const int64_t* ldc, const int32_t* rows,
+                                     const int32_t* cols, const int32_t* slabs, const int32_t* accumulate, int32_t count,
+                                     void* stream) {
+    DC_REQUIRE(count >= 0 && (count == 0 || (partials && outs && ldc && rows && cols && slabs)), "dc_gemm_tn_reduce_many: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int t0 = 0; t0 < count; t0 += TNR_MAX) {
+        TnReduceTable t;
+        t.count = 0;
+        int blocks = 0;
+        for (int i = t0; i < count && i < t0 + TNR_MAX; ++i) {
+            DC_REQUIRE(partials[i] && outs[i] && rows[i] >= 1 && cols[i] >= 1 && slabs[i] >= 1 && ldc[i] >= cols[i],
+                       "dc_gemm_tn_reduce_many: bad entry");
+            const int c = t.count++;
+            t.partial[c] = reinterpret_cast<const float*>(partials[i]);
+            t.C[c] = reinterpret_cast<float*>(outs[i]);
+            t.mn[c] = (long)rows[i] * cols[i];
+            t.ldc[c] = (long)ldc[i];
+            t.N[c] = cols[i];
+            t.slabs[c] = slabs[i];
+            t.accumulate[c] = accumulate ? accumulate[i] : 0;
+            t.first_block[c] = blocks;
+            blocks += tnr_streamed(t.partial[c], t.C[c], t.mn[c], t.ldc[c], t.N[c], t.slabs[c]) ? dc_cdiv(dc_cdiv(t.mn[c], 4L), 256L)
+                                                                                               : dc_cdiv(t.mn[c], 64L);
+        }
+        if (!t.count) continue;
+        t.first_block[t.count] = blocks;
+        hipLaunchKernelGGL(gemm_tn_reduce_many_kernel, dim3(blocks), dim3(256), 0, s, t);
+    }
+    DC_CHECK_LAUNCH("dc_gemm_tn_reduce_many");
     return DC_OK;
 }

@@ -94,3 +94,75 @@ DC_EXPORT int dc_sgd_step(const int64_t* params, const int64_t* grads, const int
     DC_CHECK_LAUNCH("dc_sgd_step");
     return DC_OK;
 }
+
+// ---- several small (strided) copies in one launch ---------------------------------------------------------------------------
+// Step glue around a replayed step: the batch load (`data.to(device)` of the reference's loops, experiments/train_modelnet.py:99 --
+// here device-to-device into the captured inputs: pos, normals, labels) and the first layer's operand blocks (`torch.cat([x, ...])`
+// of deltaconv/nn/deltaconv.py:57,65: x and v of layer 0 arrive from outside and are copied into the left columns of the layer's
+// operand buffers) were one ~4.7 us launch per tensor.  Units are 4-byte words (fp32 / int32 / halves of int64); entry i copies
+// rows_i x cols_i words, row strides ld_src_i / ld_dst_i.  All of these are <= 0.5 MB: one word per thread access, coalesced along
+// the row, is enough.
+namespace {
+constexpr int CPY_MAX = 16;
+struct CopyTable {
+    const unsigned* src[CPY_MAX];
+    unsigned* dst[CPY_MAX];
+    long lds[CPY_MAX], ldd[CPY_MAX], words[CPY_MAX];
+    int cols[CPY_MAX];
+    int first_block[CPY_MAX + 1];
+    int count;
+};
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyTable t) {
+    int lo = 0, hi = t.count;
+    const int blk = blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.first_block[mid] <= blk) lo = mid;
+        else hi = mid;
+    }
+    const unsigned* __restrict__ src = t.src[lo];
+    unsigned* __restrict__ dst = t.dst[lo];
+    const long lds = t.lds[lo], ldd = t.ldd[lo], words = t.words[lo];
+    const int cols = t.cols[lo];
+    const long base = (long)(blk - t.first_block[lo]) * 1024 + threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const long w = base + it * 256;
+        if (w < words) {
+            const long r = w / cols, c = w % cols;
+            dst[r * ldd + c] = src[r * lds + c];
+        }
+    }
+}
+}  // namespace
+
+// srcs / dsts: HOST arrays of `count` device addresses (4-byte aligned); ld_src / ld_dst / rows / cols in 4-byte words.
+DC_EXPORT int dc_copy_many(const int64_t* srcs, const int64_t* dsts, const int64_t* ld_src, const int64_t* ld_dst,
+                           const int32_t* rows, const int32_t* cols, int32_t count, void* stream) {
+    DC_REQUIRE(count >= 0 && (count == 0 || (srcs && dsts && ld_src && ld_dst && rows && cols)), "dc_copy_many: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int t0 = 0; t0 < count; t0 += CPY_MAX) {
+        CopyTable t;
+        t.count = 0;
+        int blocks = 0;
+        for (int i = t0; i < count && i < t0 + CPY_MAX; ++i) {
+            DC_REQUIRE(rows[i] >= 0 && cols[i] >= 0 && ld_src[i] >= cols[i] && ld_dst[i] >= cols[i], "dc_copy_many: bad entry");
+            if (rows[i] == 0 || cols[i] == 0) continue;
+            DC_REQUIRE(srcs[i] && dsts[i] && srcs[i] % 4 == 0 && dsts[i] % 4 == 0, "dc_copy_many: null or misaligned tensor");
+            const int c = t.count++;
+            t.src[c] = reinterpret_cast<const unsigned*>(srcs[i]);
+            t.dst[c] = reinterpret_cast<unsigned*>(dsts[i]);
+            t.lds[c] = (long)ld_src[i];
+            t.ldd[c] = (long)ld_dst[i];
+            t.words[c] = (long)rows[i] * cols[i];
+            t.cols[c] = cols[i];
+            t.first_block[c] = blocks;
+            blocks += dc_cdiv(t.words[c], 1024L);
+        }
+        if (!t.count) continue;
+        t.first_block[t.count] = blocks;
+        hipLaunchKernelGGL(copy_many_kernel, dim3(blocks), dim3(256), 0, s, t);
+    }
+    DC_CHECK_LAUNCH("dc_copy_many");
+    return DC_OK;
+}

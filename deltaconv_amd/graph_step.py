@@ -24,6 +24,7 @@ import os
 
 import torch
 
+from . import _ops
 from .nn.fused import invalidate_eval_coeffs, planes_snapshot
 
 _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
@@ -143,14 +144,17 @@ class GraphedTrainStep:
         s = self.static
         if batch is s:
             return
+        pairs = []
         for name in ("pos", "norm", "x", "y", "category"):
             dst, src = getattr(s, name, None), getattr(batch, name, None)
             if dst is not None:
                 assert src is not None and src.shape == dst.shape, f"batch.{name}: static shape {tuple(dst.shape)}"
-                # one plain device copy per tensor: torch._foreach_copy_ was tried (round 6) and is SLOWER here -- mixed
-                # dtypes / sizes take its slow path, 38 us of host gap in front of each of its launches
-                # (profiles/r06g_step_timeline.txt) against three back-to-back 4.7 us copies
-                dst.copy_(src, non_blocking=True)
+                pairs.append((src, dst))
+        # all tensors of the batch in ONE launch of the own copy kernel (csrc/optim.hip: dc_copy_many; host tensors and other
+        # layouts fall through to torch's copy).  torch._foreach_copy_ was tried (round 6) and is SLOWER than three plain
+        # copies here: mixed dtypes / sizes take its slow path, 38 us of host gap in front of each of its launches
+        # (profiles/r06g_step_timeline.txt)
+        _ops.copy_many(pairs)
 
     def __call__(self, batch=None):
         if batch is not None:

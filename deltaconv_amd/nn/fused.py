@@ -6,7 +6,10 @@ csrc/rowblock.hip.  No vendor-library GEMM is reachable for fp32 GPU inputs.
 
 Reference semantics: deltaconv/nn/mlp.py:7-17 and nn/nonlin.py:11-86 (Linear(no bias) ->
 BatchNorm1d over rows -> LeakyReLU(0.2);  Linear(no bias) -> VectorNonLin(BatchNorm1d))."""
+import contextlib
+import ctypes
 import os
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -688,9 +691,49 @@ def _require_fp32_gpu(what, *tensors):
                             "deltaconv_amd has no library / CPU product path")
 
 
+# ---- deferred slab reductions of one autograd node ------------------------------------------------------------------
+# A weight gradient is a split-K product: partial tiles per row slab, then their ordered sum.  A node that forms several
+# (a DeltaConv layer: v_mlp, s_mlp, max-aggregation Linear) runs the products as they come and ALL the sums in one launch
+# at the end of its backward (`with tn_batch():`): the same bits (csrc/gemm_tn.hip: gemm_tn_reduce_many_kernel), two or
+# three launches of ~4.7 us less per layer inside a replayed step.  DC_TN_BATCH=0: every weight reduces at once (A/B).
+USE_TN_BATCH = [os.environ.get("DC_TN_BATCH", "1") != "0"]
+_TN = threading.local()
+
+
+class _TnBatch:
+    def __init__(self):
+        self.items = []           # (workspace tensor, slabs, rows, cols, out tensor / view, ldc)
+
+    def add(self, ws, slabs, rows, cols, out, ldc):
+        self.items.append((ws, int(slabs), int(rows), int(cols), out, int(ldc)))
+
+    def flush(self):
+        it, self.items = self.items, []
+        if not it:
+            return
+        n = len(it)
+        i64, i32 = ctypes.c_int64 * n, ctypes.c_int32 * n
+        lib.call("dc_gemm_tn_reduce_many", i64(*[e[0].data_ptr() for e in it]), i64(*[e[4].data_ptr() for e in it]),
+                 i64(*[e[5] for e in it]), i32(*[e[2] for e in it]), i32(*[e[3] for e in it]), i32(*[e[1] for e in it]), None, n)
+
+
+@contextlib.contextmanager
+def tn_batch():
+    """Weight gradients formed inside are complete when the block exits (an inner block joins the outer one)."""
+    if not USE_TN_BATCH[0] or getattr(_TN, "batch", None) is not None:
+        yield
+        return
+    _TN.batch = b = _TnBatch()
+    try:
+        yield
+        b.flush()
+    finally:
+        _TN.batch = None
+
+
 def gemm_tn(a, b):
     """a.t() @ b for a [R,M], b [R,N] (weight gradient dW = dY^T X) on the hand-written fp32-MFMA split-K kernel
-    (csrc/gemm_tn.hip), whatever the shape."""
+    (csrc/gemm_tn.hip), whatever the shape.  Inside `tn_batch()` the result is complete when that block exits."""
     r, m = a.shape
     n = b.shape[1]
     # measured (profiles/r01i_kernels.log, r01n, gpurun r02c): the MFMA kernels win or tie against the TUNED library
@@ -712,8 +755,15 @@ def gemm_tn(a, b):
         nj = min(nblk, n - j0)
         nbytes = lib.raw("dc_gemm_tn_workspace_bytes")(r, m, nj)
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=a.device)
-        lib.call("dc_gemm_tn", a, a.stride(0), b[:, j0:j0 + nj], b.stride(0), r, m, nj, out[:, j0:j0 + nj], n, 0, ws,
-                 ws.numel() * 4)
+        batch = getattr(_TN, "batch", None)
+        if batch is not None:
+            slabs = ctypes.c_int32(0)
+            lib.call("dc_gemm_tn_slabs", a, a.stride(0), b[:, j0:j0 + nj], b.stride(0), r, m, nj, ws, ws.numel() * 4,
+                     ctypes.byref(slabs))
+            batch.add(ws, slabs.value, m, nj, out[:, j0:j0 + nj], n)
+        else:
+            lib.call("dc_gemm_tn", a, a.stride(0), b[:, j0:j0 + nj], b.stride(0), r, m, nj, out[:, j0:j0 + nj], n, 0, ws,
+                     ws.numel() * 4)
     return out
 
 
@@ -853,8 +903,15 @@ def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_d
         dW = torch.empty(c, k, dtype=torch.float32, device=dev)
         nb2 = lib.raw("dc_gemm_tn_workspace_bytes")(r, c, k)
         ws2 = torch.empty((nb2 + 3) // 4, dtype=torch.float32, device=dev)
-        lib.call("dc_linear_bn_backward_weight", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, dW, k, 0, ws2,
-                 ws2.numel() * 4)
+        batch = getattr(_TN, "batch", None)
+        if batch is not None:
+            slabs = ctypes.c_int32(0)
+            lib.call("dc_linear_bn_backward_weight_slabs", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, ws2,
+                     ws2.numel() * 4, ctypes.byref(slabs))
+            batch.add(ws2, slabs.value, c, k, dW, k)
+        else:
+            lib.call("dc_linear_bn_backward_weight", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, dW, k, 0, ws2,
+                     ws2.numel() * 4)
         dinp = None
         if want_dinp:
             dinp = dinp_out if dinp_out is not None else torch.empty(r, k, dtype=torch.float32, device=dev)

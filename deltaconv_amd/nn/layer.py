@@ -209,10 +209,21 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 saved_m.append((inp, hm, coef_m, use_m))
 
         # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)
+        # (x / v that the previous layer did not already write into this layer's operand buffers -- the first layer -- are
+        #  copied into their left columns: both copies in one launch)
         x_cat = _adopt(x, n, ci, 4 * ci)
+        v_cat = _adopt(v, 2 * n, ci, 2 * ci + co) if cfg.vector else None
+        copies = []
         if x_cat is None:
             x_cat = torch.empty(n, 4 * ci, **f32)
-            x_cat[:, :ci].copy_(x)
+            copies.append((x, x_cat[:, :ci]))
+        if cfg.vector and v_cat is None:
+            # (first layer, ci = 3: two spare columns in front put the `grad @ x'` block on a 16-byte boundary with a
+            #  row stride that is a multiple of 4 floats, so that block runs from the tile plans, forward and transposed)
+            v_cat = _padded(2 * n, 2 * ci + co, 2 * ci, f32)
+            copies.append((v, v_cat[:, :ci]))
+        if copies:
+            _ops.copy_many(copies)
         _ops.fwd_apply("div_curl_norm", cfg.div, v, ci, ldv, x_cat[:, ci:], 4 * ci)
         inp = x_cat
         for (W, gs, bs), bn, slope in zip(ps[:-1], cfg.bns_s[:-1], cfg.slopes_s[:-1]):
@@ -264,12 +275,6 @@ class DeltaConvLayerFn(torch.autograd.Function):
         v_new = None                       # without vector stream the caller passes v through (deltaconv.py:64,70)
         if cfg.vector:
             K = 2 * ci + co
-            v_cat = _adopt(v, 2 * n, ci, K)
-            if v_cat is None:
-                # (first layer, ci = 3: two spare columns in front put the `grad @ x'` block on a 16-byte boundary with a
-                #  row stride that is a multiple of 4 floats, so that block runs from the tile plans, forward and transposed)
-                v_cat = _padded(2 * n, K, 2 * ci, f32)
-                v_cat[:, :ci].copy_(v)
             ldvc = v_cat.stride(0)
             _ops.fwd_apply("hodge", cfg.grad, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], ldvc)
             _ops.fwd_apply("grad", cfg.grad, x_new, co, ldxn, v_cat[:, 2 * ci:], ldvc)
@@ -307,6 +312,12 @@ class DeltaConvLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx_new, dv_new, dx_dup):
+        # the slab sums of the node's three or four weight gradients run as one launch when the block exits (fused.tn_batch)
+        with fused.tn_batch():
+            return DeltaConvLayerFn._backward(ctx, dx_new, dv_new, dx_dup)
+
+    @staticmethod
+    def _backward(ctx, dx_new, dv_new, dx_dup):
         cfg = ctx.cfg
         ci, co, nm, ns, nv, use_m, use_s, use_v, centralized = ctx.meta
         sv = list(ctx.saved_tensors)

@@ -415,6 +415,16 @@ int dc_edge2_backward(const float* dout, int64_t lddo, const float* z, const flo
 size_t dc_gemm_tn_workspace_bytes(int64_t R, int32_t M, int32_t N);
 int dc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N, float* C,
                int64_t ldc, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The same product with the slab reduction deferred: an autograd node that forms several weight gradients (a DeltaConv layer:
+ * v_mlp, s_mlp and max-aggregation Linear of deltaconv/nn/deltaconv.py:35-47) writes the partial tiles [slabs][M][N] of each into
+ * its own workspace (dc_gemm_tn_slabs; *slabs <- their number, a HOST int) and sums them all with ONE dc_gemm_tn_reduce_many at
+ * the end: C_i[rows_i, cols_i] (ldc_i) (+)= ordered sum of the slabs of entry i, i < count (host arrays of device addresses /
+ * sizes) -- the bits dc_gemm_tn writes, in one launch instead of one per weight. */
+int dc_gemm_tn_slabs(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int32_t M, int32_t N,
+                     void* workspace, size_t workspace_bytes, int32_t* slabs, void* stream);
+int dc_gemm_tn_reduce_many(const int64_t* partials, const int64_t* outs, const int64_t* ldc, const int32_t* rows,
+                           const int32_t* cols, const int32_t* slabs, const int32_t* accumulate, int32_t count,
+                           void* stream);
 
 /* ---- split statistics for synchronised BatchNorm (data parallel) ----------------------------------------
  * Same arithmetic as dc_bn_stats / dc_vn_stats / dc_bn_act_backward / dc_vn_backward (nn/nonlin.py:24-35, 63-79),
@@ -529,6 +539,10 @@ int dc_linear_bn_backward_weight(const float* dy, int64_t lddy, const float* h, 
                                  float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K, float* dW,
                                  int64_t lddw, int32_t accumulate, void* workspace, size_t workspace_bytes,
                                  void* stream);
+/* partial tiles [slabs][N][K] only; the ordered sum comes later from dc_gemm_tn_reduce_many (see dc_gemm_tn_slabs) */
+int dc_linear_bn_backward_weight_slabs(const float* dy, int64_t lddy, const float* h, int64_t ldh, const float* coefs,
+                                       float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K,
+                                       void* workspace, size_t workspace_bytes, int32_t* slabs, void* stream);
 
 /* ---- embedding head fused with the per-cloud pooling -------------------------------------------------
  * MLP([sum c, E]) -> global_max_pool | global_mean_pool  (deltaconv/models/deltanet_classification.py:42-49),
@@ -592,6 +606,11 @@ int dc_rowblock_backward_dropout(const float* dY, int64_t lddy, const float* H, 
  * it between replays of a captured step). */
 int dc_sgd_step(const int64_t* params, const int64_t* grads, const int64_t* bufs, const int64_t* numel, int32_t count,
                 const float* lr, float momentum, float weight_decay, void* stream);
+/* Several small (strided) copies in one launch: the batch load into the inputs of a captured step (`data.to(device)`,
+ * experiments/train_modelnet.py:99) and the first layer's operand blocks (the `torch.cat([x, ...])` of deltaconv/nn/deltaconv.py:57,65).
+ * srcs / dsts: HOST arrays of `count` device addresses (4-byte aligned); ld_src / ld_dst / rows / cols in 4-byte words. */
+int dc_copy_many(const int64_t* srcs, const int64_t* dsts, const int64_t* ld_src, const int64_t* ld_dst, const int32_t* rows,
+                 const int32_t* cols, int32_t count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -495,3 +495,82 @@ def test_graph_keeps_the_plane_tables_it_captured_alive():
     assert all(l == l for l in losses), losses                                 # no NaN from recycled memory
     assert losses == ref, (losses, ref)
     assert [t.data_ptr() for t in step._planes_keepalive] == held
+
+
+def test_batched_slab_reductions_write_the_same_bits():
+    """`fused.tn_batch()`: the weight-gradient products of one autograd node run as they come, ALL their ordered slab sums in one
+    launch at the end (dc_gemm_tn_slabs / dc_linear_bn_backward_weight_slabs + dc_gemm_tn_reduce_many) -- the bits of the
+    one-launch-per-weight form, for every reduction shape: <= 16 slabs (streaming form), up to 128 slabs (16 chains), outputs
+    that are no multiple of 4 / unaligned (scalar form), column blocks of a wide output, the BatchNorm-prologue product."""
+    from deltaconv_amd.nn import fused
+    shapes = [(32768, 1024, 448), (32768, 64, 64), (65536, 128, 320), (4096, 64, 3), (3000, 40, 70), (1030, 13, 7),
+              (32768, 128, 128), (777, 50, 128), (16, 8, 8), (20000, 96, 33)]
+    ops = [(_rand(r, m, seed=60 + i), _rand(r, n, seed=80 + i)) for i, (r, m, n) in enumerate(shapes)]
+    R, C, K = 8192, 64, 256
+    x, w = _rand(R, K, seed=40), _rand(C, K, seed=41)
+    h = x @ w.t()
+    gamma, beta = _rand(C, seed=42) + 1.5, _rand(C, seed=43)
+    coef = _bn_reference(h, gamma, beta, 1e-5, 0.1, None, None)
+    dy = _rand(R, C + 8, seed=44)[:, 4:4 + C]
+
+    def run():
+        outs = [fused.gemm_tn(a, b) for a, b in ops]
+        outs.append(fused.bn_block_backward(dy, dy.stride(0), x, h, coef, True, gamma, 0.2, w, True)[0])
+        return outs
+
+    assert fused.USE_TN_BATCH[0]
+    ref = run()                                       # no batch open: every weight reduces at once
+    with fused.tn_batch():
+        got = run()
+        with fused.tn_batch():                        # an inner block joins the outer one
+            got2 = fused.gemm_tn(*ops[1])
+    torch.cuda.synchronize()
+    for (r, m, n), a, b in zip(shapes + [(R, C, K)], ref, got):
+        assert torch.equal(a, b), (r, m, n)
+    assert torch.equal(got2, ref[1])
+    # wide output in column blocks: each block is its own entry of the table
+    old = fused.OWN_TN_MAX_OUTPUTS
+    fused.OWN_TN_MAX_OUTPUTS = 64 * 100
+    try:
+        a, b = ops[0]
+        blocks_ref = fused.gemm_tn(a[:4096, :64], b[:4096])
+        with fused.tn_batch():
+            blocks_got = fused.gemm_tn(a[:4096, :64], b[:4096])
+    finally:
+        fused.OWN_TN_MAX_OUTPUTS = old
+    assert torch.equal(blocks_ref, blocks_got)
+    assert rel_err(blocks_got, a[:4096, :64].double().t() @ b[:4096].double()) < 1e-5
+    # an exception inside the block drops the queue instead of launching on half-built operands
+    with pytest.raises(ZeroDivisionError):
+        with fused.tn_batch():
+            fused.gemm_tn(*ops[1])
+            1 / 0
+    assert getattr(fused._TN, "batch", None) is None
+    # switch off (DC_TN_BATCH=0): the block is a no-op
+    fused.USE_TN_BATCH[0] = False
+    try:
+        with fused.tn_batch():
+            assert getattr(fused._TN, "batch", None) is None
+            assert torch.equal(fused.gemm_tn(*ops[1]), ref[1])
+    finally:
+        fused.USE_TN_BATCH[0] = True
+
+
+def test_layer_gradients_identical_with_and_without_batched_reductions():
+    """A DeltaConv layer step with the slab sums batched per node == the same step with one reduction launch per weight."""
+    import deltaconv_amd as dc
+    from deltaconv_amd.data import synthetic_batch
+    from deltaconv_amd.nn import fused
+    b = synthetic_batch(8, 1024, seed=5).to(DEV)
+    res = []
+    for on in (True, False):
+        torch.manual_seed(0)
+        model = dc.models.DeltaNetClassification(3, 40).to(DEV).train()
+        fused.USE_TN_BATCH[0] = on
+        try:
+            model(b).square().mean().backward()
+        finally:
+            fused.USE_TN_BATCH[0] = True
+        res.append([None if p.grad is None else p.grad.clone() for p in model.parameters()])
+    assert len(res[0]) == len(res[1]) and sum(a is not None for a in res[0]) > 40
+    assert all((a is None and c is None) or torch.equal(a, c) for a, c in zip(*res))

@@ -115,3 +115,41 @@ def test_sgd_learning_rate_moves_between_graph_replays(monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)      # (no real capture: nothing to poison)
     with pytest.raises(RuntimeError, match="before capturing"):
         fresh.step()
+
+
+def test_copy_many_one_launch_for_the_batch_load_and_the_first_layer_blocks():
+    """dc_copy_many (csrc/optim.hip): several small, possibly row-strided copies of 4- / 8-byte elements in one launch == torch's
+    copies; pairs it does not take (1-byte elements, host tensors) fall through to torch, empty ones are skipped."""
+    from deltaconv_amd import _ops
+    g = torch.Generator().manual_seed(0)
+    n = 5000
+    pos, wide = torch.rand(n, 3, generator=g).to(DEV), torch.zeros(n, 12, device=DEV)
+    v, vpad = torch.rand(2 * n, 3, generator=g).to(DEV), torch.zeros(2 * n, 72, device=DEV)[:, 2:]
+    y, ydst = torch.randint(0, 40, (32,), generator=g).to(DEV), torch.zeros(32, dtype=torch.int64, device=DEV)
+    big, bigdst = torch.rand(3000, 130, generator=g).to(DEV)[:, 1:129], torch.zeros(3000, 128, device=DEV)
+    i32, i32dst = torch.randint(0, 9, (777,), generator=g, dtype=torch.int32).to(DEV), torch.zeros(777, dtype=torch.int32, device=DEV)
+    u8, u8dst = torch.randint(0, 255, (100, 7), generator=g, dtype=torch.uint8).to(DEV), torch.zeros(100, 7, dtype=torch.uint8, device=DEV)
+    host, hostdst = torch.rand(10, 3, generator=g), torch.zeros(10, 3, device=DEV)
+    empty, emptydst = torch.zeros(0, 3, device=DEV), torch.zeros(0, 3, device=DEV)
+    pairs = [(pos, wide[:, :3]), (v, vpad[:, :3]), (y, ydst), (big, bigdst), (i32, i32dst), (u8, u8dst), (host, hostdst),
+             (empty, emptydst)]
+    _ops.copy_many(pairs)
+    torch.cuda.synchronize()
+    for src, dst in pairs:
+        assert torch.equal(dst.cpu(), src.cpu())
+    assert float(wide[:, 3:].abs().max()) == 0 and float(vpad[:, 3:].abs().max()) == 0      # nothing beyond the blocks
+    # more pairs than one table holds (16 per launch)
+    many = [(torch.full((50, 5), float(i), device=DEV), torch.zeros(50, 8, device=DEV)[:, :5]) for i in range(40)]
+    _ops.copy_many(many)
+    assert all(torch.equal(d, s) for s, d in many)
+    # capturable: the copies of a captured graph replay with new source contents
+    src, dst = torch.zeros(1000, 3, device=DEV), torch.zeros(1000, 4, device=DEV)
+    _ops.copy_many([(src, dst[:, :3])])
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        _ops.copy_many([(src, dst[:, :3])])
+    src.fill_(3.0)
+    gr.replay()
+    torch.cuda.synchronize()
+    assert float(dst[:, :3].min()) == 3.0 and float(dst[:, 3].max()) == 0.0
