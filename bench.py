@@ -525,7 +525,7 @@ def main(argv=None):
     torch.manual_seed(1)
     model = C.build_model(args.config, k=args.k).to(dev).train()
     ddp = FlatGradDataParallel(model, always_reduce=args.force_dist, sync_bn=args.sync_bn and use_dist)
-    # the configuration's optimizer (train_modelnet.py:67 / train_shapeseg.py:82); fused=True = one multi-tensor kernel
+    # the configuration's optimizer (train_modelnet.py:67 / train_shapeseg.py:82), each with its step in ONE launch (deltaconv_amd/optim.py)
     opt = C.build_optimizer(args.config, model.parameters())
     # Inputs resident in HBM before the timed region; every step consumes a different batch.
     batches = [C.make_batch(args.config, args.batch, 100 + rank + 1000 * i, args.points).to(dev)

@@ -20,7 +20,7 @@ HEADER_PATH = next((h for h in _HEADERS if os.path.exists(h)), _HEADERS[0])
 
 _CTYPES = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t,
-    "float": ctypes.c_float,
+    "float": ctypes.c_float, "double": ctypes.c_double,
 }
 # element type a pointer parameter is declared with -> the torch dtype a tensor bound to it must have
 _PTR_DTYPES = {"float": torch.float32, "double": torch.float64, "int32_t": torch.int32, "int": torch.int32,

@@ -31,11 +31,11 @@ def build_model(name, package=None, k=None):
 
 def build_optimizer(name, params):
     """train_modelnet.py:67 (SGD lr 0.1, momentum 0.9, weight decay 1e-4) / train_shapeseg.py:82 (Adam lr 5e-3)."""
-    import torch
     if CONFIGS[name]["optimizer"] == "sgd":
         from .optim import SGD           # torch.optim.SGD with its step in one launch (csrc/optim.hip)
         return SGD(params, lr=0.1, momentum=0.9, weight_decay=1e-4)
-    return torch.optim.Adam(params, lr=5e-3, fused=True, capturable=True)
+    from .optim import Adam              # torch.optim.Adam with its step in one launch (csrc/optim.hip)
+    return Adam(params, lr=5e-3)
 
 
 def make_batch(name, clouds, seed, points=None):

@@ -6,7 +6,7 @@
 // are never materialised as COO/CSR: G[Nt,k,2] and D[Nt,k,2] share nbr[Nt,k].
 //
 // Three launches over a (blocks, cloud) grid:
-//   1 mls_avgdist  per-cloud mean edge length          (one block per cloud, deterministic tree)
+//   1 mls_avgdist  per-cloud mean edge length          (16 fixed chunks per cloud, combined in order by the consumers)
 //   2 mls_fit      per point: 6x6 weighted normal equations, Cholesky, gradient rows, surface
 //                  coefficients; per-cloud infinity norm by integer atomicMax (order independent)
 //   3 mls_div      per edge: normalise G, contract with the pushed-forward frame map -> D
@@ -17,7 +17,34 @@
 
 namespace {
 
-constexpr int AVG_THREADS = 1024;
+// Per-cloud mean edge length: AVG_CHUNKS fixed partitions per cloud (one workgroup each), combined in chunk order by every
+// consumer -- deterministic, and the partition depends on the cloud's OWN size only (a cloud's operators do not depend on
+// what else is in the batch).  Round 6: was one workgroup of 1024 threads per cloud -- 96 us for one cloud of 4096 points,
+// k = 30 (the per-rank step of 8-GPU strong scaling), 14 us at 32 x 1024.
+constexpr int AVG_THREADS = 256, AVG_CHUNKS = 16;
+__host__ __device__ inline int avg_chunk_points(int n) {            // points per chunk: >= 256, a multiple of 64, <= 16 chunks
+    const int c = ((n + AVG_CHUNKS - 1) / AVG_CHUNKS + 63) / 64 * 64;
+    return c < 256 ? 256 : c;
+}
+__device__ inline double cloud_avg(const double* __restrict__ part, int cloud, int n) {
+    if (n <= 0) return 0.0;
+    const int cp = avg_chunk_points(n), chunks = (n + cp - 1) / cp;
+    double t = 0;
+    for (int c = 0; c < chunks; ++c) t += part[cloud * AVG_CHUNKS + c];
+    return t / n;                                                    // scatter_mean over the cloud (:112)
+}
+// sum of `acc` over the workgroup -> part[cloud][chunk] (wave butterflies, then the waves in order)
+__device__ inline void avg_chunk_store(double acc, double* __restrict__ part, int cloud, int chunk) {
+    __shared__ double wsum[AVG_THREADS / 64];
+    acc = dc_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0;
+        for (int w = 0; w < AVG_THREADS / 64; ++w) t += wsum[w];
+        part[cloud * AVG_CHUNKS + chunk] = t;
+    }
+}
 
 // The first launch of the assembly also does the two pieces of per-cloud / per-point set-up that used to be launches of their
 // own (round 6: -2 launches per step): it clears the cloud's infinity-norm word (mls_fit's atomicMax target) and, when
@@ -29,24 +56,18 @@ __global__ __launch_bounds__(AVG_THREADS) void mls_avgdist_kernel(const float* _
                                                                   double* __restrict__ avg, unsigned* __restrict__ inf_bits,
                                                                   const float* __restrict__ normal, float* __restrict__ xb,
                                                                   float* __restrict__ yb) {
-    __shared__ double part[AVG_THREADS / 64];
-    const int cloud = blockIdx.x;
+    const int cloud = blockIdx.y, chunk = blockIdx.x;
     const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
-    if (threadIdx.x == 0) inf_bits[cloud] = 0u;
+    const int cp = avg_chunk_points(n), q0 = chunk * cp, q1 = min(q0 + cp, n);
+    if (chunk == 0 && threadIdx.x == 0) inf_bits[cloud] = 0u;
+    if (q0 >= n) return;                                             // workgroup-uniform
     double acc = 0;
-    for (int q = threadIdx.x; q < n; q += AVG_THREADS) {
+    for (int q = q0 + threadIdx.x; q < q1; q += AVG_THREADS) {
         const long i = begin + q;
         if (normal) dcmath::tangent_basis_point(normal + 3 * i, xb + 3 * i, yb + 3 * i);
         acc += dcmath::point_dist_sum(pos, nbr + i * k, i, k) / k;  // dist.mean(dim=1) (:112)
     }
-    acc = dc_wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int w = 0; w < AVG_THREADS / 64; ++w) t += part[w];
-        avg[cloud] = (n > 0) ? t / n : 0.0;  // scatter_mean over the cloud (:112)
-    }
+    avg_chunk_store(acc, avg, cloud, chunk);
 }
 
 template <bool SHAPE>
@@ -62,7 +83,7 @@ __global__ __launch_bounds__(128) void mls_fit_kernel(const float* __restrict__ 
     float rownorm = 0.f;
     if (q < n) {
         const long i = begin + q;
-        rownorm = dcmath::mls_fit_point<SHAPE>(pos, normal, xb, yb, nbr + i * k, i, k, avg[cloud], kernel_width, lambda,
+        rownorm = dcmath::mls_fit_point<SHAPE>(pos, normal, xb, yb, nbr + i * k, i, k, cloud_avg(avg, cloud, n), kernel_width, lambda,
                                                G + i * k * 2, coef + i * 6, lambda_shape);
     }
     rownorm = dc_wave_max(rownorm);  // non-negative floats order like their bit patterns
@@ -119,24 +140,18 @@ __global__ __launch_bounds__(256) void mls_coords_kernel(const float* __restrict
 __global__ __launch_bounds__(AVG_THREADS) void mls_avg_of_dist_kernel(const float* __restrict__ dist,
                                                                       const int* __restrict__ cloud_ptr, int k,
                                                                       double* __restrict__ avg) {
-    __shared__ double part[AVG_THREADS / 64];
-    const int cloud = blockIdx.x;
+    const int cloud = blockIdx.y, chunk = blockIdx.x;
     const int begin = cloud_ptr[cloud], n = cloud_ptr[cloud + 1] - begin;
+    const int cp = avg_chunk_points(n), q0 = chunk * cp, q1 = min(q0 + cp, n);
+    if (q0 >= n) return;
     double acc = 0;
-    for (int q = threadIdx.x; q < n; q += AVG_THREADS) {
+    for (int q = q0 + threadIdx.x; q < q1; q += AVG_THREADS) {
         const float* d = dist + (long)(begin + q) * k;
         double s = 0;
         for (int e = 0; e < k; ++e) s += (double)d[e];
         acc += s / k;
     }
-    acc = dc_wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0;
-        for (int w = 0; w < AVG_THREADS / 64; ++w) t += part[w];
-        avg[cloud] = (n > 0) ? t / n : 0.0;
-    }
+    avg_chunk_store(acc, avg, cloud, chunk);
 }
 
 __global__ __launch_bounds__(128) void mls_weights_kernel(const float* __restrict__ dist,
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(128) void mls_weights_kernel(const float* __restric
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n) return;
     const long i = begin + q;
-    dcmath::gaussian_weights_point(dist + i * k, k, avg[cloud], kernel_width, weights + i * k);
+    dcmath::gaussian_weights_point(dist + i * k, k, cloud_avg(avg, cloud, n), kernel_width, weights + i * k);
 }
 
 // weighted_least_squares (:119-144): one point per thread
@@ -190,7 +205,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 DC_EXPORT size_t dc_mls_workspace_bytes(int32_t num_clouds, int32_t num_points) {
-    return align_up((size_t)num_clouds * 8, 256) + align_up((size_t)num_clouds * 4, 256) + (size_t)num_points * 48;
+    return align_up((size_t)num_clouds * AVG_CHUNKS * 8, 256) + align_up((size_t)num_clouds * 4, 256) + (size_t)num_points * 48;
 }
 
 namespace {
@@ -216,10 +231,10 @@ int mls_assemble(const char* name, const float* pos, const float* normal, float*
     hipStream_t s = static_cast<hipStream_t>(stream);
     char* ws = static_cast<char*>(workspace);
     double* avg = reinterpret_cast<double*>(ws);
-    unsigned* inf_bits = reinterpret_cast<unsigned*>(ws + align_up((size_t)num_clouds * 8, 256));
-    double* coef = reinterpret_cast<double*>(ws + align_up((size_t)num_clouds * 8, 256) +
+    unsigned* inf_bits = reinterpret_cast<unsigned*>(ws + align_up((size_t)num_clouds * AVG_CHUNKS * 8, 256));
+    double* coef = reinterpret_cast<double*>(ws + align_up((size_t)num_clouds * AVG_CHUNKS * 8, 256) +
                                              align_up((size_t)num_clouds * 4, 256));
-    hipLaunchKernelGGL(mls_avgdist_kernel, dim3(num_clouds), dim3(AVG_THREADS), 0, s, pos, nbr, cloud_ptr, k, avg, inf_bits,
+    hipLaunchKernelGGL(mls_avgdist_kernel, dim3(AVG_CHUNKS, num_clouds), dim3(AVG_THREADS), 0, s, pos, nbr, cloud_ptr, k, avg, inf_bits,
                        make_basis ? normal : nullptr, x_basis, y_basis);
     const dim3 grid(dc_cdiv(max_cloud_size, 128), num_clouds);
     if (shape)
@@ -315,14 +330,14 @@ DC_EXPORT int dc_mls_gaussian_weights(const float* dist, const int32_t* cloud_pt
         dc_set_error("dc_mls_gaussian_weights: null pointer");
         return DC_ERR_ARG;
     }
-    if (!workspace || workspace_bytes < (size_t)num_clouds * 8) {
+    if (!workspace || workspace_bytes < (size_t)num_clouds * AVG_CHUNKS * 8) {
         dc_set_error("dc_mls_gaussian_weights: workspace too small (%zu < %zu)", workspace_bytes,
-                     (size_t)num_clouds * 8);
+                     (size_t)num_clouds * AVG_CHUNKS * 8);
         return DC_ERR_WORKSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     double* avg = static_cast<double*>(workspace);
-    hipLaunchKernelGGL(mls_avg_of_dist_kernel, dim3(num_clouds), dim3(AVG_THREADS), 0, s, dist, cloud_ptr, k, avg);
+    hipLaunchKernelGGL(mls_avg_of_dist_kernel, dim3(AVG_CHUNKS, num_clouds), dim3(AVG_THREADS), 0, s, dist, cloud_ptr, k, avg);
     hipLaunchKernelGGL(mls_weights_kernel, dim3(dc_cdiv(max_cloud_size, 128), num_clouds), dim3(128), 0, s, dist,
                        cloud_ptr, k, (double)kernel_width, avg, weights);
     return launch_status("dc_mls_gaussian_weights");

@@ -95,6 +95,129 @@ DC_EXPORT int dc_sgd_step(const int64_t* params, const int64_t* grads, const int
     return DC_OK;
 }
 
+// ---- Adam, all parameters in one launch ----------------------------------------------------------------------------------------
+// The optimizer of the reference's shape-segmentation script (/root/reference/experiments/train_shapeseg.py:82: torch.optim.Adam(lr = 5e-3),
+// betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad), in torch's op order (torch/optim/adam.py, single-tensor form):
+//     t = step + 1;  g' = g + wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g' g';
+//     p += -(lr / (1 - b1^t)) * (m / (sqrt(v) / sqrt(1 - b2^t) + eps))
+// ATen's fused form takes three multi_tensor_apply launches of ~43 us for the 8 x 128-channel segmentation net; at one cloud per
+// rank (8-GPU strong scaling) that is 4 % of the step.  `step` is ONE device scalar for all parameters: every workgroup reads it,
+// the LAST workgroup to finish (a ticket counter, reset for the next launch) writes step + 1 -- no second launch, and no workgroup
+// can read the new value.  lr from device memory as in dc_sgd_step.  HBM-bound: 28 bytes per parameter.
+namespace {
+constexpr int ADAM_MAX_TENSORS = 80;      // 80 * (4 * 8 + 4) + scalars < 4 KiB of kernel arguments
+
+struct AdamTable {
+    float* p[ADAM_MAX_TENSORS];
+    const float* g[ADAM_MAX_TENSORS];
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    int first_chunk[ADAM_MAX_TENSORS + 1];
+    int numel[ADAM_MAX_TENSORS];
+    int count;
+};
+
+__global__ __launch_bounds__(SGD_THREADS) void adam_kernel(AdamTable t, const float* __restrict__ lr_dev, float* step_dev,
+                                                           int* ticket, int bump, double beta1d, double beta2d, float eps,
+                                                           float weight_decay) {
+    __shared__ float coef[2];             // step size lr / (1 - b1^t), sqrt(1 - b2^t)
+    if (threadIdx.x == 0) {
+        const double tt = (double)*step_dev + 1.0;
+        coef[0] = (float)((double)*lr_dev / (1.0 - pow(beta1d, tt)));
+        coef[1] = (float)sqrt(1.0 - pow(beta2d, tt));
+    }
+    __syncthreads();
+    // (torch hands `beta2`, `1 - beta1`, `1 - beta2` to its kernels as doubles rounded to fp32: 1.f - (float)beta2 is 1.3e-5 off)
+    const float step_size = coef[0], bc2s = coef[1], beta2 = (float)beta2d, w1 = (float)(1.0 - beta1d), w2 = (float)(1.0 - beta2d);
+    int lo = 0, hi = t.count;
+    const int chunk = blockIdx.x;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (t.first_chunk[mid] <= chunk) lo = mid;
+        else hi = mid;
+    }
+    const int n = t.numel[lo];
+    const long base = (long)(chunk - t.first_chunk[lo]) * SGD_CHUNK;
+    float* __restrict__ p = t.p[lo];
+    const float* __restrict__ g = t.g[lo];
+    float* __restrict__ m = t.m[lo];
+    float* __restrict__ v = t.v[lo];
+    auto one = [&](float& pq, float gq, float& mq, float& vq) {
+        if (weight_decay != 0.f) gq = gq + weight_decay * pq;
+        mq = mq + w1 * (gq - mq);
+        vq = vq * beta2 + w2 * gq * gq;
+        const float denom = sqrtf(vq) / bc2s + eps;
+        pq = pq + (-step_size) * (mq / denom);
+    };
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+#pragma unroll
+    for (int it = 0; it < SGD_CHUNK / (SGD_THREADS * 4); ++it) {
+        const long e = base + ((long)it * SGD_THREADS + threadIdx.x) * 4;
+        if (e >= n) break;
+        if (vec && e + 3 < n) {
+            float4 pv = *reinterpret_cast<const float4*>(p + e), mv = *reinterpret_cast<const float4*>(m + e),
+                   vv = *reinterpret_cast<const float4*>(v + e);
+            const float4 gv = *reinterpret_cast<const float4*>(g + e);
+            one(pv.x, gv.x, mv.x, vv.x); one(pv.y, gv.y, mv.y, vv.y); one(pv.z, gv.z, mv.z, vv.z); one(pv.w, gv.w, mv.w, vv.w);
+            *reinterpret_cast<float4*>(m + e) = mv;
+            *reinterpret_cast<float4*>(v + e) = vv;
+            *reinterpret_cast<float4*>(p + e) = pv;
+        } else {
+            for (long q = e; q < e + 4 && q < n; ++q) one(p[q], g[q], m[q], v[q]);
+        }
+    }
+    if (bump) {
+        // every workgroup read *step_dev above, before it arrives here: the one that takes the last ticket is alone
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(ticket, 1) == (int)gridDim.x - 1) {
+            atomicExch(ticket, 0);
+            *step_dev = *step_dev + 1.f;
+        }
+    }
+}
+}  // namespace
+
+// params / grads / exp_avgs / exp_avg_sqs / numel: HOST arrays of `count` device addresses / element counts (fp32, contiguous);
+// lr: device scalar; step: device scalar (fp32, torch's `state["step"]`), incremented by one; ticket: device int32, zero (left zero).
+DC_EXPORT int dc_adam_step(const int64_t* params, const int64_t* grads, const int64_t* exp_avgs, const int64_t* exp_avg_sqs,
+                           const int64_t* numel, int32_t count, const float* lr, float* step, int32_t* ticket, double beta1,
+                           double beta2, float eps, float weight_decay, void* stream) {
+    DC_REQUIRE(count >= 0 && lr && step && ticket && (count == 0 || (params && grads && exp_avgs && exp_avg_sqs && numel)),
+               "dc_adam_step: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int live = 0;
+    for (int i = 0; i < count; ++i) live += numel[i] > 0;
+    if (!live) return DC_OK;
+    int seen = 0;
+    for (int t0 = 0; t0 < count;) {
+        AdamTable t;
+        t.count = 0;
+        int chunks = 0, i = t0;
+        for (; i < count && t.count < ADAM_MAX_TENSORS; ++i) {
+            DC_REQUIRE(numel[i] >= 0 && numel[i] < 2147483647L, "dc_adam_step: tensor too large");
+            if (numel[i] == 0) continue;
+            DC_REQUIRE(params[i] && grads[i] && exp_avgs[i] && exp_avg_sqs[i], "dc_adam_step: null tensor");
+            const int c = t.count++;
+            t.p[c] = reinterpret_cast<float*>(params[i]);
+            t.g[c] = reinterpret_cast<const float*>(grads[i]);
+            t.m[c] = reinterpret_cast<float*>(exp_avgs[i]);
+            t.v[c] = reinterpret_cast<float*>(exp_avg_sqs[i]);
+            t.numel[c] = (int)numel[i];
+            t.first_chunk[c] = chunks;
+            chunks += dc_cdiv(numel[i], SGD_CHUNK);
+        }
+        t0 = i;
+        t.first_chunk[t.count] = chunks;
+        seen += t.count;
+        if (chunks)          // the launch that holds the last live tensor advances `step`
+            hipLaunchKernelGGL(adam_kernel, dim3(chunks), dim3(SGD_THREADS), 0, s, t, lr, step, ticket, (int)(seen == live), beta1,
+                               beta2, eps, weight_decay);
+    }
+    DC_CHECK_LAUNCH("dc_adam_step");
+    return DC_OK;
+}
+
 // ---- several small (strided) copies in one launch ---------------------------------------------------------------------------
 // Step glue around a replayed step: the batch load (`data.to(device)` of the reference's loops, experiments/train_modelnet.py:99 --
 // here device-to-device into the captured inputs: pos, normals, labels) and the first layer's operand blocks (`torch.cat([x, ...])`

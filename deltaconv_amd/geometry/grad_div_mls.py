@@ -159,7 +159,7 @@ def gaussian_weights(dist, k, batch=None, kernel_width=1):
             raise ValueError("gaussian_weights: batch must be sorted (clouds contiguous)")
         info = _ptr_from_batch(batch.to(dist.device), n, dist.device)
         ptr, num_clouds, max_cloud = info[0], info[1], info[2]
-    ws = torch.empty(num_clouds, dtype=torch.float64, device=dist.device)
+    ws = torch.empty(16 * num_clouds, dtype=torch.float64, device=dist.device)   # 16 ordered partial sums per cloud
     lib.call("dc_mls_gaussian_weights", dist, ptr, num_clouds, max_cloud, k, float(kernel_width), weights, ws,
              ws.numel() * 8)
     return weights

@@ -123,7 +123,8 @@ int dc_mls_assemble_shape(const float* pos, const float* normal, const float* x_
 int dc_mls_coords(const float* pos, const float* normal, const float* x_basis, const float* y_basis,
                   const int32_t* row, const int32_t* col, int64_t num_edges, int32_t k, float* coords, void* stream);
 /* gaussian_weights -- grad_div_mls.py:100-116: dist[Nt*k] -> weights[Nt*k]; cloud_ptr[num_clouds+1] delimits the
- * clouds whose mean edge length scales the kernel (batch=None: one cloud); workspace >= 8 * num_clouds bytes */
+ * clouds whose mean edge length scales the kernel (batch=None: one cloud); workspace >= 128 * num_clouds bytes
+ * (16 ordered fp64 partial sums per cloud) */
 int dc_mls_gaussian_weights(const float* dist, const int32_t* cloud_ptr, int32_t num_clouds, int32_t max_cloud_size,
                             int32_t k, float kernel_width, float* weights, void* workspace, size_t workspace_bytes,
                             void* stream);
@@ -606,6 +607,14 @@ int dc_rowblock_backward_dropout(const float* dY, int64_t lddy, const float* H, 
  * it between replays of a captured step). */
 int dc_sgd_step(const int64_t* params, const int64_t* grads, const int64_t* bufs, const int64_t* numel, int32_t count,
                 const float* lr, float momentum, float weight_decay, void* stream);
+/* torch.optim.Adam(lr, betas, eps, weight_decay) (no amsgrad; experiments/train_shapeseg.py:82) over ALL parameters in one
+ * launch (80 tensors per launch), torch's single-tensor op order:  t = step + 1;  g' = g + weight_decay p;
+ * m += (1 - beta1)(g' - m);  v = beta2 v + (1 - beta2) g'^2;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps).
+ * Host arrays as in dc_sgd_step; lr: DEVICE scalar; step: DEVICE fp32 scalar shared by all parameters, incremented by one (by
+ * the last workgroup to finish); ticket: DEVICE int32 holding zero (left zero). */
+int dc_adam_step(const int64_t* params, const int64_t* grads, const int64_t* exp_avgs, const int64_t* exp_avg_sqs,
+                 const int64_t* numel, int32_t count, const float* lr, float* step, int32_t* ticket, double beta1, double beta2,
+                 float eps, float weight_decay, void* stream);
 /* Several small (strided) copies in one launch: the batch load into the inputs of a captured step (`data.to(device)`,
  * experiments/train_modelnet.py:99) and the first layer's operand blocks (the `torch.cat([x, ...])` of deltaconv/nn/deltaconv.py:57,65).
  * srcs / dsts: HOST arrays of `count` device addresses (4-byte aligned); ld_src / ld_dst / rows / cols in 4-byte words. */

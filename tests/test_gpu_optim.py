@@ -153,3 +153,104 @@ def test_copy_many_one_launch_for_the_batch_load_and_the_first_layer_blocks():
     gr.replay()
     torch.cuda.synchronize()
     assert float(dst[:, :3].min()) == 3.0 and float(dst[:, 3].max()) == 0.0
+
+
+# ---- Adam (experiments/train_shapeseg.py:82) -----------------------------------------------------------------------------------
+def _adam_pair(shapes, seed=0, **kw):
+    import deltaconv_amd as dc
+    g = torch.Generator().manual_seed(seed)
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    pa = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    pb = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    return pa, pb, dc.optim.Adam(pa, **kw), torch.optim.Adam(pb, foreach=False, **kw), g      # torch's single-tensor form
+
+
+def _grads(pa, pb, g, scale=1.0):
+    for a, b in zip(pa, pb):
+        gr = (torch.randn(*a.shape, generator=g) * scale).to(DEV)
+        a.grad, b.grad = gr.clone(), gr.clone()
+
+
+@pytest.mark.parametrize("kw", [dict(lr=5e-3), dict(lr=1e-3, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2)])
+def test_adam_matches_torch_over_steps(kw):
+    """dc_adam_step vs torch.optim.Adam (the reference's default, single-tensor form) over 8 steps with a StepLR schedule
+    (train_shapeseg.py:83).  Tolerance: 2e-6 of the parameter scale per step for the parameters, 1e-6 for the moments."""
+    pa, pb, oa, ob, g = _adam_pair(SHAPES, **kw)
+    sa, sb = torch.optim.lr_scheduler.StepLR(oa, 3, gamma=0.1), torch.optim.lr_scheduler.StepLR(ob, 3, gamma=0.1)
+    for step in range(8):
+        _grads(pa, pb, g, scale=10.0 ** (step % 3 - 1))
+        oa.step(); ob.step()
+        sa.step(); sb.step()
+        for a, b in zip(pa, pb):
+            assert rel_err(a, b) < 2e-6 * (step + 1), (step, tuple(a.shape))
+    for a, b in zip(pa, pb):
+        assert rel_err(oa.state[a]["exp_avg"], ob.state[b]["exp_avg"]) < 1e-6
+        assert rel_err(oa.state[a]["exp_avg_sq"], ob.state[b]["exp_avg_sq"]) < 1e-6
+        assert float(oa.state[a]["step"]) == 8.0 == float(ob.state[b]["step"])
+    assert len({id(oa.state[a]["step"]) for a in pa}) == 1                   # ONE device counter for the group
+
+
+def test_adam_many_tensors_missing_grads_state_dict_and_fallback():
+    """> 80 tensors (two launches, the step counter moves once), unaligned views (scalar path), parameters without a gradient;
+    state_dict round trip with torch.optim.Adam in both directions (the loaded per-parameter counters are re-shared); an
+    amsgrad group runs torch's own step."""
+    import copy
+    import deltaconv_amd as dc
+    g = torch.Generator().manual_seed(1)
+    base_a = torch.randn(170 * 37 + 3, generator=g).to(DEV)
+    base_b = base_a.clone()
+    pa = [torch.nn.Parameter(base_a[1 + i * 37:1 + i * 37 + 35]) for i in range(170)]
+    pb = [torch.nn.Parameter(base_b[1 + i * 37:1 + i * 37 + 35]) for i in range(170)]
+    oa, ob = dc.optim.Adam(pa, lr=5e-3), torch.optim.Adam(pb, lr=5e-3, foreach=False)
+    skip = lambda i: i % 7 == 3
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if skip(i):
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(35, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step()
+    assert rel_err(base_a, base_b) < 5e-6
+    assert torch.equal(base_a[:1], base_b[:1]) and torch.equal(base_a[-2:], base_b[-2:])
+    assert float(oa.state[pa[0]]["step"]) == 3.0
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))       # ours -> torch
+    oa.load_state_dict(copy.deepcopy(ob.state_dict()))       # torch -> ours: every parameter comes back with its own counter
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        if not skip(i):
+            gr = torch.randn(35, generator=g).to(DEV)
+            a.grad, b.grad = gr.clone(), gr.clone()
+    oa.step(); ob.step()
+    assert rel_err(base_a, base_b) < 5e-6
+    assert float(oa.state[pa[0]]["step"]) == 4.0 and len({id(oa.state[a]["step"]) for i, a in enumerate(pa) if not skip(i)}) == 1
+    qa, qb = torch.nn.Parameter(torch.ones(5, device=DEV)), torch.nn.Parameter(torch.ones(5, device=DEV))
+    na, nb = dc.optim.Adam([qa], lr=0.1, amsgrad=True), torch.optim.Adam([qb], lr=0.1, amsgrad=True)
+    qa.grad, qb.grad = torch.full((5,), 2.0, device=DEV), torch.full((5,), 2.0, device=DEV)
+    na.step(); nb.step()
+    assert rel_err(qa, qb) < 1e-6
+
+
+def test_adam_in_a_captured_step():
+    """Replays of a captured step advance the shared device counter (bias corrections move) and read the learning rate from
+    its device scalar; the first step must be eager."""
+    import deltaconv_amd as dc
+    pa, pb, oa, ob, g = _adam_pair([(1000,), (64, 33)], lr=5e-3)
+    _grads(pa, pb, g)
+    oa.step(); ob.step()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        oa.step()
+    ob.step()                                               # (the capture itself runs nothing)
+    for rep in range(3):
+        if rep == 2:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 1e-3
+            oa.sync_lr()
+        gr.replay()
+        if rep:
+            ob.step()
+        torch.cuda.synchronize()
+    # both sides: one eager step, then three more with the same gradients, the last one at the lower learning rate
+    assert float(oa.state[pa[0]]["step"]) == 4.0 and float(ob.state[pb[0]]["step"]) == 4.0
+    for a, b in zip(pa, pb):
+        assert rel_err(a, b) < 1e-5
