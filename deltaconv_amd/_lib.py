@@ -72,6 +72,11 @@ class _Lib:
             # (option 3 of dc_set_option; A/B runs and bitwise comparisons against an fmaf chain)
             if os.environ.get("DC_GEMM_EXACT", "0") not in ("", "0"):
                 cdll.dc_set_option(3, 1)
+            # DC_OPTIONS="key=value,...": any experiment switch of dc_set_option at load (same-box A/B runs of bench.py)
+            for item in filter(None, os.environ.get("DC_OPTIONS", "").split(",")):
+                key, value = item.split("=")
+                if cdll.dc_set_option(int(key), int(value)) != 0:
+                    raise RuntimeError(f"DC_OPTIONS: dc_set_option({key}, {value}) refused")
         return self._cdll
 
     def last_error(self):

@@ -43,7 +43,7 @@ bool dc_take_lds_failure();
     } while (0)
 
 // Runtime experiment switches (dc_set_option): index -> value.
-enum { DC_OPT_XCD_REMAP = 0, DC_OPT_GATHER_BATCH = 1, DC_OPT_TN_LDS = 2 /* 2: weight-gradient GEMM through the direct-load kernel of round 1 (lab) */, DC_OPT_GEMM_EXACT = 3 /* 1: dense products through the exact fp32 MFMA chain instead of the bf16 split products */, DC_OPT_GEMM_STAGGER = 4 /* first-round phase shift of every second 128 x 128 workgroup of a CU, percent of a K loop */, DC_OPT_TN_TILE = 5 /* lab: 1..4 forces the weight-gradient tile */, DC_OPT_TN_SLABS = 6 /* lab: forces the slab count */, DC_OPT_TILE_UPW = 7, DC_OPT_CSC_ONE_WG = 8 /* 1: CSC count / scan / fill by one workgroup per cloud (round 3) instead of eight column ranges */, DC_OPT_NO_PLANES = 9 /* 1: ignore pre-split weight planes (every product splits its B operand in the K loop: round 3) */, DC_OPT_CE_TWO_LAUNCH = 10 /* 1: cross-entropy of <= 64 rows through the two-launch form (A/B, bit-identity test) */, DC_OPT_COUNT = 12 };
+enum { DC_OPT_XCD_REMAP = 0, DC_OPT_GATHER_BATCH = 1, DC_OPT_TN_LDS = 2 /* 2: weight-gradient GEMM through the direct-load kernel of round 1 (lab) */, DC_OPT_GEMM_EXACT = 3 /* 1: dense products through the exact fp32 MFMA chain instead of the bf16 split products */, DC_OPT_GEMM_STAGGER = 4 /* first-round phase shift of every second 128 x 128 workgroup of a CU, percent of a K loop */, DC_OPT_TN_TILE = 5 /* lab: 1..4 forces the weight-gradient tile */, DC_OPT_TN_SLABS = 6 /* lab: forces the slab count */, DC_OPT_TILE_UPW = 7, DC_OPT_CSC_ONE_WG = 8 /* 1: CSC count / scan / fill by one workgroup per cloud (round 3) instead of eight column ranges */, DC_OPT_NO_PLANES = 9 /* 1: ignore pre-split weight planes (every product splits its B operand in the K loop: round 3) */, DC_OPT_CE_TWO_LAUNCH = 10 /* 1: cross-entropy of <= 64 rows through the two-launch form (A/B, bit-identity test) */, DC_OPT_WIDE_TILES = 11 /* 1: dense products on few rows keep 128-column tiles (A/B of the round-6 rule: 64-column tiles while a launch has fewer than 256 workgroups) */, DC_OPT_COUNT = 12 };
 int dc_option(int key);
 
 static inline int dc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

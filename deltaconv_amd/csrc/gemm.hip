@@ -886,10 +886,13 @@ Tile pick_tile(long M, int N, int K, int tile) {
     // divides the problem runs the unguarded fast path (e.g. N = 192: 3 x 64 instead of 2 x 128 with guards)
     int bn = N > 64 ? 128 : 64;
     if (N % 128 != 0 && N % 64 == 0) bn = 64;
-    const long tn = (N + bn - 1) / bn;
+    long tn = (N + bn - 1) / bn;
     // row tile: enough workgroups for 256 CUs x 2; 64-row tiles for short problems
     int bm = ((M + 127) / 128) * tn >= 384 ? 128 : 64;
     if (M % bm != 0 && M % 64 == 0) bm = 64;
+    // few rows (the per-rank steps of 8-GPU strong scaling: 4096 points): 64 x 128 tiles leave 64 workgroups for 256 CUs at
+    // N = 128 -- 64-column tiles while the launch has fewer than one workgroup per CU (round 6, profiles/r06_labs.txt item 9)
+    if (bm == 64 && bn == 128 && N % 64 == 0 && ((M + 63) / 64) * tn < 256 && dc_option(DC_OPT_WIDE_TILES) == 0) bn = 64;
     return {bm, bn};
 }
 

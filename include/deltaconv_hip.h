@@ -43,7 +43,8 @@ const char* dc_last_error(void);
  * 7: units (tile x 64-channel slab) per workgroup of the persistent two-piece tiled applies (0 = launcher's choice);
  * 8: value 1 = CSC count / scan / fill by one workgroup per cloud (round 3) instead of eight column ranges per cloud;
  * 9: value 1 = ignore pre-split weight planes (every product splits its weight operand in the K loop, as in round 3);
- * 10: value 1 = cross-entropy of <= 64 rows through the two-launch form (same bits as the one-launch form). */
+ * 10: value 1 = cross-entropy of <= 64 rows through the two-launch form (same bits as the one-launch form);
+ * 11: value 1 = dense products with fewer than 256 workgroups keep 128-column tiles (round-6 rule off). */
 int dc_set_option(int32_t key, int32_t value);
 
 /* Measurement aid (bench.py `roofline.frac`): device-clock stamps of the tiled two-piece forward applies and the tiled transposed applies.  After
