@@ -358,6 +358,72 @@ struct PoolBwdBody {
     }
 };
 
+// y[i] = h[i] + g[cloud of i]: the per-cloud half of the segmentation head's first Linear, computed on B rows, joins the per-point
+// half (models/deltanet_segmentation.py; reference: x_max[batch] concatenated in front of the features, deltanet_segmentation.py:59-64)
+template <int V>
+struct CloudBiasBody {
+    const float *h, *g; float* y; long ldh, ldg, ldy, mx;
+    __device__ void init(int) {}
+    __device__ void row(long r, int c0) {
+        const FV<V> x = ldv<V>(h + r * ldh + c0), b = ldv<V>(g + (r / mx) * ldg + c0);
+        FV<V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o.v[j] = x.v[j] + b.v[j];
+        stv<V>(y + r * ldy + c0, o);
+    }
+};
+
+// Its backward: per-cloud column sums of d h (the gradient of `x_max[batch]`: index_select backward = index_add over the cloud's
+// points).  Ordered two-stage reduction like colreduce.h: fp64 partial per (cloud, row chunk, column), then one wave per
+// (cloud, column) over the chunks -- bit-reproducible.  grid = (chunks, column tiles, clouds).
+template <int V>
+__global__ __launch_bounds__(TPB) void cloud_colsum_kernel(const float* __restrict__ x, long ldx, long mx, int C, int chunks,
+                                                           int rpc, double* __restrict__ partial) {
+    __shared__ double sm[RT][CT * V];
+    const int cgl = threadIdx.x % CT, rl = threadIdx.x / CT;
+    const int c0 = (blockIdx.y * CT + cgl) * V;
+    const long cloud = blockIdx.z;
+    const long r0 = cloud * mx + (long)blockIdx.x * rpc, r1 = min(r0 + rpc, (cloud + 1) * mx);
+    double acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.0;
+    if (c0 < C) {
+#pragma unroll 2
+        for (long r = r0 + rl; r < r1; r += RT) {
+            const FV<V> v = ldv<V>(x + r * ldx + c0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += (double)v.v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) sm[rl][cgl * V + j] = acc[j];
+    __syncthreads();
+    for (int cl = threadIdx.x; cl < CT * V; cl += TPB) {
+        const int col = blockIdx.y * CT * V + cl;
+        if (col < C) {
+            double t = 0;
+#pragma unroll
+            for (int rr = 0; rr < RT; ++rr) t += sm[rr][cl];
+            partial[(cloud * C + col) * chunks + blockIdx.x] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(64) void cloud_colsum_final_kernel(const double* __restrict__ partial, int chunks, int C,
+                                                                float* __restrict__ out, long ldo) {
+    const int col = blockIdx.x;
+    const long cloud = blockIdx.y;
+    const double* p = partial + (cloud * C + col) * chunks;
+    double t = 0;
+    for (int ch = threadIdx.x; ch < chunks; ch += 64) t += p[ch];
+    t = dc_wave_sum(t);
+    if (threadIdx.x == 0) out[cloud * ldo + col] = (float)t;
+}
+inline int cloud_colsum_chunks(long num_clouds, long mx, int C) {       // ~768 workgroups, >= RT rows each
+    const long coltiles = dc_cdiv(C, CT * 4);
+    const long want = std::max<long>(1, 768 / std::max<long>(1, num_clouds * coltiles));
+    return (int)std::max<long>(1, std::min<long>(want, dc_cdiv(mx, RT)));
+}
+
 template <int V, class BODY>
 void run_tile(BODY body, long R, int C, hipStream_t s) {
     const long coltiles = dc_cdiv(C, CT * V);
@@ -443,6 +509,51 @@ DC_EXPORT int dc_bn_act2(const float* h, int64_t R, int32_t C, int64_t ldh, cons
                          float slope, const float* residual, int64_t ldr, float* y, int64_t ldy, float* y2,
                          int64_t ldy2, void* stream) {
     return bn_act_impl(h, R, C, ldh, scale, shift, slope, residual, ldr, y, ldy, y2, ldy2, stream);
+}
+
+// y[n, C] (ldy) = h[n, C] (ldh) + g[i / mx, C] (ldg): equal-size clouds of mx points, y may be h.
+DC_EXPORT int dc_cloud_bias_add(const float* h, int64_t ldh, const float* g, int64_t ldg, int64_t n, int32_t C, int64_t mx,
+                                float* y, int64_t ldy, void* stream) {
+    DC_REQUIRE(h && g && y, "dc_cloud_bias_add: null pointer");
+    DC_REQUIRE(n >= 0 && C >= 1 && mx >= 1 && ldh >= C && ldg >= C && ldy >= C, "dc_cloud_bias_add: bad size");
+    if (n == 0) return DC_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool v4 = C % 4 == 0 && ldh % 4 == 0 && ldg % 4 == 0 && ldy % 4 == 0 && al16(h) && al16(g) && al16(y);
+    if (v4) run_tile<4>(CloudBiasBody<4>{h, g, y, (long)ldh, (long)ldg, (long)ldy, (long)mx}, n, C, s);
+    else run_tile<1>(CloudBiasBody<1>{h, g, y, (long)ldh, (long)ldg, (long)ldy, (long)mx}, n, C, s);
+    DC_CHECK_LAUNCH("dc_cloud_bias_add");
+    return DC_OK;
+}
+
+DC_EXPORT size_t dc_cloud_colsum_workspace_bytes(int32_t num_clouds, int64_t mx, int32_t C) {
+    return (size_t)std::max(num_clouds, 0) * (size_t)std::max(C, 0) * cloud_colsum_chunks(num_clouds, mx, C) * sizeof(double);
+}
+
+// out[num_clouds, C] (ldo) = column sums of x[num_clouds * mx, C] (ldx) over each cloud's mx rows.
+DC_EXPORT int dc_cloud_colsum(const float* x, int64_t ldx, int32_t num_clouds, int64_t mx, int32_t C, float* out, int64_t ldo,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    DC_REQUIRE(x && out, "dc_cloud_colsum: null pointer");
+    DC_REQUIRE(num_clouds >= 0 && mx >= 1 && C >= 1 && ldx >= C && ldo >= C, "dc_cloud_colsum: bad size");
+    if (num_clouds == 0) return DC_OK;
+    if (!workspace || workspace_bytes < dc_cloud_colsum_workspace_bytes(num_clouds, mx, C)) {
+        dc_set_error("dc_cloud_colsum: workspace too small");
+        return DC_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int chunks = cloud_colsum_chunks(num_clouds, mx, C);
+    const int rpc = (int)(dc_cdiv(dc_cdiv(mx, chunks), RT) * RT);
+    const int used = dc_cdiv(mx, rpc);                                    // <= chunks
+    double* partial = static_cast<double*>(workspace);
+    const bool v4 = C % 4 == 0 && ldx % 4 == 0 && al16(x);
+    if (v4)
+        hipLaunchKernelGGL(cloud_colsum_kernel<4>, dim3(used, dc_cdiv(C, CT * 4), num_clouds), dim3(TPB), 0, s, x, (long)ldx,
+                           (long)mx, C, used, rpc, partial);
+    else
+        hipLaunchKernelGGL(cloud_colsum_kernel<1>, dim3(used, dc_cdiv(C, CT), num_clouds), dim3(TPB), 0, s, x, (long)ldx, (long)mx,
+                           C, used, rpc, partial);
+    hipLaunchKernelGGL(cloud_colsum_final_kernel, dim3(C, num_clouds), dim3(64), 0, s, partial, used, C, out, (long)ldo);
+    DC_CHECK_LAUNCH("dc_cloud_colsum");
+    return DC_OK;
 }
 
 // Backward of y = leaky(scale*h + shift): dh (through the batch statistics when training != 0),

@@ -46,9 +46,10 @@ class DeltaNetSegmentation(torch.nn.Module):
             # Linear([x_max[batch] | conv]) = Linear_a(x_max)[batch] + Linear_b(conv): the per-cloud half of the
             # first head GEMM runs on B rows instead of Nt and the [Nt, E+S] concatenation is never built
             # (deltanet_segmentation.py:66-68; same sum, different association of the fp32 additions).
-            w, p = blk[0].weight, pooled.shape[1]
-            h = fused.linear(conv_cat, w[:, p:]).view(nc, mx, -1)
-            h = (h + fused.linear(pooled, w[:, :p]).unsqueeze(1)).view(n, -1)
+            # (round 6: the weight halves through fused.split_cols -- one copy launch in backward instead of autograd's fill /
+            #  copy / add per slice -- and the join through fused.cloud_bias: in place, backward = own per-cloud column sums)
+            wa, wb = fused.split_cols(blk[0].weight, pooled.shape[1])
+            h = fused.cloud_bias(fused.linear(conv_cat, wb), fused.linear(pooled, wa), mx)
             y = fused.bn_act(h, blk[1].bn, fused.slope_of(blk[2]))
             return run_head(list(self.segmentation_head)[1:], y)
         x_max = broadcast_to_points(pooled, batch, info, n)

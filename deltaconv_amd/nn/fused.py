@@ -1144,6 +1144,75 @@ def linear(x, w, b=None):
     return _Linear.apply(x, w, b)
 
 
+class _CloudBias(torch.autograd.Function):
+    """h[i] += g[cloud of i] in place (h: a fresh product nobody else reads; equal-size clouds of mx points): the per-cloud half of
+    the segmentation head's first Linear joins the per-point half (csrc/nn.hip: dc_cloud_bias_add).  Backward: d h is the
+    incoming gradient itself, d g its per-cloud column sums (dc_cloud_colsum: the index_add of `x_max[batch]`,
+    deltaconv/models/deltanet_segmentation.py:59) -- an ordered fp64 two-stage reduction instead of ATen's `sum(1)`
+    (29 us whatever the batch, profiles/r06_c4_per_rank_step_timeline.txt)."""
+
+    @staticmethod
+    def forward(ctx, h, g, mx):
+        n, c = h.shape
+        lib.call("dc_cloud_bias_add", h, h.stride(0), g, g.stride(0), n, c, mx, h, h.stride(0))
+        ctx.mark_dirty(h)
+        ctx.cfg = (g.shape[0], mx)
+        return h
+
+    @staticmethod
+    def backward(ctx, dy):
+        nc, mx = ctx.cfg
+        dg = None
+        if ctx.needs_input_grad[1]:
+            d = _rowmajor(dy)
+            c = d.shape[1]
+            dg = torch.empty(nc, c, dtype=torch.float32, device=d.device)
+            nb = lib.raw("dc_cloud_colsum_workspace_bytes")(nc, mx, c)
+            ws = torch.empty((nb + 7) // 8, dtype=torch.float64, device=d.device)
+            lib.call("dc_cloud_colsum", d, d.stride(0), nc, mx, c, dg, c, ws, ws.numel() * 8)
+        return dy, dg, None
+
+
+def cloud_bias(h, g, mx):
+    """h [B * mx, C] (a fresh fp32 product, overwritten) + g [B, C] broadcast over each cloud's mx rows."""
+    _require_fp32_gpu("cloud_bias", h, g)
+    if h.shape[0] != g.shape[0] * mx or h.shape[1] != g.shape[1] or h.stride(1) != 1:
+        raise ValueError(f"cloud_bias: h {tuple(h.shape)} against g {tuple(g.shape)} x {mx} rows")
+    return _CloudBias.apply(h, _c(g), int(mx))
+
+
+class _SplitCols(torch.autograd.Function):
+    """(w[:, :p], w[:, p:]) as views; backward writes both gradients into ONE fresh [rows, cols] tensor with one copy launch
+    (autograd's own slicing pays a fill and a copy per block and an add of the two full-size results: five launches)."""
+
+    @staticmethod
+    def forward(ctx, w, p):
+        ctx.cfg = (tuple(w.shape), p)
+        return w[:, :p], w[:, p:]
+
+    @staticmethod
+    def backward(ctx, da, db):
+        (r, c), p = ctx.cfg
+        src = da if da is not None else db
+        if src is None:
+            return None, None
+        dw = torch.empty(r, c, dtype=src.dtype, device=src.device)
+        pairs = []
+        for d, blk in ((da, dw[:, :p]), (db, dw[:, p:])):
+            if d is None:
+                blk.zero_()
+            else:
+                pairs.append((d if d.stride(-1) == 1 else d.contiguous(), blk))
+        from .. import _ops
+        _ops.copy_many(pairs)
+        return dw, None
+
+
+def split_cols(w, p):
+    """-> (w[:, :p], w[:, p:]) with a one-launch backward."""
+    return _SplitCols.apply(w, int(p))
+
+
 class _LinearBNAct(torch.autograd.Function):
     """One MLP block of nn/mlp.py:7-11 as a single node: y = leaky(batch_norm(x W^T)) (+ residual).  The batch
     statistics come out of the GEMM epilogue (no pass over the Linear output), the backward is

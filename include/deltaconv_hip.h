@@ -546,6 +546,18 @@ int dc_linear_bn_backward_weight_slabs(const float* dy, int64_t lddy, const floa
                                        float slope, const float* X, int64_t ldx, int64_t R, int32_t N, int32_t K,
                                        void* workspace, size_t workspace_bytes, int32_t* slabs, void* stream);
 
+/* ---- per-cloud term of the segmentation head's first Linear ----------------------------------------------------------------
+ * deltaconv/models/deltanet_segmentation.py:59-66: x_max[batch] (+ the category vector) is concatenated in front of the point
+ * features and fed to Linear(E + S, 256).  Here Linear([x_max[batch] | conv]) = Linear_a(x_max)[batch] + Linear_b(conv): the
+ * per-cloud half runs on B rows; dc_cloud_bias_add joins it to the per-point half (y[i] = h[i] + g[i / mx], equal-size clouds of
+ * mx points, y may be h), dc_cloud_colsum is its backward (out[b] = sum of the rows of cloud b: the index_add of `[batch]`),
+ * an ordered two-stage fp64 reduction (bit-reproducible).  Workspace: dc_cloud_colsum_workspace_bytes. */
+int dc_cloud_bias_add(const float* h, int64_t ldh, const float* g, int64_t ldg, int64_t n, int32_t C, int64_t mx, float* y,
+                      int64_t ldy, void* stream);
+size_t dc_cloud_colsum_workspace_bytes(int32_t num_clouds, int64_t mx, int32_t C);
+int dc_cloud_colsum(const float* x, int64_t ldx, int32_t num_clouds, int64_t mx, int32_t C, float* out, int64_t ldo,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- embedding head fused with the per-cloud pooling -------------------------------------------------
  * MLP([sum c, E]) -> global_max_pool | global_mean_pool  (deltaconv/models/deltanet_classification.py:42-49),
  * -> global_max_pool (deltanet_segmentation.py:58-61).  h = Linear output [B*N, C] (equal-size clouds);

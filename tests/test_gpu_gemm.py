@@ -23,6 +23,18 @@ def _tol(k):
     return 2e-6 * math.sqrt(k) + 1e-6
 
 
+@pytest.fixture
+def wide_tiles():
+    """Round 6: products with fewer than 256 workgroups run on 64-column tiles (in-loop: the exact chain).  Tests of the
+    128-column split path on such shapes switch the rule off (dc_set_option 11)."""
+    opt = lib.raw("dc_set_option")
+    opt(11, 1)
+    try:
+        yield
+    finally:
+        opt(11, 0)
+
+
 SHAPES = [  # M, N, K
     (32768, 64, 64), (32768, 64, 256), (32768, 128, 256), (32768, 256, 512), (8192, 1024, 512),
     (65536, 128, 192), (65536, 256, 256),
@@ -191,7 +203,7 @@ def test_bn_block_backward_fused_matches_unfused(R, C, K, training, accumulate):
 
 @pytest.mark.parametrize("M,N,K", [(32768, 1024, 448), (16384, 256, 512), (8192, 128, 128), (4096, 256, 64)])
 @pytest.mark.parametrize("binades", [0.0, 3.0])
-def test_split_products_no_worse_than_exact_chain(M, N, K, binades):
+def test_split_products_no_worse_than_exact_chain(M, N, K, binades, wide_tiles):
     """The default dense products (three bf16 planes per fp32 operand, six partial products on the bf16 matrix pipe, fp32
     accumulation) against the exact fp32 MFMA chain (option 3 = 1) and an fp64 product, for the three products of a Linear
     layer (forward, input gradient, weight gradient): the split error is no larger than 1.5 x the chain's + 1e-7, on
@@ -288,7 +300,7 @@ def test_split_products_extreme_scales(log2_scale):
         assert e_split < 2.0 ** -15
 
 
-def test_split_products_nonfinite_operands():
+def test_split_products_nonfinite_operands(wide_tiles):
     """inf / values beyond the bfloat16 range in an operand: the documented behaviour.  The row that
     holds the value comes back non-finite (NaN from inf - inf in the residual planes, where the exact chain returns +-inf);
     every other row is bit-identical to the product without it -- nothing leaks across rows."""
@@ -323,7 +335,7 @@ def test_split_products_nonfinite_operands():
 
 @pytest.mark.parametrize("M,N,K", [(32768, 1024, 448), (16384, 256, 512), (8192, 128, 128), (8192, 64, 256), (4096, 64, 64),
                                    (8192, 448, 1024)])
-def test_presplit_weight_planes(M, N, K):
+def test_presplit_weight_planes(M, N, K, wide_tiles):
     """Round 4: the weight operand of a product arrives as bf16 planes cut once per step (dc_presplit_weights +
     dc_gemm_next_b_planes) instead of being cut by every wave in its K loop.  Same planes, same MFMA order: on 128-column
     tiles the product from planes returns the SAME BITS as the in-loop split (forward and input gradient); on 64-column
@@ -375,7 +387,7 @@ def test_presplit_weight_planes(M, N, K):
 
 
 @pytest.mark.parametrize("R,C,K", [(16384, 256, 512), (8192, 128, 64), (8192, 64, 256)])
-def test_presplit_planes_with_batchnorm_prologue(R, C, K):
+def test_presplit_planes_with_batchnorm_prologue(R, C, K, wide_tiles):
     """The input-gradient product whose operand loader rebuilds the BatchNorm / activation backward (dc_linear_bn_backward_input)
     from the transposed weight planes: same bits as without planes on 128-column outputs (same planes, same MFMA order; the
     pipelined loop instead of the simple one), fp32-accurate on 64-column outputs."""
@@ -574,3 +586,39 @@ def test_layer_gradients_identical_with_and_without_batched_reductions():
         res.append([None if p.grad is None else p.grad.clone() for p in model.parameters()])
     assert len(res[0]) == len(res[1]) and sum(a is not None for a in res[0]) > 40
     assert all((a is None and c is None) or torch.equal(a, c) for a, c in zip(*res))
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 128, 128), (4096, 256, 64), (4096, 128, 512), (4096, 256, 448)])
+def test_narrow_tiles_on_few_rows(M, N, K):
+    """Round 6 rule (csrc/gemm.hip: pick_tile): a product that would launch fewer than one workgroup per CU on 64 x 128 tiles
+    runs on 64-column tiles (twice the workgroups).  Without planes that is the exact fp32 chain, with the step's weight planes
+    a split product: both no further from fp64 than 1.5 x the wide-tile exact chain + 1e-7; switch 11 restores the wide tiles."""
+    from deltaconv_amd.nn import fused
+    fused._planes_reset()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, dy = torch.randn(M, K, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    w = torch.nn.Parameter((torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV))
+    opt = lib.raw("dc_set_option")
+
+    def products():
+        with torch.no_grad():
+            return fused.mm_nt(x, w), fused.mm_nn(dy, w)
+    try:
+        opt(9, 1)
+        narrow = products()                      # no planes: exact chain on 64-column tiles
+        opt(3, 1); opt(11, 1)
+        exact_wide = products()                  # exact chain on 128-column tiles
+        opt(3, 0)
+        split_wide = products()                  # in-loop split on 128-column tiles
+        opt(11, 0); opt(9, 0)
+        fused.presplit_begin()
+        planes_narrow = products()               # the model's path: planes on 64-column tiles
+    finally:
+        opt(3, 0); opt(9, 0); opt(11, 0)
+        fused._planes_reset()
+    refs = (x.double() @ w.detach().double().t(), dy.double() @ w.detach().double())
+    assert not torch.equal(narrow[0], split_wide[0])          # forward, N % 128 == 0: the rule moved it off the wide split path
+    for i, (ref, red) in enumerate(zip(refs, (K, N))):
+        e0, e1, e2 = rel_err(exact_wide[i], ref), rel_err(narrow[i], ref), rel_err(planes_narrow[i], ref)
+        assert e1 < 1.5 * e0 + 1e-7 and e1 < _tol(red), (i, e0, e1)     # exact chain on the narrow tiles
+        assert e2 < 1.5 * e0 + 1e-7 and e2 < _tol(red), (i, e0, e2)     # split product from the planes

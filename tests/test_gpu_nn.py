@@ -609,3 +609,42 @@ def test_classification_head_dropout_runs_in_the_row_blocks():
     g = GraphedTrainStep(model, calc_loss, b, optimizer=opt)
     losses = [float(g()) for _ in range(4)]
     assert len(set(losses)) == 4 and all(l == l for l in losses), losses       # every replay: another mask
+
+
+@pytest.mark.parametrize("nc,mx,c", [(2, 2048, 256), (16, 2048, 256), (1, 4096, 256), (3, 50, 7), (5, 17, 64)])
+def test_cloud_bias_join_and_its_backward(nc, mx, c):
+    """fused.cloud_bias (dc_cloud_bias_add / dc_cloud_colsum): h + g[batch] in place for equal-size clouds and the per-cloud
+    column sums of its backward, vs the broadcast form in fp64 (reference: x_max[batch], deltanet_segmentation.py:59).
+    Tolerance: fp32 rounding of an fp64-accumulated sum, 1e-6 relative; repeated calls give the same bits."""
+    from deltaconv_amd.nn import fused
+    g = torch.Generator().manual_seed(nc * 1000 + mx + c)
+    h0 = torch.randn(nc * mx, c, generator=g).to(DEV)
+    b0 = torch.randn(nc, c, generator=g).to(DEV)
+    dy = torch.randn(nc * mx, c, generator=g).to(DEV)
+    outs = []
+    for _ in range(2):
+        h = (h0.clone() * 1.0).requires_grad_(True)
+        b = b0.clone().requires_grad_(True)
+        y = fused.cloud_bias(h * 1.0, b, mx)              # (a fresh non-leaf tensor, as the product is in the model)
+        y.backward(dy)
+        outs.append((y.detach().clone(), h.grad.clone(), b.grad.clone()))
+    ref_y = h0.double().view(nc, mx, c) + b0.double().unsqueeze(1)
+    assert rel_err(outs[0][0], ref_y.view(nc * mx, c)) < 1e-7
+    assert torch.equal(outs[0][1], dy)
+    assert rel_err(outs[0][2], dy.double().view(nc, mx, c).sum(1)) < 1e-6
+    assert all(torch.equal(a, b_) for a, b_ in zip(*outs))
+    with pytest.raises(ValueError):
+        fused.cloud_bias(h0.clone(), b0, mx + 1)
+
+
+def test_split_cols_views_and_one_launch_backward():
+    from deltaconv_amd.nn import fused
+    w = torch.randn(40, 100, device=DEV, requires_grad=True)
+    a, b = fused.split_cols(w, 36)
+    assert a.shape == (40, 36) and b.shape == (40, 64) and a.data_ptr() == w.data_ptr()
+    ga, gb = torch.randn(40, 36, device=DEV), torch.randn(40, 64, device=DEV)
+    (a * ga).sum().backward(retain_graph=True)            # only one half used: the other block is zero
+    assert torch.equal(w.grad[:, :36], ga) and float(w.grad[:, 36:].abs().max()) == 0
+    w.grad = None
+    ((a * ga).sum() + (b * gb).sum()).backward()
+    assert torch.equal(w.grad, torch.cat([ga, gb], 1))
