@@ -1066,7 +1066,9 @@ DcTnPlan dc_tn_lds_plan(long R, int M, int N) {
     // workgroups = ONE resident wave of 2 per CU (576 cost +25 %: a second, nearly empty round); <= 128 slabs
     // (r03 lab, profiles/r03_tn_x3_lab.txt: with the split products a 128 x 256 / 256 x 128 / 128 x 384 output runs 10-13 % faster on
     // 128 x 128 tiles than on 64 x 64 ones -- the bound between the two plans moved from 64K to 32K outputs)
-    const bool small = (long)M * N < 32768;
+    // (round 6: few ROWS -- the per-rank steps of 8-GPU strong scaling, R <= 8192 -- take the small plan whatever the output: 128 x 128
+    //  tiles over 128-row slabs are all prologue and epilogue; C5 per rank -3.4 %, profiles/r06_labs.txt item 9; switch 11 = 1: off)
+    const bool small = (long)M * N < 32768 || (R <= 8192 && dc_option(DC_OPT_WIDE_TILES) == 0);
     pl.bm = (M > 64 && !small) ? 128 : 64;
     pl.bn = (N > 64 && !small) ? 128 : 64;
     if (M % pl.bm != 0 && M % 64 == 0) pl.bm = 64;        // a tile that divides the output runs the unguarded loads
