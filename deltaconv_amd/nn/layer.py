@@ -68,6 +68,8 @@ class LayerCfg:
 
 # A/B switch: the max aggregation takes the last s_mlp block's BatchNorm / activation / residual into its epilogue (tile plan only)
 FUSE_MAX_RESIDUAL = [os.environ.get("DC_FUSE_MAX_RESIDUAL", "1") != "0"]
+# A/B switch: the div|curl|norm apply of a layer runs before (1) / after (0) the max-aggregation stream's dense product
+APPLY_FIRST = [os.environ.get("DC_APPLY_FIRST", "1") != "0"]
 
 
 def _padded(rows, cols, block, f32):
@@ -166,75 +168,93 @@ class DeltaConvLayerFn(torch.autograd.Function):
         co = ps[-1][0].shape[0]
         saved_m, saved_s, saved_v = [], [], []      # per block: (input, h, coef, use_batch_stats)
 
-        # ---- scalar stream, max aggregation over the k neighbours (deltaconv.py:50-54)
-        max_saved = None
-        pending_max = pending_edge = None
-        if nm == 0:
-            x_max, ldm = _rows(x_max_ext)
-        else:
-            x_max, ldm = torch.empty(n, co, **f32), co
-            inp = x
-            for (W, gm, bm), bn, slope in zip(pm[:-1], cfg.bns_m[:-1], cfg.slopes_m[:-1]):
-                h, coef, use = fused.linear_stats(inp, W, bn, gm, bm)
-                a = torch.empty_like(h)
-                call("dc_bn_act", h, n, h.shape[1], h.shape[1], coef[2], coef[3], slope, None, 0, a, h.shape[1])
-                saved_m.append((inp, h, coef, use))
-                inp = a
-            Wm, gm, bm = pm[-1]
-            bn_m, slope_m = cfg.bns_m[-1], cfg.slopes_m[-1]
-            if cfg.centralized:                      # depth 1 only (DeltaConv.forward routes depth > 1 outside)
-                y0 = fused.mm_nt(inp, Wm)
-                stat = torch.empty(3, n, co, **f32)
-                args = torch.empty(2, n, co, dtype=torch.uint8, device=dev)
-                use_m, mom, rm, rv = _bn_mode(bn_m)
-                coef_m = torch.empty(4, co, **f32)
-                ws, nb = fused._ws(n, co, dev)
-                if not use_m:
-                    coef_m = fused.eval_coeffs(gm, bm, rm, rv, float(bn_m.eps), co)
-                call("dc_edge_gather_stats", y0, co, g.nbr, n, k, co, int(use_m), gm, bm, float(bn_m.eps), mom,
-                     rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
-                     coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)
-                argsel = torch.empty(n, co, dtype=torch.uint8, device=dev)   # the selected slot: backward from the tile plan
-                # (applied below, behind the last s_mlp block, whose BatchNorm / activation / residual add it takes along)
-                pending_edge = (stat, args, coef_m, slope_m, argsel)
-                max_saved = (stat, args, argsel)
-                saved_m.append((inp, y0, coef_m, use_m))
-            else:
-                hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
-                arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
-                # the gather itself waits for the last s_mlp block (below): from the tile plan it takes that block's BatchNorm /
-                # activation pass and the residual add into its epilogue (round 6: one launch and the x_max round trip less)
-                pending_max = (hm, coef_m, slope_m, arg)
-                max_saved = (arg,)
-                saved_m.append((inp, hm, coef_m, use_m))
+        # ---- [x | div v | curl v | |v|] (deltaconv.py:57): formed FIRST (round 6, A/B switch DC_APPLY_FIRST): the apply reads v right
+        # behind the vector non-linearity that wrote it, with no dense product's output in between (profiles/r06_labs.txt item 11)
+        def build_cat():
+            # (x / v that the previous layer did not already write into this layer's operand buffers -- the first layer -- are
+            #  copied into their left columns: both copies in one launch)
+            x_cat = _adopt(x, n, ci, 4 * ci)
+            v_cat = _adopt(v, 2 * n, ci, 2 * ci + co) if cfg.vector else None
+            copies = []
+            if x_cat is None:
+                x_cat = torch.empty(n, 4 * ci, **f32)
+                copies.append((x, x_cat[:, :ci]))
+            if cfg.vector and v_cat is None:
+                # (first layer, ci = 3: two spare columns in front put the `grad @ x'` block on a 16-byte boundary with a
+                #  row stride that is a multiple of 4 floats, so that block runs from the tile plans, forward and transposed)
+                v_cat = _padded(2 * n, 2 * ci + co, 2 * ci, f32)
+                copies.append((v, v_cat[:, :ci]))
+            if copies:
+                _ops.copy_many(copies)
+            _ops.fwd_apply("div_curl_norm", cfg.div, v, ci, ldv, x_cat[:, ci:], 4 * ci)
+            return x_cat, v_cat
+        if APPLY_FIRST[0]:
+            x_cat, v_cat = build_cat()
 
         # ---- [x | div v | curl v | |v|] -> s_mlp, residual x_max (deltaconv.py:57-59)
-        # (x / v that the previous layer did not already write into this layer's operand buffers -- the first layer -- are
-        #  copied into their left columns: both copies in one launch)
-        x_cat = _adopt(x, n, ci, 4 * ci)
-        v_cat = _adopt(v, 2 * n, ci, 2 * ci + co) if cfg.vector else None
-        copies = []
-        if x_cat is None:
-            x_cat = torch.empty(n, 4 * ci, **f32)
-            copies.append((x, x_cat[:, :ci]))
-        if cfg.vector and v_cat is None:
-            # (first layer, ci = 3: two spare columns in front put the `grad @ x'` block on a 16-byte boundary with a
-            #  row stride that is a multiple of 4 floats, so that block runs from the tile plans, forward and transposed)
-            v_cat = _padded(2 * n, 2 * ci + co, 2 * ci, f32)
-            copies.append((v, v_cat[:, :ci]))
-        if copies:
-            _ops.copy_many(copies)
-        _ops.fwd_apply("div_curl_norm", cfg.div, v, ci, ldv, x_cat[:, ci:], 4 * ci)
-        inp = x_cat
-        for (W, gs, bs), bn, slope in zip(ps[:-1], cfg.bns_s[:-1], cfg.slopes_s[:-1]):
-            h, coef, use = fused.linear_stats(inp, W, bn, gs, bs)
-            a = torch.empty_like(h)
-            call("dc_bn_act", h, n, h.shape[1], h.shape[1], coef[2], coef[3], slope, None, 0, a, h.shape[1])
-            saved_s.append((inp, h, coef, use))
-            inp = a
-        Ws, gs, bs = ps[-1]
-        hs, coef_s, use_s = fused.linear_stats(inp, Ws, cfg.bns_s[-1], gs, bs)
-        saved_s.append((inp, hs, coef_s, use_s))
+        if not APPLY_FIRST[0]:
+            x_cat, v_cat = build_cat()
+        # ---- scalar stream, max aggregation over the k neighbours (deltaconv.py:50-54)
+        def run_m():
+            max_saved = None
+            pending_max = pending_edge = None
+            if nm == 0:
+                x_max, ldm = _rows(x_max_ext)
+            else:
+                x_max, ldm = torch.empty(n, co, **f32), co
+                inp = x
+                for (W, gm, bm), bn, slope in zip(pm[:-1], cfg.bns_m[:-1], cfg.slopes_m[:-1]):
+                    h, coef, use = fused.linear_stats(inp, W, bn, gm, bm)
+                    a = torch.empty_like(h)
+                    call("dc_bn_act", h, n, h.shape[1], h.shape[1], coef[2], coef[3], slope, None, 0, a, h.shape[1])
+                    saved_m.append((inp, h, coef, use))
+                    inp = a
+                Wm, gm, bm = pm[-1]
+                bn_m, slope_m = cfg.bns_m[-1], cfg.slopes_m[-1]
+                if cfg.centralized:                      # depth 1 only (DeltaConv.forward routes depth > 1 outside)
+                    y0 = fused.mm_nt(inp, Wm)
+                    stat = torch.empty(3, n, co, **f32)
+                    args = torch.empty(2, n, co, dtype=torch.uint8, device=dev)
+                    use_m, mom, rm, rv = _bn_mode(bn_m)
+                    coef_m = torch.empty(4, co, **f32)
+                    ws, nb = fused._ws(n, co, dev)
+                    if not use_m:
+                        coef_m = fused.eval_coeffs(gm, bm, rm, rv, float(bn_m.eps), co)
+                    call("dc_edge_gather_stats", y0, co, g.nbr, n, k, co, int(use_m), gm, bm, float(bn_m.eps), mom,
+                         rm if use_m else None, rv if use_m else None, stat[0], stat[1], args[0], args[1], stat[2],
+                         coef_m[0], coef_m[1], coef_m[2], coef_m[3], ws, nb)
+                    argsel = torch.empty(n, co, dtype=torch.uint8, device=dev)   # the selected slot: backward from the tile plan
+                    # (applied below, behind the last s_mlp block, whose BatchNorm / activation / residual add it takes along)
+                    pending_edge = (stat, args, coef_m, slope_m, argsel)
+                    max_saved = (stat, args, argsel)
+                    saved_m.append((inp, y0, coef_m, use_m))
+                else:
+                    hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
+                    arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
+                    # the gather itself waits for the last s_mlp block (below): from the tile plan it takes that block's BatchNorm /
+                    # activation pass and the residual add into its epilogue (round 6: one launch and the x_max round trip less)
+                    pending_max = (hm, coef_m, slope_m, arg)
+                    max_saved = (arg,)
+                    saved_m.append((inp, hm, coef_m, use_m))
+            return x_max, ldm, pending_max, pending_edge, max_saved
+
+        def run_s():
+            inp = x_cat
+            for (W, gs, bs), bn, slope in zip(ps[:-1], cfg.bns_s[:-1], cfg.slopes_s[:-1]):
+                h, coef, use = fused.linear_stats(inp, W, bn, gs, bs)
+                a = torch.empty_like(h)
+                call("dc_bn_act", h, n, h.shape[1], h.shape[1], coef[2], coef[3], slope, None, 0, a, h.shape[1])
+                saved_s.append((inp, h, coef, use))
+                inp = a
+            Ws, gs, bs = ps[-1]
+            hs, coef_s, use_s = fused.linear_stats(inp, Ws, cfg.bns_s[-1], gs, bs)
+            saved_s.append((inp, hs, coef_s, use_s))
+            return hs, coef_s
+
+        # (round-6 lab: the two independent products in the other order -- the rows the aggregation gathers written last -- +0.3 % of
+        #  the step, profiles/r06_labs.txt item 11: the max-aggregation stream's product stays first)
+        x_max, ldm, pending_max, pending_edge, max_saved = run_m()
+        hs, coef_s = run_s()
         if cfg.chain is not None:
             xbuf = torch.empty(n, cfg.chain[0], **f32)
             xbuf._dc_chain = True
@@ -276,6 +296,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
         if cfg.vector:
             K = 2 * ci + co
             ldvc = v_cat.stride(0)
+            # (round-6 lab: this apply right behind div|curl|norm, whose streamed-out block it reads: 14.2 -> 16.3 us in step, dropped)
             _ops.fwd_apply("hodge", cfg.grad, x_cat[:, ci:], ci, 4 * ci, v_cat[:, ci:], ldvc)
             _ops.fwd_apply("grad", cfg.grad, x_new, co, ldxn, v_cat[:, 2 * ci:], ldvc)
             if cfg.chain is not None and cfg.chain[1] is not None:
@@ -445,6 +466,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
             else:
                 (arg,) = max_saved
                 dcur = torch.empty(n, co, **f32)
+                # (round-6 lab: this launch right behind the one that completed d x' -- neutral: the kernel is latency-, not cache-bound)
                 _ops.bwd_knn_max(g, arg, dxn, co, lddx, dcur, co, 0)
                 first = nm - 1
             for j in range(first, -1, -1):        # [Linear -> BN -> act] blocks, last to first; block 0 feeds d x
