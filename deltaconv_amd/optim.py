@@ -112,11 +112,25 @@ def _lr_scalar(cache, group, device, who):
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
         kw.pop("fused", None)
-        kw["capturable"] = True         # step counters live on the device (torch's own step, where it runs, is capturable too)
+        self._capturable_arg = kw.pop("capturable", None)
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
         self._lr_dev = {}
         self._ticket = {}               # device -> int32 zero (the kernel's "last workgroup" counter)
         self._masters = {}              # id(group) -> the step counter its parameters share
+
+    def add_param_group(self, param_group):
+        """Groups of device parameters keep their step counters on the device (torch's `capturable` layout: its own step, where
+        it runs instead of the kernel, is then graph-capturable too); host parameters stay with torch's defaults."""
+        super().add_param_group(param_group)
+        group = self.param_groups[-1]
+        want = getattr(self, "_capturable_arg", None)
+        group["capturable"] = bool(want) if want is not None else all(p.is_cuda for p in group["params"])
+
+    def __setstate__(self, state):
+        super().__setstate__(state)             # (load_state_dict lands here with the SAVED groups' flags)
+        if getattr(self, "_capturable_arg", None) is None:
+            for group in self.param_groups:
+                group["capturable"] = all(p.is_cuda for p in group["params"])
 
     def _own_kernel(self, group):
         return (not group["amsgrad"] and not group.get("maximize", False) and not group.get("differentiable", False)
