@@ -49,3 +49,26 @@ def test_adam_on_cpu_parameters_is_torch_adam_and_keeps_its_state_dict_layout():
     oa2 = dc.optim.Adam(_params(1)[0], lr=5e-3)
     oa2.load_state_dict(copy.deepcopy(ob.state_dict()))                         # and ours takes torch's
     assert float(next(iter(oa2.state.values()))["step"]) == 3.0
+
+
+def test_copy_many_and_split_cols_host_logic():
+    """Pairs the copy kernel does not take (host tensors here) go through torch's copy; split_cols' backward assembles ONE
+    gradient tensor from the two halves (or zeros for a half nobody used)."""
+    from deltaconv_amd import _ops
+    from deltaconv_amd.nn import fused
+    a, b = torch.arange(12.).view(4, 3), torch.zeros(4, 5)
+    y, yd = torch.arange(6), torch.zeros(6, dtype=torch.int64)
+    _ops.copy_many([(a, b[:, :3]), (y, yd), (torch.zeros(0, 3), torch.zeros(0, 3))])
+    assert torch.equal(b[:, :3], a) and float(b[:, 3:].abs().max()) == 0 and torch.equal(yd, y)
+    w = torch.randn(6, 10, requires_grad=True)
+    wa, wb = fused.split_cols(w, 4)
+    assert wa.shape == (6, 4) and wb.shape == (6, 6)
+    ga, gb = torch.randn(6, 4), torch.randn(6, 6)
+    ((wa * ga).sum() + (wb * gb).sum()).backward()
+    assert torch.equal(w.grad, torch.cat([ga, gb], 1))
+    w.grad = None
+    wa, wb = fused.split_cols(w, 4)
+    (wb * gb).sum().backward()
+    assert torch.equal(w.grad[:, 4:], gb) and float(w.grad[:, :4].abs().max()) == 0
+    with fused.tn_batch():                       # nothing queued: nothing launched
+        pass
