@@ -4,6 +4,8 @@
 #pragma once
 #include "common.h"
 #include <algorithm>
+#include <type_traits>
+#include <cstring>
 
 namespace dccol {
 namespace {   // internal linkage: this header is included by several translation units
@@ -162,6 +164,64 @@ struct SumsFin {
     }
 };
 
+// Several finalisers in ONE launch (deferred finalisers, common.h): block -> (entry, column); the same lane-strided sums and
+// butterfly as colreduce_final_kernel, hence the same bits.
+struct FinTable {
+    int count;
+    int first[DC_FIN_MAX + 1];                 // prefix sums of the entries' column counts
+    int kind[DC_FIN_MAX], chunks[DC_FIN_MAX], C[DC_FIN_MAX];
+    const double* partial[DC_FIN_MAX];
+    BnFin bn[DC_FIN_MAX];
+    BwdCoefFin bc[DC_FIN_MAX];
+};
+__global__ __launch_bounds__(64) void colreduce_final_many_kernel(FinTable t) {
+    int e = 0;
+    while (e + 1 < t.count && (int)blockIdx.x >= t.first[e + 1]) ++e;
+    const int col = blockIdx.x - t.first[e], chunks = t.chunks[e], C = t.C[e];
+    const double* p0 = t.partial[e] + (long)col * chunks;
+    const double* p1 = t.partial[e] + ((long)C + col) * chunks;
+    double s0 = 0, s1 = 0;
+    for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+        s0 += p0[ch];
+        s1 += p1[ch];
+    }
+    s0 = dc_wave_sum(s0);
+    s1 = dc_wave_sum(s1);
+    if (threadIdx.x == 0) {
+        if (t.kind[e] == DC_FIN_BN) t.bn[e](col, s0, s1);
+        else t.bc[e](col, s0, s1);
+    }
+}
+// launch (or queue, when the caller asked for it inside an open batch) the finaliser of a reduction whose partials are in place
+template <class FIN>
+inline void finalise_or_defer(int kind, const double* partial, int chunks, int C, const FIN& fin, hipStream_t s) {
+    static_assert(sizeof(FIN) <= DC_FIN_BLOB, "finaliser object larger than the queue's blob");
+    if (dc_fin_take_request()) {
+        dc_fin_push(kind, partial, chunks, C, &fin, sizeof(FIN));
+        return;
+    }
+    hipLaunchKernelGGL((colreduce_final_kernel<FIN>), dim3(C), dim3(64), 0, s, partial, chunks, C, fin);
+}
+inline void flush_finalisers(hipStream_t s) {
+    DcFinPending* q;
+    const int n = dc_fin_pending(&q);
+    if (n > 0) {
+        FinTable t;
+        t.count = n;
+        int cols = 0;
+        for (int i = 0; i < n; ++i) {
+            t.first[i] = cols;
+            t.kind[i] = q[i].kind; t.chunks[i] = q[i].chunks; t.C[i] = q[i].C; t.partial[i] = q[i].partial;
+            if (q[i].kind == DC_FIN_BN) memcpy(&t.bn[i], q[i].blob, sizeof(BnFin));
+            else memcpy(&t.bc[i], q[i].blob, sizeof(BwdCoefFin));
+            cols += q[i].C;
+        }
+        t.first[n] = cols;
+        hipLaunchKernelGGL(colreduce_final_many_kernel, dim3(cols), dim3(64), 0, s, t);
+    }
+    dc_fin_clear();
+}
+
 // coefficients from (possibly all-reduced) column sums over `count` rows; one thread per column
 // count <= 0: the row count is itself on the device, sums[2C] (all-reduced together with the sums: no host sync)
 __global__ void bn_coeffs_from_sums_kernel(const double* __restrict__ sums, long count, int C, BnFin fin) {
@@ -213,10 +273,16 @@ inline Ws carve(void* ws, long R, int C) {
 }
 
 template <int V, class F, class FIN>
-void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s, FIN fin, int blocks = DC_COLRED_BLOCKS) {
+void run_colreduce(F f, long R, int C, const Ws& w, hipStream_t s, FIN fin, int blocks = DC_COLRED_BLOCKS, int defer_kind = -1) {
     const int rpc = rows_per_chunk(R, C, blocks), chunks = chunks_of(R, C, blocks);
     dim3 grid(chunks, dc_cdiv(C, CT * V));
     hipLaunchKernelGGL((colreduce_kernel<V, 2, F>), grid, dim3(TPB), 0, s, f, R, C, chunks, rpc, w.partial);
+    if constexpr (std::is_same<FIN, BnFin>::value || std::is_same<FIN, BwdCoefFin>::value) {
+        if (defer_kind >= 0) {                  // (deferrable kinds only: the queue's kernel knows these two finalisers)
+            finalise_or_defer(defer_kind, w.partial, chunks, C, fin, s);
+            return;
+        }
+    }
     hipLaunchKernelGGL((colreduce_final_kernel<FIN>), dim3(C), dim3(64), 0, s, w.partial, chunks, C, fin);
 }
 

@@ -72,6 +72,21 @@ __device__ __forceinline__ void dc_store16(float* p, dc_f32x4 v) {
 // exit with its stores complete | unused | unused], constant 100 MHz clock (s_memrealtime) -- at ENQUEUE time, so a launch
 // captured into a HIP graph keeps its record across replays; the caller resets the records (min = huge, max = 0) before a
 // replay.  Off (buf = NULL): the kernels get a null pointer and skip two scalar branches.
+// ---- deferred finalisers (round 6): between dc_finalisers_begin() and dc_finalisers_end() an entry point whose caller asked for it
+// (dc_finaliser_defer_next(): one-shot) queues the second stage of its column reduction instead of launching it; the end call
+// launches ONE kernel for all queued finalisers (colreduce.h: colreduce_final_many_kernel).  Two independent products of a layer
+// node (max-aggregation stream, s_mlp) thus share one finaliser launch.  Host-side state, thread-local (error.hip).
+constexpr int DC_FIN_MAX = 4, DC_FIN_BLOB = 128;
+enum { DC_FIN_BN = 0, DC_FIN_BWD_COEF = 1 };
+struct DcFinPending {
+    int kind, chunks, C;
+    const double* partial;
+    alignas(8) unsigned char blob[DC_FIN_BLOB];       // the finaliser object (dccol::BnFin / BwdCoefFin), copied by bytes
+};
+bool dc_fin_take_request();                           // true once after dc_finaliser_defer_next() inside an open batch with room
+void dc_fin_push(int kind, const double* partial, int chunks, int C, const void* fin, size_t bytes);
+int dc_fin_pending(DcFinPending** out);               // -> count (and the queue)
+void dc_fin_clear();
 unsigned long long* dc_stamp_next(int tag);        // host side; nullptr when stamping is off or the records are used up
 __device__ __forceinline__ void dc_stamp_in(unsigned long long* st) {
     if (st && threadIdx.x == 0) atomicMin(st, (unsigned long long)wall_clock64());

@@ -1,4 +1,5 @@
 // Error string + version of the C-ABI library.
+#include <cstring>
 #include "common.h"
 #include <stdarg.h>
 
@@ -45,6 +46,35 @@ bool dc_ensure_lds(unsigned long long* done_mask, const void* kernel, size_t byt
     }
     if (bit) __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
     return true;
+}
+
+// ---- deferred finalisers (common.h) -------------------------------------------------------------------------------------------
+static thread_local DcFinPending g_fin[DC_FIN_MAX];
+static thread_local int g_fin_count = 0;
+static thread_local bool g_fin_open = false, g_fin_request = false;
+bool dc_fin_take_request() {
+    const bool take = g_fin_open && g_fin_request && g_fin_count < DC_FIN_MAX;
+    g_fin_request = false;
+    return take;
+}
+void dc_fin_push(int kind, const double* partial, int chunks, int C, const void* fin, size_t bytes) {
+    DcFinPending& e = g_fin[g_fin_count++];
+    e.kind = kind; e.partial = partial; e.chunks = chunks; e.C = C;
+    memcpy(e.blob, fin, bytes);
+}
+int dc_fin_pending(DcFinPending** out) { *out = g_fin; return g_fin_count; }
+void dc_fin_clear() { g_fin_count = 0; g_fin_open = false; g_fin_request = false; }
+DC_EXPORT int dc_finalisers_begin(void) {
+    if (g_fin_open) {
+        dc_set_error("dc_finalisers_begin: a batch is already open on this thread");
+        return DC_ERR_ARG;
+    }
+    g_fin_open = true; g_fin_count = 0; g_fin_request = false;
+    return DC_OK;
+}
+DC_EXPORT int dc_finaliser_defer_next(void) {
+    g_fin_request = g_fin_open;
+    return DC_OK;
 }
 
 // ---- device-clock stamps (common.h) --------------------------------------------------------------------------------------

@@ -1176,8 +1176,7 @@ DC_EXPORT int dc_linear_bn_stats_forward(const float* X, int64_t ldx, const floa
                           N, s))
         return rc;
     const dccol::BnFin fin{(long)M, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift};
-    hipLaunchKernelGGL((dccol::colreduce_final_kernel<dccol::BnFin>), dim3(N), dim3(64), 0, s, part,
-                       chunks_for(M, N, K, tile), N, fin);
+    dccol::finalise_or_defer(DC_FIN_BN, part, chunks_for(M, N, K, tile), N, fin, s);     // (queued when the caller asked: common.h)
     DC_CHECK_LAUNCH("dc_linear_bn_stats_forward");
     return DC_OK;
 }

@@ -660,10 +660,22 @@ DC_EXPORT int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const flo
     const Ws w = carve(workspace, R, C);
     const BwdCoefFin fin{(long)R, gamma, scale, shift, mean, invstd, training, dgamma, dbeta, coefs, C};
     if (C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && al16(dy) && al16(h))
-        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
+        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin, DC_COLRED_BLOCKS,
+                         DC_FIN_BWD_COEF);
     else
-        run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin);
+        run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin, DC_COLRED_BLOCKS,
+                         DC_FIN_BWD_COEF);
     DC_CHECK_LAUNCH("dc_bn_act_backward_reduce");
+    return DC_OK;
+}
+
+// Closes the batch opened by dc_finalisers_begin: ONE launch for every finaliser queued since (those of dc_linear_bn_stats_forward
+// and dc_bn_act_backward_reduce calls announced by dc_finaliser_defer_next); discard != 0 drops the queue instead (error paths).
+// The coefficient outputs of the queued calls are valid behind this launch; their workspaces must stay alive until then.
+DC_EXPORT int dc_finalisers_end(int32_t discard, void* stream) {
+    if (discard) dc_fin_clear();
+    else flush_finalisers(static_cast<hipStream_t>(stream));
+    DC_CHECK_LAUNCH("dc_finalisers_end");
     return DC_OK;
 }
 

@@ -731,6 +731,44 @@ def tn_batch():
         _TN.batch = None
 
 
+# ---- deferred finalisers: the second stages of independent column reductions in ONE launch ----------------------------------
+# (csrc/common.h, colreduce.h: dc_finalisers_begin / dc_finaliser_defer_next / dc_finalisers_end).  `with fin_batch():` opens the
+# queue; `linear_stats(..., defer_final=True)` / `bn_block_reduce(..., defer_final=True)` inside it queue their finaliser; the
+# coefficients are valid when the block exits.  DC_FIN_BATCH=0: every finaliser is its own launch (A/B: same bits).
+USE_FIN_BATCH = [os.environ.get("DC_FIN_BATCH", "1") != "0"]
+_FIN = threading.local()
+
+
+@contextlib.contextmanager
+def fin_batch():
+    if not USE_FIN_BATCH[0] or getattr(_FIN, "keep", None) is not None:
+        yield
+        return
+    rc = lib.raw("dc_finalisers_begin")()
+    if rc != 0:
+        raise RuntimeError(f"dc_finalisers_begin failed (rc={rc}): {lib.last_error()}")
+    _FIN.keep = []
+    ok = False
+    try:
+        yield
+        ok = True
+    finally:
+        _FIN.keep = None
+        rc = lib.raw("dc_finalisers_end")(0 if ok else 1, torch.cuda.current_stream().cuda_stream)
+        if ok and rc != 0:
+            raise RuntimeError(f"dc_finalisers_end failed (rc={rc}): {lib.last_error()}")
+
+
+def _defer_final(*keepalive):
+    """Ask the next reduction call to queue its finaliser (only inside fin_batch()); its workspaces stay alive until the flush."""
+    keep = getattr(_FIN, "keep", None)
+    if keep is None:
+        return False
+    keep.extend(keepalive)
+    lib.raw("dc_finaliser_defer_next")()
+    return True
+
+
 def gemm_tn(a, b):
     """a.t() @ b for a [R,M], b [R,N] (weight gradient dW = dY^T X) on the hand-written fp32-MFMA split-K kernel
     (csrc/gemm_tn.hip), whatever the shape.  Inside `tn_batch()` the result is complete when that block exits."""
@@ -815,7 +853,7 @@ def linear_grads(dh, x, w, dx_out=None, accumulate=False):
     return gemm_tn(dh, xx), mm_nn(dh, w, out=dx_out, accumulate=accumulate)
 
 
-def linear_stats(x, w, bn, gamma, beta, vn=0):
+def linear_stats(x, w, bn, gamma, beta, vn=0, defer_final=False):
     """h = x w^T together with the BatchNorm coefficients of the layer behind it, from the GEMM epilogue:
     -> (h, coef[4, C] = mean / invstd / scale / shift, use_batch_stats).  vn = 2: w = the [2co, K] view of the first
     vector block, statistics of the per-point norms of the interleaved (P_c, Q_c) output (C = co); vn = 1: a deeper
@@ -864,6 +902,8 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
             lib.call("dc_linear_vn_stats_forward", x, x.stride(0), w, w.stride(0), rows, c, k, h, n, int(vn == 2), gamma,
                      beta, float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
         else:
+            if defer_final:
+                _defer_final(ws)           # (inside fin_batch(): coef is valid when that block exits)
             lib.call("dc_linear_bn_stats_forward", x, x.stride(0), w, w.stride(0), m, n, k, h, n, gamma, beta,
                      float(bn.eps), mom, rm, rv, coef[0], coef[1], coef[2], coef[3], 0, ws, nb)
         return h, coef, BatchStats(None)
@@ -874,55 +914,87 @@ def linear_stats(x, w, bn, gamma, beta, vn=0):
 FUSE_BN_BWD = True     # A/B switch: BatchNorm/activation backward folded into the consuming GEMMs (no dh tensor)
 
 
+def bn_block_reduce(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, defer_final=False):
+    """First half of bn_block_backward in its fused form: the one reduction over (dy, h) -> dgamma / dbeta and the five
+    per-column coefficients of the GEMM prologue.  -> state for bn_block_products, or None when the fused form does not
+    apply (the caller then uses bn_block_backward).  defer_final (inside fin_batch()): the finaliser is queued -- the
+    coefficients are valid when that block exits, bn_block_products must come after it."""
+    r, c = h.shape
+    k = W.shape[1]
+    dev = h.device
+    inp = _rowmajor(inp)
+    _require_fp32_gpu("bn_block_backward", h, inp)
+    group = group_of(use_batch)        # the group of the FORWARD statistics
+    if not ((FUSE_BN_BWD or group is not None) and c * k <= OWN_TN_MAX_OUTPUTS):
+        return None
+    dg = torch.empty(c, dtype=torch.float32, device=dev)
+    db = torch.empty(c, dtype=torch.float32, device=dev)
+    ws, nb = _ws(r, c, dev)
+    coefs = torch.empty(5 * c, dtype=torch.float32, device=dev)
+    if group is not None:     # sums of this rank -> all-reduce -> the prologue coefficients from the global sums
+        stats, local = _sync_stats(("dc_bn_act_backward_sums", lambda out: (dy, lddy, h, c, r, c, coef[2], coef[3], coef[0],
+                                                                         coef[1], slope, out, ws, nb)), c, r, dev, group)
+        lib.call("dc_bn_backward_coefs_from_sums", stats, 0, local, c, gamma, coef[2], coef[3], coef[0], coef[1], 1, dg, db,
+                 coefs)
+    else:
+        if defer_final:
+            _defer_final(ws, coefs, dg, db, coef)
+        lib.call("dc_bn_act_backward_reduce", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
+                 int(use_batch), dg, db, coefs, ws, nb)
+    return dy, lddy, inp, h, coefs, slope, W, dg, db
+
+
+def bn_block_products(state, want_dinp=True, dinp_out=None, accumulate=False):
+    """Second half: both products rebuild dh = c_g dy act'(c_sc h + c_sh) + c_a h + c_b in their operand loaders.
+    -> (dW [C, K], dgamma, dbeta, d_inp [R, K] or None)."""
+    dy, lddy, inp, h, coefs, slope, W, dg, db = state
+    r, c = h.shape
+    k = W.shape[1]
+    dev = h.device
+    dW = torch.empty(c, k, dtype=torch.float32, device=dev)
+    nb2 = lib.raw("dc_gemm_tn_workspace_bytes")(r, c, k)
+    ws2 = torch.empty((nb2 + 3) // 4, dtype=torch.float32, device=dev)
+    batch = getattr(_TN, "batch", None)
+    if batch is not None:
+        slabs = ctypes.c_int32(0)
+        lib.call("dc_linear_bn_backward_weight_slabs", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, ws2,
+                 ws2.numel() * 4, ctypes.byref(slabs))
+        batch.add(ws2, slabs.value, c, k, dW, k)
+    else:
+        lib.call("dc_linear_bn_backward_weight", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, dW, k, 0, ws2,
+                 ws2.numel() * 4)
+    dinp = None
+    if want_dinp:
+        dinp = dinp_out if dinp_out is not None else torch.empty(r, k, dtype=torch.float32, device=dev)
+        W = _rowmajor(W)
+        _hint_planes(W, True)
+        lib.call("dc_linear_bn_backward_input", dy, lddy, h, c, coefs, slope, W, W.stride(0), r, c, k, dinp,
+                 dinp.stride(0), int(accumulate), 0)
+    return dW, dg, db, dinp
+
+
 def bn_block_backward(dy, lddy, inp, h, coef, use_batch, gamma, slope, W, want_dinp=True, dinp_out=None,
                       accumulate=False):
     """Backward of one block y = leaky(batch_norm(inp W^T)) for the incoming dy [R, C] (row stride lddy):
     -> (dW [C, K], dgamma, dbeta, d_inp [R, K] or None).  d_inp lands in `dinp_out` (+= when accumulate) if given.
     Fused form (csrc/gemm.hip prologue): one reduction over (dy, h) yields dgamma / dbeta and five per-column
-    coefficients; both products rebuild dh = c_g dy act'(c_sc h + c_sh) + c_a h + c_b in their operand loaders, so the
-    [R, C] tensor dh is never written or read.  Otherwise: dc_bn_act_backward, then the two products on dh."""
+    coefficients (bn_block_reduce); both products rebuild dh = c_g dy act'(c_sc h + c_sh) + c_a h + c_b in their operand
+    loaders (bn_block_products), so the [R, C] tensor dh is never written or read.  Otherwise: dc_bn_act_backward, then the
+    two products on dh."""
+    state = bn_block_reduce(dy, lddy, inp, h, coef, use_batch, gamma, slope, W)
+    if state is not None:
+        return bn_block_products(state, want_dinp, dinp_out, accumulate)
     r, c = h.shape
     k = W.shape[1]
     dev = h.device
+    group = group_of(use_batch)
+    if group is not None:              # same shapes on every rank: every rank raises here, before any collective
+        raise NotImplementedError(f"synchronised BatchNorm backward of a fused block with {c} x {k} > {OWN_TN_MAX_OUTPUTS} "
+                                  "weight entries (the un-fused form has no split reduction)")
     dg = torch.empty(c, dtype=torch.float32, device=dev)
     db = torch.empty(c, dtype=torch.float32, device=dev)
     ws, nb = _ws(r, c, dev)
     inp = _rowmajor(inp)
-    _require_fp32_gpu("bn_block_backward", h, inp)
-    group = group_of(use_batch)        # the group of the FORWARD statistics
-    if (FUSE_BN_BWD or group is not None) and c * k <= OWN_TN_MAX_OUTPUTS:
-        coefs = torch.empty(5 * c, dtype=torch.float32, device=dev)
-        if group is not None:     # sums of this rank -> all-reduce -> the prologue coefficients from the global sums
-            stats, local = _sync_stats(("dc_bn_act_backward_sums", lambda out: (dy, lddy, h, c, r, c, coef[2], coef[3], coef[0],
-                                                                             coef[1], slope, out, ws, nb)), c, r, dev, group)
-            lib.call("dc_bn_backward_coefs_from_sums", stats, 0, local, c, gamma, coef[2], coef[3], coef[0], coef[1], 1, dg, db,
-                     coefs)
-        else:
-            lib.call("dc_bn_act_backward_reduce", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope,
-                     int(use_batch), dg, db, coefs, ws, nb)
-        dW = torch.empty(c, k, dtype=torch.float32, device=dev)
-        nb2 = lib.raw("dc_gemm_tn_workspace_bytes")(r, c, k)
-        ws2 = torch.empty((nb2 + 3) // 4, dtype=torch.float32, device=dev)
-        batch = getattr(_TN, "batch", None)
-        if batch is not None:
-            slabs = ctypes.c_int32(0)
-            lib.call("dc_linear_bn_backward_weight_slabs", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, ws2,
-                     ws2.numel() * 4, ctypes.byref(slabs))
-            batch.add(ws2, slabs.value, c, k, dW, k)
-        else:
-            lib.call("dc_linear_bn_backward_weight", dy, lddy, h, c, coefs, slope, inp, inp.stride(0), r, c, k, dW, k, 0, ws2,
-                     ws2.numel() * 4)
-        dinp = None
-        if want_dinp:
-            dinp = dinp_out if dinp_out is not None else torch.empty(r, k, dtype=torch.float32, device=dev)
-            W = _rowmajor(W)
-            _hint_planes(W, True)
-            lib.call("dc_linear_bn_backward_input", dy, lddy, h, c, coefs, slope, W, W.stride(0), r, c, k, dinp,
-                     dinp.stride(0), int(accumulate), 0)
-        return dW, dg, db, dinp
-    if group is not None:              # same shapes on every rank: every rank raises here, before any collective
-        raise NotImplementedError(f"synchronised BatchNorm backward of a fused block with {c} x {k} > {OWN_TN_MAX_OUTPUTS} "
-                                  "weight entries (the un-fused form has no split reduction)")
     dh = torch.empty_like(h)
     lib.call("dc_bn_act_backward", dy, lddy, h, c, r, c, coef[2], coef[3], coef[0], coef[1], gamma, slope, int(use_batch),
              dh, c, dg, db, ws, nb)

@@ -229,7 +229,7 @@ class DeltaConvLayerFn(torch.autograd.Function):
                     max_saved = (stat, args, argsel)
                     saved_m.append((inp, y0, coef_m, use_m))
                 else:
-                    hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm)        # GEMM + statistics epilogue
+                    hm, coef_m, use_m = fused.linear_stats(inp, Wm, bn_m, gm, bm, defer_final=True)   # GEMM + statistics epilogue
                     arg = torch.empty(n, co, dtype=torch.uint8, device=dev)     # BN + activation folded into the gather
                     # the gather itself waits for the last s_mlp block (below): from the tile plan it takes that block's BatchNorm /
                     # activation pass and the residual add into its epilogue (round 6: one launch and the x_max round trip less)
@@ -247,14 +247,17 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 saved_s.append((inp, h, coef, use))
                 inp = a
             Ws, gs, bs = ps[-1]
-            hs, coef_s, use_s = fused.linear_stats(inp, Ws, cfg.bns_s[-1], gs, bs)
+            hs, coef_s, use_s = fused.linear_stats(inp, Ws, cfg.bns_s[-1], gs, bs, defer_final=True)
             saved_s.append((inp, hs, coef_s, use_s))
             return hs, coef_s
 
         # (round-6 lab: the two independent products in the other order -- the rows the aggregation gathers written last -- +0.3 % of
         #  the step, profiles/r06_labs.txt item 11: the max-aggregation stream's product stays first)
-        x_max, ldm, pending_max, pending_edge, max_saved = run_m()
-        hs, coef_s = run_s()
+        # (the finalisers of the two streams' LAST products share one launch: their coefficients are first read by the max
+        #  aggregation below -- fused.fin_batch, round 6)
+        with fused.fin_batch():
+            x_max, ldm, pending_max, pending_edge, max_saved = run_m()
+            hs, coef_s = run_s()
         if cfg.chain is not None:
             xbuf = torch.empty(n, cfg.chain[0], **f32)
             xbuf._dc_chain = True
@@ -413,12 +416,31 @@ class DeltaConvLayerFn(torch.autograd.Function):
         # ---- s_mlp blocks (residual: d x_max = d x')
         d_xcat = None
         dcur, ldd = dxn, lddx
+        # (round 6) the BatchNorm-backward reductions of the LAST s_mlp block and of the max-aggregation stream's last block
+        # both start from d x': the max aggregation's backward runs up here and the two finalisers share one launch
+        # (fused.fin_batch; same sums, same bits); the products follow in the old order
+        st_s = pair_m = None
+        if nm > 0 and not centralized and fused.USE_FIN_BATCH[0]:
+            (arg,) = max_saved
+            dmax = torch.empty(n, co, **f32)
+            _ops.bwd_knn_max(g, arg, dxn, co, lddx, dmax, co, 0)
+            (inp_s, h_s, coef_s), (W_s, gs_s, _) = ss[ns - 1], ps[ns - 1]
+            (inp_m, h_m, coef_m), (W_m, gm_m, _) = sm[nm - 1], pm[nm - 1]
+            with fused.fin_batch():
+                st_s = fused.bn_block_reduce(dcur, ldd, inp_s, h_s, coef_s, use_s[ns - 1], gs_s, cfg.slopes_s[ns - 1], W_s,
+                                             defer_final=True)
+                st_m = fused.bn_block_reduce(dmax, co, inp_m, h_m, coef_m, use_m[nm - 1], gm_m, cfg.slopes_m[nm - 1], W_m,
+                                             defer_final=True)
+            pair_m = (st_m, dmax)
         for j in range(ns - 1, -1, -1):
             inp, h, coef = ss[j]
             W, gs, _ = ps[j]
             # (j == 0: d_inp = [n, 4ci] = d[x | div | curl | norm])
-            dW, dg, db, dinp = fused.bn_block_backward(dcur, ldd, inp, h, coef, use_s[j], gs, cfg.slopes_s[j], W,
-                                                       want_dinp=(j > 0 or need_x or need_v))
+            if j == ns - 1 and st_s is not None:
+                dW, dg, db, dinp = fused.bn_block_products(st_s, want_dinp=(j > 0 or need_x or need_v))
+            else:
+                dW, dg, db, dinp = fused.bn_block_backward(dcur, ldd, inp, h, coef, use_s[j], gs, cfg.slopes_s[j], W,
+                                                           want_dinp=(j > 0 or need_x or need_v))
             gs_list[j] = (dW, dg, db)
             if j > 0:
                 dcur, ldd = dinp, dinp.stride(0)
@@ -465,17 +487,23 @@ class DeltaConvLayerFn(torch.autograd.Function):
                 first = nm - 2
             else:
                 (arg,) = max_saved
-                dcur = torch.empty(n, co, **f32)
-                # (round-6 lab: this launch right behind the one that completed d x' -- neutral: the kernel is latency-, not cache-bound)
-                _ops.bwd_knn_max(g, arg, dxn, co, lddx, dcur, co, 0)
+                if pair_m is not None:            # (done above, with the reduction of its last block)
+                    dcur = pair_m[1]
+                else:
+                    dcur = torch.empty(n, co, **f32)
+                    _ops.bwd_knn_max(g, arg, dxn, co, lddx, dcur, co, 0)
                 first = nm - 1
             for j in range(first, -1, -1):        # [Linear -> BN -> act] blocks, last to first; block 0 feeds d x
                 inp, h, coef = sm[j]
                 W, gmj, _ = pm[j]
                 into_dx = j == 0 and need_x
-                dW, dg, db, dinp = fused.bn_block_backward(dcur, dcur.stride(0), inp, h, coef, use_m[j], gmj,
-                                                           cfg.slopes_m[j], W, want_dinp=(j > 0 or need_x),
-                                                           dinp_out=dx if into_dx else None, accumulate=into_dx)
+                if j == nm - 1 and pair_m is not None and pair_m[0] is not None:
+                    dW, dg, db, dinp = fused.bn_block_products(pair_m[0], want_dinp=(j > 0 or need_x),
+                                                               dinp_out=dx if into_dx else None, accumulate=into_dx)
+                else:
+                    dW, dg, db, dinp = fused.bn_block_backward(dcur, dcur.stride(0), inp, h, coef, use_m[j], gmj,
+                                                               cfg.slopes_m[j], W, want_dinp=(j > 0 or need_x),
+                                                               dinp_out=dx if into_dx else None, accumulate=into_dx)
                 gm_list[j] = (dW, dg, db)
                 dcur = dinp
 

@@ -47,6 +47,16 @@ const char* dc_last_error(void);
  * 11: value 1 = dense products with fewer than 256 workgroups keep 128-column tiles (round-6 rule off). */
 int dc_set_option(int32_t key, int32_t value);
 
+/* Deferred finalisers (round 6): a column reduction is two launches (partials, finaliser).  Between dc_finalisers_begin() and
+ * dc_finalisers_end() a call of dc_linear_bn_stats_forward / dc_bn_act_backward_reduce announced by dc_finaliser_defer_next()
+ * (one-shot, per call) queues its finaliser instead of launching it; dc_finalisers_end launches ONE kernel for all of them (at
+ * most 4; discard != 0: drops them).  The independent products of a DeltaConv layer (max-aggregation stream and s_mlp,
+ * deltaconv/nn/deltaconv.py:50-59) share a finaliser launch this way -- same sums, same bits.  The coefficient outputs of the
+ * queued calls are valid behind dc_finalisers_end; their workspaces must stay alive until then.  Thread-local host state. */
+int dc_finalisers_begin(void);
+int dc_finaliser_defer_next(void);
+int dc_finalisers_end(int32_t discard, void* stream);
+
 /* Measurement aid (bench.py `roofline.frac`): device-clock stamps of the tiled two-piece forward applies and the tiled transposed applies.  After
  * dc_stamp_buffer(buf, slots) every launch of that family takes the next 4 x uint64 record of `buf` AT ENQUEUE TIME (a launch
  * captured into a HIP graph keeps its record across replays): [0] earliest workgroup entry, [1] latest workgroup exit with

@@ -568,22 +568,29 @@ def test_batched_slab_reductions_write_the_same_bits():
         fused.USE_TN_BATCH[0] = True
 
 
-def test_layer_gradients_identical_with_and_without_batched_reductions():
-    """A DeltaConv layer step with the slab sums batched per node == the same step with one reduction launch per weight."""
+@pytest.mark.parametrize("switch", ["USE_TN_BATCH", "USE_FIN_BATCH"])
+def test_layer_gradients_identical_with_and_without_batched_reductions(switch):
+    """A DeltaConv model step with the slab sums batched per node (USE_TN_BATCH) / the finalisers of a node's independent column
+    reductions in one launch (USE_FIN_BATCH) == the same step with one launch per weight / per reduction: logits, running
+    statistics and every gradient bit for bit."""
     import deltaconv_amd as dc
     from deltaconv_amd.data import synthetic_batch
     from deltaconv_amd.nn import fused
     b = synthetic_batch(8, 1024, seed=5).to(DEV)
-    res = []
+    res, outs, bufs = [], [], []
     for on in (True, False):
         torch.manual_seed(0)
         model = dc.models.DeltaNetClassification(3, 40).to(DEV).train()
-        fused.USE_TN_BATCH[0] = on
+        getattr(fused, switch)[0] = on
         try:
-            model(b).square().mean().backward()
+            out = model(b)
+            out.square().mean().backward()
         finally:
-            fused.USE_TN_BATCH[0] = True
+            getattr(fused, switch)[0] = True
+        outs.append(out.detach().clone())
+        bufs.append([t.clone() for t in model.buffers()])
         res.append([None if p.grad is None else p.grad.clone() for p in model.parameters()])
+    assert torch.equal(outs[0], outs[1]) and all(torch.equal(a, c) for a, c in zip(*bufs))
     assert len(res[0]) == len(res[1]) and sum(a is not None for a in res[0]) > 40
     assert all((a is None and c is None) or torch.equal(a, c) for a, c in zip(*res))
 
