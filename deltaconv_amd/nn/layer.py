@@ -397,7 +397,9 @@ class DeltaConvLayerFn(torch.autograd.Function):
                     else:   # first layer (x, v carry no gradient): only the `grad @ x'` block of d v_cat is consumed
                         dW = fused.gemm_tn(dh, inp).view(W.shape[0], 2 * K)
                         dv_cat = _padded(2 * n, K, 2 * ci, f32)
-                        fused.mm_nn(dh, Wst[:, 2 * ci:].contiguous(), out=dv_cat[:, 2 * ci:])
+                        # (the strided, 8-byte-aligned weight block as it lies: the product's guarded scalar loads of it cost what the
+                        #  copy launch that made it contiguous did -- round 6: 2.846 / 2.844 -> 2.849 / 2.844 ms, one launch less)
+                        fused.mm_nn(dh, Wst[:, 2 * ci:], out=dv_cat[:, 2 * ci:])
                 else:
                     dW, dcur = fused.linear_grads(dh, inp, W)
                     ldd = dcur.stride(0)
