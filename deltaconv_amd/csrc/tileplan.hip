@@ -21,13 +21,11 @@ __device__ __forceinline__ unsigned spread10(unsigned x) {   // 10 bits -> every
     return x;
 }
 
-// Morton order of every cloud by RANKING, two kernels.
-// tile_key_kernel: workgroup (cloud, chunk of 256 points) reduces the cloud's bounding box (redundantly per chunk: 12
-//   bytes per point) and writes the sort keys of its chunk: an 18-bit Morton code (6 bits per axis: 262 144 cells for
-//   <= 4096 points) above the 12-bit index inside the cloud -- one 32-bit word per point, unique, so the order is total
-//   and deterministic.  Chunk 0 also resets the cloud's tile range: -1 padding behind the last point, zero unique-row
-//   counts (unused tile ids stay empty).
-// tile_rank_kernel: workgroup (cloud, 64 points) holds the cloud's keys in LDS; four lanes per point each count the keys
+// Morton order of every cloud by RANKING.
+// Sort keys: an 18-bit Morton code (6 bits per axis of the cloud's bounding box: 262 144 cells for <= 4096 points) above the
+//   12-bit index inside the cloud -- one 32-bit word per point, unique, so the order is total and deterministic.
+// tile_rank_kernel: workgroup (cloud, 64 points) forms the cloud's keys in LDS (chunk 0 also resets the cloud's tile range: -1
+//   padding behind the last point, zero unique-row counts: unused tile ids stay empty); four lanes per point each count the keys
 //   below their point's key in a quarter of the list (broadcast 16-byte LDS reads, one compare + add per candidate),
 //   the four counts are added and the point's id is written at its rank.  No sort passes, no barriers in the loop,
 //   N / 64 workgroups per cloud (a bitonic sort in one workgroup per cloud took 24 us at 32 x 1024 points and left 7/8
@@ -64,21 +62,27 @@ __device__ __forceinline__ int block_find_cloud(const int* __restrict__ cloud_pt
     return b;
 }
 
-__global__ __launch_bounds__(256) void tile_key_kernel(const float* __restrict__ pos, const int* __restrict__ cloud_ptr,
-                                                       int num_clouds, unsigned* __restrict__ keys, int* __restrict__ plan,
-                                                       DcTilePlan L) {
+// (round 6: ONE kernel.  The keys were a launch of their own -- workgroup (cloud, 256 points) -- that wrote one word per point for
+//  the ranking workgroups to read back; every ranking workgroup now forms the cloud's keys itself, straight into LDS: the bounding
+//  box and the Morton codes of N points are N x 24 bytes of cached reads and a few dozen operations per point, less than the
+//  launch they replace.  min / max are exact, so the keys -- and the order -- are the same bits.)
+__global__ __launch_bounds__(256) void tile_rank_kernel(const float* __restrict__ pos, const int* __restrict__ cloud_ptr,
+                                                        int num_clouds, int* __restrict__ plan, DcTilePlan L) {
+    __shared__ __attribute__((aligned(16))) unsigned key[MAX_CLOUD];
     __shared__ float red[6][4];
     __shared__ int tred[4];
     const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int begin = cloud_ptr[b], N = cloud_ptr[b + 1] - begin;
-    if (chunk == 0) {                                      // block-uniform
-        const int tile0 = block_tile_base(cloud_ptr, b, L.P, tred);
+    if (chunk * 64 >= N && chunk != 0) return;             // block-uniform
+    const int tile0 = block_tile_base(cloud_ptr, b, L.P, tred);
+    if (chunk == 0) {                                      // the cloud's tile range: -1 padding behind the last point, zero unique-row counts
         const int tile1 = b + 1 < num_clouds ? tile0 + (max(N, 0) + L.P - 1) / L.P : L.T;   // the last cloud also clears the unused ids
         int* pts = plan + L.o_pts + (long)tile0 * L.P;
         for (int i = max(N, 0) + tid; i < (tile1 - tile0) * L.P; i += 256) pts[i] = -1;
         for (int t = tile0 + tid; t < tile1; t += 256) plan[L.o_nu + t] = 0;
+        if (N <= 0) return;
     }
-    if (chunk * 256 >= N) return;                          // block-uniform
+    // bounding box of the cloud
     float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     for (int i = tid; i < N; i += 256)
 #pragma unroll
@@ -99,9 +103,7 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const float* __restrict__
             red[3 + a][tid >> 6] = hi[a];
         }
     __syncthreads();
-    const int i = chunk * 256 + tid;
-    if (i >= N) return;
-    unsigned q[3];
+    float l3[3], inv3[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float l = red[a][0], h = red[3 + a][0];
@@ -109,23 +111,22 @@ __global__ __launch_bounds__(256) void tile_key_kernel(const float* __restrict__
             l = fminf(l, red[a][w]);
             h = fmaxf(h, red[3 + a][w]);
         }
-        const float inv = h > l ? 64.f / (h - l) : 0.f;
-        q[a] = (unsigned)min(63, max(0, (int)((pos[(long)(begin + i) * 3 + a] - l) * inv)));
+        l3[a] = l;
+        inv3[a] = h > l ? 64.f / (h - l) : 0.f;
     }
-    const unsigned m = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-    keys[begin + i] = (m << 12) | (unsigned)i;
-}
-
-__global__ __launch_bounds__(256) void tile_rank_kernel(const unsigned* __restrict__ keys, const int* __restrict__ cloud_ptr,
-                                                        int* __restrict__ plan, DcTilePlan L) {
-    __shared__ __attribute__((aligned(16))) unsigned key[MAX_CLOUD];
-    __shared__ int tred[4];
-    const int b = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
-    const int begin = cloud_ptr[b], N = cloud_ptr[b + 1] - begin;
-    if (chunk * 64 >= N) return;                           // block-uniform
-    const int tile0 = block_tile_base(cloud_ptr, b, L.P, tred);
+    // the sort keys of the whole cloud: 18-bit Morton code above the 12-bit index inside the cloud (unique: a total, deterministic order)
     const int N16 = (N + 15) & ~15;
-    for (int i = tid; i < N16; i += 256) key[i] = i < N ? keys[begin + i] : 0xffffffffu;   // padding sorts last
+    for (int i = tid; i < N16; i += 256) {
+        unsigned kv = 0xffffffffu;                          // padding sorts last
+        if (i < N) {
+            unsigned q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                q[a] = (unsigned)min(63, max(0, (int)((pos[(long)(begin + i) * 3 + a] - l3[a]) * inv3[a])));
+            kv = ((spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2)) << 12) | (unsigned)i;
+        }
+        key[i] = kv;
+    }
     __syncthreads();
     const int i = chunk * 64 + (tid >> 2), sub = tid & 3;
     const unsigned mine = key[min(i, N - 1)];
@@ -441,10 +442,7 @@ DC_EXPORT int dc_tile_plan_build(const float* pos, const int32_t* nbr, const int
     if (num_points == 0 || num_clouds == 0) return DC_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const DcTilePlan L = dc_tile_plan_layout(dc_tile_plan_num_tiles(num_points, num_clouds, max_cloud, P), k, P);
-    unsigned* keys = reinterpret_cast<unsigned*>(plan + L.o_uniq);      // scratch: the uniq section is written afterwards
-    hipLaunchKernelGGL(tile_key_kernel, dim3(num_clouds, dc_cdiv(max_cloud, 256)), dim3(256), 0, s, pos, cloud_ptr, num_clouds, keys,
-                       plan, L);
-    hipLaunchKernelGGL(tile_rank_kernel, dim3(num_clouds, dc_cdiv(max_cloud, 64)), dim3(256), 0, s, keys, cloud_ptr, plan, L);
+    hipLaunchKernelGGL(tile_rank_kernel, dim3(num_clouds, dc_cdiv(max_cloud, 64)), dim3(256), 0, s, pos, cloud_ptr, num_clouds, plan, L);
     hipLaunchKernelGGL(tile_unique_kernel, dim3(L.T), dim3(256), 0, s, nbr, cloud_ptr, num_clouds, plan, L);
     DC_CHECK_LAUNCH("dc_tile_plan_build");
     return DC_OK;
