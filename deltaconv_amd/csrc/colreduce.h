@@ -29,12 +29,12 @@ __device__ __forceinline__ void stv(float* p, const FV<V>& a) {
 // ---- generic ordered column reduction: NQ quantities per element ------------------------------
 // grid = (row_chunks, col_tiles); partial[(chunk*NQ + q)*C + col] (double)
 template <int V, int NQ, class F>
-__global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int chunks, int rpc,
-                                                        double* __restrict__ partial) {
+__device__ __forceinline__ void colreduce_body(F& f, long R, int C, int chunks, int rpc, double* __restrict__ partial, int bx,
+                                               int by) {
     __shared__ double sm[NQ][RT][CT * V];
     const int cgl = threadIdx.x % CT, rl = threadIdx.x / CT;
-    const int c0 = (blockIdx.y * CT + cgl) * V;
-    const long r0 = (long)blockIdx.x * rpc;
+    const int c0 = (by * CT + cgl) * V;
+    const long r0 = (long)bx * rpc;
     const long r1 = min(r0 + rpc, R);
     double acc[NQ][V];   // fp64: sum x^2 - (sum x)^2 / R must survive cancellation (R can be 2)
 #pragma unroll
@@ -62,14 +62,30 @@ __global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int 
     __syncthreads();
     for (int idx = threadIdx.x; idx < NQ * CT * V; idx += TPB) {
         const int q = idx / (CT * V), cl = idx % (CT * V);
-        const int col = blockIdx.y * CT * V + cl;
+        const int col = by * CT * V + cl;
         if (col < C) {
             double s = 0;
 #pragma unroll
             for (int rr = 0; rr < RT; ++rr) s += sm[q][rr][cl];
-            partial[((long)q * C + col) * chunks + blockIdx.x] = s;   // [q][col][chunk]
+            partial[((long)q * C + col) * chunks + bx] = s;   // [q][col][chunk]
         }
     }
+}
+template <int V, int NQ, class F>
+__global__ __launch_bounds__(TPB) void colreduce_kernel(F f, long R, int C, int chunks, int rpc,
+                                                        double* __restrict__ partial) {
+    colreduce_body<V, NQ, F>(f, R, C, chunks, rpc, partial, blockIdx.x, blockIdx.y);
+}
+// two reductions of the same kind in one launch (deferred first stages, common.h): blockIdx.z picks the parameter set
+template <int V, int NQ, class F>
+__global__ __launch_bounds__(TPB) void colreduce_pair_kernel(F f0, F f1, long R0, long R1, int C0, int C1, int chunks0, int chunks1,
+                                                             int rpc0, int rpc1, double* __restrict__ partial0,
+                                                             double* __restrict__ partial1) {
+    const bool second = blockIdx.z != 0;
+    const int chunks = second ? chunks1 : chunks0, C = second ? C1 : C0;
+    if ((int)blockIdx.x >= chunks || (int)blockIdx.y * CT * V >= C) return;      // (grid = the larger of the two)
+    if (second) colreduce_body<V, NQ, F>(f1, R1, C1, chunks1, rpc1, partial1, blockIdx.x, blockIdx.y);
+    else colreduce_body<V, NQ, F>(f0, R0, C0, chunks0, rpc0, partial0, blockIdx.x, blockIdx.y);
 }
 
 // Final stage: one wave per column, lanes stride the chunks of both quantities, butterfly reduce

@@ -82,9 +82,14 @@ struct DcFinPending {
     int kind, chunks, C;
     const double* partial;
     alignas(8) unsigned char blob[DC_FIN_BLOB];       // the finaliser object (dccol::BnFin / BwdCoefFin), copied by bytes
+    // the reduction's FIRST stage, when that is queued too (BatchNorm-backward reductions: two of them run as one launch)
+    int stage1, rpc;                                  // stage1 != 0: not launched yet
+    long R;
+    alignas(8) unsigned char functor[DC_FIN_BLOB];    // the row functor (nn.hip: BnBwdF<4>), copied by bytes
 };
 bool dc_fin_take_request();                           // true once after dc_finaliser_defer_next() inside an open batch with room
-void dc_fin_push(int kind, const double* partial, int chunks, int C, const void* fin, size_t bytes);
+void dc_fin_push(int kind, const double* partial, int chunks, int C, const void* fin, size_t bytes, const void* functor = nullptr,
+                 size_t functor_bytes = 0, long R = 0, int rpc = 0);
 int dc_fin_pending(DcFinPending** out);               // -> count (and the queue)
 void dc_fin_clear();
 unsigned long long* dc_stamp_next(int tag);        // host side; nullptr when stamping is off or the records are used up

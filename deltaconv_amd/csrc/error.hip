@@ -57,10 +57,13 @@ bool dc_fin_take_request() {
     g_fin_request = false;
     return take;
 }
-void dc_fin_push(int kind, const double* partial, int chunks, int C, const void* fin, size_t bytes) {
+void dc_fin_push(int kind, const double* partial, int chunks, int C, const void* fin, size_t bytes, const void* functor,
+                 size_t functor_bytes, long R, int rpc) {
     DcFinPending& e = g_fin[g_fin_count++];
     e.kind = kind; e.partial = partial; e.chunks = chunks; e.C = C;
     memcpy(e.blob, fin, bytes);
+    e.stage1 = functor != nullptr; e.R = R; e.rpc = rpc;
+    if (functor) memcpy(e.functor, functor, functor_bytes);
 }
 int dc_fin_pending(DcFinPending** out) { *out = g_fin; return g_fin_count; }
 void dc_fin_clear() { g_fin_count = 0; g_fin_open = false; g_fin_request = false; }

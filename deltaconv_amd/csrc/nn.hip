@@ -659,9 +659,15 @@ DC_EXPORT int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const flo
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Ws w = carve(workspace, R, C);
     const BwdCoefFin fin{(long)R, gamma, scale, shift, mean, invstd, training, dgamma, dbeta, coefs, C};
-    if (C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && al16(dy) && al16(h))
-        run_colreduce<4>(BnBwdF<4>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin, DC_COLRED_BLOCKS,
-                         DC_FIN_BWD_COEF);
+    if (C % 4 == 0 && lddy % 4 == 0 && ldh % 4 == 0 && al16(dy) && al16(h)) {
+        const BnBwdF<4> f{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope};
+        static_assert(sizeof(f) <= DC_FIN_BLOB, "row functor larger than the queue's blob");
+        if (dc_fin_take_request()) {             // inside a batch, announced: BOTH stages wait for dc_finalisers_end
+            dc_fin_push(DC_FIN_BWD_COEF, w.partial, chunks_of(R, C), C, &fin, sizeof(fin), &f, sizeof(f), (long)R, rows_per_chunk(R, C));
+            return DC_OK;
+        }
+        run_colreduce<4>(f, R, C, w, s, fin);
+    }
     else
         run_colreduce<1>(BnBwdF<1>{dy, h, scale, shift, mean, invstd, (long)lddy, (long)ldh, slope}, R, C, w, s, fin, DC_COLRED_BLOCKS,
                          DC_FIN_BWD_COEF);
@@ -673,8 +679,35 @@ DC_EXPORT int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const flo
 // and dc_bn_act_backward_reduce calls announced by dc_finaliser_defer_next); discard != 0 drops the queue instead (error paths).
 // The coefficient outputs of the queued calls are valid behind this launch; their workspaces must stay alive until then.
 DC_EXPORT int dc_finalisers_end(int32_t discard, void* stream) {
-    if (discard) dc_fin_clear();
-    else flush_finalisers(static_cast<hipStream_t>(stream));
+    if (discard) {
+        dc_fin_clear();
+        return DC_OK;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // queued FIRST stages (BatchNorm-backward reductions): two of them as one launch, a single one as it would have run
+    DcFinPending* q;
+    const int n = dc_fin_pending(&q);
+    int idx[DC_FIN_MAX], m = 0;
+    for (int i = 0; i < n; ++i)
+        if (q[i].stage1) idx[m++] = i;
+    for (int j = 0; j < m; j += 2) {
+        BnBwdF<4> f0, f1;
+        DcFinPending& a = q[idx[j]];
+        memcpy(&f0, a.functor, sizeof(f0));
+        if (j + 1 < m) {
+            DcFinPending& b = q[idx[j + 1]];
+            memcpy(&f1, b.functor, sizeof(f1));
+            const dim3 grid(std::max(a.chunks, b.chunks), dc_cdiv(std::max(a.C, b.C), CT * 4), 2);
+            hipLaunchKernelGGL((colreduce_pair_kernel<4, 2, BnBwdF<4>>), grid, dim3(TPB), 0, s, f0, f1, a.R, b.R, a.C, b.C, a.chunks,
+                               b.chunks, a.rpc, b.rpc, const_cast<double*>(a.partial), const_cast<double*>(b.partial));
+            b.stage1 = 0;
+        } else {
+            hipLaunchKernelGGL((colreduce_kernel<4, 2, BnBwdF<4>>), dim3(a.chunks, dc_cdiv(a.C, CT * 4)), dim3(TPB), 0, s, f0, a.R, a.C,
+                               a.chunks, a.rpc, const_cast<double*>(a.partial));
+        }
+        a.stage1 = 0;
+    }
+    flush_finalisers(s);
     DC_CHECK_LAUNCH("dc_finalisers_end");
     return DC_OK;
 }
