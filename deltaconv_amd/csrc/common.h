@@ -87,6 +87,9 @@ struct DcFinPending {
     long R;
     alignas(8) unsigned char functor[DC_FIN_BLOB];    // the row functor (nn.hip: BnBwdF<4>), copied by bytes
 };
+bool dc_gemm_take_request();                          // true once after dc_gemm_defer_next() inside an open batch whose finaliser request is pending too
+void dc_gemm_flush(void* stream);                     // gemm.hip: launches the queued dense products (two of one kind as one launch)
+void dc_gemm_discard();
 bool dc_fin_take_request();                           // true once after dc_finaliser_defer_next() inside an open batch with room
 void dc_fin_push(int kind, const double* partial, int chunks, int C, const void* fin, size_t bytes, const void* functor = nullptr,
                  size_t functor_bytes = 0, long R = 0, int rpc = 0);

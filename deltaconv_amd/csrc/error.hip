@@ -51,7 +51,12 @@ bool dc_ensure_lds(unsigned long long* done_mask, const void* kernel, size_t byt
 // ---- deferred finalisers (common.h) -------------------------------------------------------------------------------------------
 static thread_local DcFinPending g_fin[DC_FIN_MAX];
 static thread_local int g_fin_count = 0;
-static thread_local bool g_fin_open = false, g_fin_request = false;
+static thread_local bool g_fin_open = false, g_fin_request = false, g_gemm_request = false;
+bool dc_gemm_take_request() {
+    const bool take = g_fin_open && g_gemm_request && g_fin_request;   // (a queued product needs its finaliser queued behind it)
+    g_gemm_request = false;
+    return take;
+}
 bool dc_fin_take_request() {
     const bool take = g_fin_open && g_fin_request && g_fin_count < DC_FIN_MAX;
     g_fin_request = false;
@@ -66,7 +71,7 @@ void dc_fin_push(int kind, const double* partial, int chunks, int C, const void*
     if (functor) memcpy(e.functor, functor, functor_bytes);
 }
 int dc_fin_pending(DcFinPending** out) { *out = g_fin; return g_fin_count; }
-void dc_fin_clear() { g_fin_count = 0; g_fin_open = false; g_fin_request = false; }
+void dc_fin_clear() { g_fin_count = 0; g_fin_open = false; g_fin_request = false; g_gemm_request = false; }
 DC_EXPORT int dc_finalisers_begin(void) {
     if (g_fin_open) {
         dc_set_error("dc_finalisers_begin: a batch is already open on this thread");
@@ -77,6 +82,10 @@ DC_EXPORT int dc_finalisers_begin(void) {
 }
 DC_EXPORT int dc_finaliser_defer_next(void) {
     g_fin_request = g_fin_open;
+    return DC_OK;
+}
+DC_EXPORT int dc_gemm_defer_next(void) {
+    g_gemm_request = g_fin_open;
     return DC_OK;
 }
 

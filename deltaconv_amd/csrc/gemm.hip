@@ -182,7 +182,7 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
 }
 
 template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0, int X3 = 0, int BP = 0>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_body(const GemmP& p, const unsigned bid, const unsigned gemm_blocks) {
     static_assert(!BP || (X3 == 2 && AL == A_MK && BL == B_NK && MODE == 0), "pre-split B planes: pipelined split loop, K-contiguous operands, whole tiles");
     constexpr bool FAST = MODE == 0;               // no guards anywhere (loads, statistics, stores)
     // guarded modes per operand: 1 = 16-byte loads, 2 = dword loads.  MODE 1: both vector, 2: both scalar, 3: A vector /
@@ -205,9 +205,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
     // workgroup placed on the CU) by about half a K loop in the first round puts one workgroup's epilogue under the
     // other's K loop for the rest of the launch.
     DC_STAMP(0);
-    const unsigned gemm_blocks = gridDim.x;
-    const unsigned bid = blockIdx.x;
-    if (p.stagger > 0 && (long)blockIdx.y * gridDim.x + bid < p.resident) {
+    if (p.stagger > 0 && (long)blockIdx.y * gemm_blocks + bid < p.resident) {
         const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);      // HW_REG_HW_ID bits [3:0]
         if (slot & 1) {
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -872,6 +870,18 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
 #endif
 }
 
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0, int X3 = 0, int BP = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_kernel(GemmP p) {
+    gemm_body<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>(p, blockIdx.x, gridDim.x);
+}
+// Two products of the SAME instantiation in one launch (round 6: the max-aggregation stream's and the s_mlp's last products of a
+// DeltaConv layer are independent): the first nb0 workgroups multiply p0, the rest p1 -- the body is the single kernel's.
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO = 0, int X3 = 0, int BP = 0>
+__global__ __launch_bounds__(NT, 2) void gemm_pair_kernel(GemmP p0, GemmP p1, unsigned nb0) {
+    if (blockIdx.x < nb0) gemm_body<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>(p0, blockIdx.x, nb0);
+    else gemm_body<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>(p1, blockIdx.x - nb0, gridDim.x - nb0);
+}
+
 struct Tile { int bm, bn; };
 
 Tile pick_tile(long M, int N, int K, int tile) {
@@ -901,11 +911,46 @@ size_t lds_bytes(int bm, int bn, int al, int bl) {
     return std::max(2 * (a + b), (size_t)bm * bn) * sizeof(float);      // operand ring | output staging
 }
 
+// ---- deferred products (common.h: deferred finalisers): a forward product with the statistics epilogue whose caller asked for it
+// waits in this queue until dc_finalisers_end; two queued products of the same instantiation run as ONE launch (gemm_pair_kernel).
+typedef void (*GemmSingleFn)(const GemmP&, unsigned, size_t, hipStream_t);
+typedef void (*GemmPairFn)(const GemmP&, const GemmP&, unsigned, unsigned, size_t, hipStream_t);
+struct GemmPending { GemmP p; unsigned blocks; size_t lds; GemmSingleFn single; GemmPairFn pair; };
+static thread_local GemmPending g_gemm_q[DC_FIN_MAX];
+static thread_local int g_gemm_n = 0;
+
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO, int X3, int BP>
+void gemm_single_thunk(const GemmP& p, unsigned blocks, size_t lds, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>), dim3(blocks, 1), dim3(NT), lds, s, p);
+}
+template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO, int X3, int BP>
+void gemm_pair_thunk(const GemmP& p0, const GemmP& p1, unsigned b0, unsigned b1, size_t lds, hipStream_t s) {
+    static unsigned long long configured = 0;
+    if (!dc_ensure_lds(&configured, reinterpret_cast<const void*>(&gemm_pair_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>), lds, "dense product pair"))
+        return;
+    GemmP q1 = p1;
+    q1.stagger = 0;                         // (the phase shift is a first-round device: the second product's workgroups come later)
+    hipLaunchKernelGGL((gemm_pair_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>), dim3(b0 + b1, 1), dim3(NT), lds, s, p0, q1, b0);
+}
+
 template <int BM, int BN, int AL, int BL, int MODE, int EPI, int PRO, int X3, int BP = 0>
 void launch_one(const GemmP& p, long tiles_m, int slabs, hipStream_t s) {
     static unsigned long long configured = 0;
     const size_t lds = lds_bytes(BM, BN, AL, BL);
     if (!dc_ensure_lds(&configured, reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>), lds, "dense product")) return;
+    // the pairable kind: forward product from the step's weight planes with the BatchNorm-statistics epilogue (whole tiles)
+    constexpr bool PAIRABLE = EPI == EPI_COLSTATS && BP == 1 && MODE == 0 && PRO == 0 && AL == A_MK && BL == B_NK;
+    if (dc_gemm_take_request()) {           // (always consumed, whatever the kind)
+        if constexpr (PAIRABLE) {
+            if (slabs == 1 && g_gemm_n < DC_FIN_MAX) {
+                GemmPending& e = g_gemm_q[g_gemm_n++];
+                e.p = p; e.blocks = (unsigned)(tiles_m * p.tiles_n); e.lds = lds;
+                e.single = &gemm_single_thunk<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>;
+                e.pair = &gemm_pair_thunk<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>;
+                return;
+            }
+        }
+    }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AL, BL, MODE, EPI, PRO, X3, BP>),
                        dim3((unsigned)(tiles_m * p.tiles_n), (unsigned)slabs), dim3(NT), lds, s, p);
 }
@@ -1051,6 +1096,22 @@ int chunks_for(long M, int N, int K, int tile) {
 }
 
 }  // namespace
+
+void dc_gemm_flush(void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < g_gemm_n;) {
+        GemmPending& a = g_gemm_q[i];
+        if (i + 1 < g_gemm_n && g_gemm_q[i + 1].pair == a.pair && g_gemm_q[i + 1].lds == a.lds) {
+            a.pair(a.p, g_gemm_q[i + 1].p, a.blocks, g_gemm_q[i + 1].blocks, a.lds, s);
+            i += 2;
+        } else {
+            a.single(a.p, a.blocks, a.lds, s);
+            i += 1;
+        }
+    }
+    g_gemm_n = 0;
+}
+void dc_gemm_discard() { g_gemm_n = 0; }
 
 // ---- weight gradient through the LDS-staged kernel (called by dc_gemm_tn, gemm_tn.hip) ----------------------------
 // partial[slab][M][N] = A[rows of the slab, M]^T B[rows of the slab, N];  returns the number of slabs.

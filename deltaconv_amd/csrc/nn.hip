@@ -680,10 +680,12 @@ DC_EXPORT int dc_bn_act_backward_reduce(const float* dy, int64_t lddy, const flo
 // The coefficient outputs of the queued calls are valid behind this launch; their workspaces must stay alive until then.
 DC_EXPORT int dc_finalisers_end(int32_t discard, void* stream) {
     if (discard) {
+        dc_gemm_discard();
         dc_fin_clear();
         return DC_OK;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    dc_gemm_flush(stream);                    // queued dense products first: their statistics partials feed the finalisers below
     // queued FIRST stages (BatchNorm-backward reductions): two of them as one launch, a single one as it would have run
     DcFinPending* q;
     const int n = dc_fin_pending(&q);

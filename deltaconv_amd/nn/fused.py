@@ -736,6 +736,7 @@ def tn_batch():
 # queue; `linear_stats(..., defer_final=True)` / `bn_block_reduce(..., defer_final=True)` inside it queue their finaliser; the
 # coefficients are valid when the block exits.  DC_FIN_BATCH=0: every finaliser is its own launch (A/B: same bits).
 USE_FIN_BATCH = [os.environ.get("DC_FIN_BATCH", "1") != "0"]
+USE_GEMM_PAIR = [os.environ.get("DC_GEMM_PAIR", "1") != "0"]     # the two queued forward products of a layer node as one launch
 _FIN = threading.local()
 
 
@@ -766,6 +767,8 @@ def _defer_final(*keepalive):
         return False
     keep.extend(keepalive)
     lib.raw("dc_finaliser_defer_next")()
+    if USE_GEMM_PAIR[0]:
+        lib.raw("dc_gemm_defer_next")()     # (consumed by the call's product, if it has one of the pairable kind)
     return True
 
 

@@ -55,6 +55,9 @@ int dc_set_option(int32_t key, int32_t value);
  * queued calls are valid behind dc_finalisers_end; their workspaces must stay alive until then.  Thread-local host state. */
 int dc_finalisers_begin(void);
 int dc_finaliser_defer_next(void);
+/* with it: the dense product of the announced dc_linear_bn_stats_forward call (weight planes, whole tiles) waits as well; two
+ * queued products of one kernel instantiation run as ONE launch at dc_finalisers_end (same arithmetic per element: same bits) */
+int dc_gemm_defer_next(void);
 int dc_finalisers_end(int32_t discard, void* stream);
 
 /* Measurement aid (bench.py `roofline.frac`): device-clock stamps of the tiled two-piece forward applies and the tiled transposed applies.  After

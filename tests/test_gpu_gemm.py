@@ -568,7 +568,7 @@ def test_batched_slab_reductions_write_the_same_bits():
         fused.USE_TN_BATCH[0] = True
 
 
-@pytest.mark.parametrize("switch", ["USE_TN_BATCH", "USE_FIN_BATCH"])
+@pytest.mark.parametrize("switch", ["USE_TN_BATCH", "USE_FIN_BATCH", "USE_GEMM_PAIR"])
 def test_layer_gradients_identical_with_and_without_batched_reductions(switch):
     """A DeltaConv model step with the slab sums batched per node (USE_TN_BATCH) / the finalisers of a node's independent column
     reductions in one launch (USE_FIN_BATCH) == the same step with one launch per weight / per reduction: logits, running
